@@ -1,0 +1,169 @@
+/*
+ * w3hip.h — C ABI of the MI355X-native weath3rb0i hot path (libw3hip.so).
+ *
+ * The reference (mitiko/weath3rb0i) is a CPU-only Rust crate with no FFI or
+ * plugin interface; its seams are Rust traits and two private functions in
+ * src/main.rs.  This header is the drop-in boundary a Rust shim would bind
+ * (see INTEGRATION.md for the `extern "C"` block).  Each entry point cites
+ * the reference interface it replaces (paths under /root/reference/src).
+ *
+ * Conventions: plain pointers and sizes; caller owns every buffer; every call
+ * returns 0 (W3_OK) or a negative W3_E_* code — nothing panics or throws
+ * across the ABI (the reference aborts on panic, Cargo.toml:24).  A w3_ctx is
+ * bound to one GPU and is NOT thread-safe (the reference is single-threaded,
+ * Cargo.toml:14-15).  There is no CPU fallback: without a HIP device
+ * w3_ctx_create fails with W3_E_HIP.
+ */
+#ifndef W3HIP_H
+#define W3HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define W3_ABI_VERSION 1
+
+/* ---- error codes --------------------------------------------------------- */
+enum {
+    W3_OK            =  0,
+    W3_E_INVALID     = -1,  /* bad argument / malformed model spec                    */
+    W3_E_NOSPACE     = -2,  /* out_cap too small; *out_len holds the size needed      */
+    W3_E_HIP         = -3,  /* HIP runtime error (w3_last_error has the text)         */
+    W3_E_UNSUPPORTED = -4,  /* valid spec the device path does not implement          */
+    W3_E_NOMEM       = -5,  /* device workspace does not fit                          */
+    W3_E_FORMAT      = -6   /* bad container magic (main.rs:123-124 assert_eq!)       */
+};
+
+/* ---- model spec ----------------------------------------------------------
+ * Mirrors the compile-time composition done in init_model() (main.rs:146-152)
+ * as a caller-owned, read-only POD: the model tree in POSTFIX order.
+ *   leaf  W3_NODE_ORDERN : OrderN::new(bits, align)              models/ordern.rs:14-23
+ *                          history = W3_HIST_RAW / W3_HIST_AC makes it
+ *                          OrderNEntropy::new(bits, align, hist) models/ordern_entropy.rs:15-24
+ *                          (RawHistory history/raw_history.rs; ACHistory::new(max_bits,
+ *                          StationaryModel::from_table(table)) history/ac_history.rs:16-19)
+ *                          frozen=1 wraps it in FrozenModel      models/frozen.rs:7-11
+ *                          Order0 == (11,3), Order1 == (19,3)    models/order0.rs, order1.rs
+ *                          (bijective re-indexing, bin/cmp/main.rs:14-24)
+ *   node  W3_NODE_BEST_OF_TWO : BestOfTwoModel::new(a, b)        models/mod.rs:42-75
+ *                          pops the two preceding subtrees (a pushed first).
+ */
+enum { W3_NODE_ORDERN = 1, W3_NODE_BEST_OF_TWO = 2 };
+enum { W3_HIST_NONE = 0, W3_HIST_RAW = 1, W3_HIST_AC = 2 };
+#define W3_MAX_NODES  31
+#define W3_MAX_LEAVES 16
+
+typedef struct w3_node {
+    uint8_t  kind;      /* W3_NODE_*                                  */
+    uint8_t  bits;      /* bits_in_context   (1..32)                  */
+    uint8_t  align;     /* alignment_bits    (0..7, <= bits)          */
+    uint8_t  history;   /* W3_HIST_*                                  */
+    uint8_t  max_bits;  /* ACHistory max_bits (0..32)                 */
+    uint8_t  frozen;    /* 1 = FrozenModel wrapper                    */
+    uint8_t  reserved[2];
+    uint16_t table[8];  /* StationaryModel table, index 0 = MSB       */
+} w3_node;
+
+typedef struct w3_model_spec {
+    uint32_t n_nodes;
+    w3_node  nodes[W3_MAX_NODES];
+} w3_model_spec;
+
+/* ---- lifecycle ------------------------------------------------------------ */
+typedef struct w3_ctx w3_ctx;
+
+/* One ctx per process and GPU; owns device workspace + a HIP stream. */
+int         w3_ctx_create(int device, w3_ctx **out);
+void        w3_ctx_destroy(w3_ctx *ctx);
+const char *w3_strerror(int code);
+const char *w3_last_error(const w3_ctx *ctx);
+int         w3_abi_version(void);
+
+/* 0 if the spec is well-formed AND implemented on the device. */
+int         w3_spec_validate(const w3_model_spec *spec);
+
+/* Options */
+enum {
+    W3_OPT_PATH   = 1,  /* W3_PATH_*: which device implementation encode uses      */
+    W3_OPT_TIMING = 2   /* 1 = record per-kernel hipEvent timings (w3_get_timing) */
+};
+enum { W3_PATH_AUTO = 0, W3_PATH_GENERIC = 1, W3_PATH_TWOPHASE = 2 };
+int         w3_ctx_set_option(w3_ctx *ctx, int opt, int64_t value);
+
+/* Upper bound on the concatenated block streams for n input bytes. */
+size_t      w3_max_compressed_size(size_t n, size_t block_size);
+
+/* ---- block encode / decode (host buffers) ---------------------------------
+ * Replaces the bit loop of compress()/decompress() (main.rs:99-111, 127-140)
+ * run once per block with a fresh model + coder: block b's stream is exactly
+ * what the reference writes after its 12-byte header for a file holding only
+ * that block.  Streams are byte-aligned (ACWriter::flush, io.rs:91-100) and
+ * concatenated in block order; block_lens[ceil(n/block_size)] gets the sizes.
+ * *out_len is set even on W3_E_NOSPACE.                                       */
+int w3_encode_blocks(w3_ctx *ctx, const w3_model_spec *spec,
+                     const uint8_t *in, size_t n, size_t block_size,
+                     uint8_t *out, size_t out_cap, size_t *out_len, uint32_t *block_lens);
+
+int w3_decode_blocks(w3_ctx *ctx, const w3_model_spec *spec,
+                     const uint8_t *in, const uint32_t *block_lens, size_t nblocks,
+                     size_t block_size, uint64_t orig_len, uint8_t *out);
+
+/* ---- same, device-resident (no PCIe in the call) ---------------------------
+ * d_* are device pointers on ctx's GPU.  `stream` is a hipStream_t (NULL =
+ * the ctx's own stream); the call only enqueues work and reads back one
+ * status word, so it can be timed with events on that stream.
+ * d_block_lens[nblocks] u32, d_total[1] u64.                                  */
+int w3_encode_blocks_device(w3_ctx *ctx, const w3_model_spec *spec,
+                            const uint8_t *d_in, size_t n, size_t block_size,
+                            uint8_t *d_out, size_t out_cap,
+                            uint32_t *d_block_lens, uint64_t *d_total, void *stream);
+
+int w3_decode_blocks_device(w3_ctx *ctx, const w3_model_spec *spec,
+                            const uint8_t *d_in, const uint32_t *d_block_lens, size_t nblocks,
+                            size_t block_size, uint64_t orig_len, uint8_t *d_out, void *stream);
+
+/* ---- the reference's whole-file container ----------------------------------
+ * compress()/decompress() of main.rs:89-144: b"w30i" + u64 BE length + ONE
+ * stream.  One serial chain => one GPU lane; provided for format parity.     */
+int w3_compress_stream(w3_ctx *ctx, const w3_model_spec *spec,
+                       const uint8_t *in, size_t n, uint8_t *out, size_t out_cap, size_t *out_len);
+int w3_decompress_stream(w3_ctx *ctx, const w3_model_spec *spec,
+                         const uint8_t *in, size_t in_len, uint8_t *out, size_t out_cap, size_t *out_len);
+
+/* ---- per-step probabilities (Model::predict for every bit of every block) --
+ * models/mod.rs:12-15 evaluated by the device predict phase; p_out[8*n] u16.
+ * Lets a test drive the model surface without the coder.                      */
+int w3_predict_blocks(w3_ctx *ctx, const w3_model_spec *spec,
+                      const uint8_t *in, size_t n, size_t block_size, uint16_t *p_out);
+
+/* ---- StationaryModel::new(buf) (models/ac_hash/stationary.rs:14-34) ---------
+ * Host-side table preparation for ACHistory: 8 Counters by bit position walked
+ * over `buf`, table[i] = p().  Model construction, not the hot path.          */
+int w3_stationary_table(const uint8_t *buf, size_t n, uint16_t table[8]);
+
+/* ---- device self-test ---------------------------------------------------------
+ * Exhaustively compares the kernels' division-free Counter::p with the literal
+ * u64 formula (models/counter.rs:13-18) for all 2^32 (c0,c1) states, on the GPU. */
+int w3_selftest_counter_p(w3_ctx *ctx, uint64_t *mismatches);
+
+/* ---- timing of the last encode call (W3_OPT_TIMING=1) ----------------------- */
+typedef struct w3_timing {
+    float    predict_ms;   /* context + rank + Counter::p kernels            */
+    float    coder_ms;     /* lane-per-block arithmetic coder kernel         */
+    float    pack_ms;      /* scan + compaction of the block streams         */
+    float    generic_ms;   /* fused lane-per-block kernel (generic path)     */
+    float    total_ms;
+    uint32_t path;         /* W3_PATH_* actually taken                       */
+    uint32_t n_coder_launches;
+    uint64_t coder_bytes;  /* algorithmic HBM bytes of the coder launches    */
+    uint64_t predict_bytes;
+} w3_timing;
+int w3_get_timing(const w3_ctx *ctx, w3_timing *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,172 @@
+"""GPU parity: the HIP path (through the C ABI) against the CPU oracle, byte for byte."""
+import hashlib
+
+import numpy as np
+import pytest
+
+import weath3rb0i_amd as w3
+from tests.synth import lcg_text, markov_text, mixed_bytes
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = w3.Context(0)
+    yield c
+    c.close()
+
+
+def pair(oracle, name):
+    """(device model, oracle model factory) for a named configuration."""
+    book1 = [1, 50188, 62497, 15819, 22545, 31499, 22988, 29616]
+    enwik7 = [752, 50314, 58928, 21421, 24680, 30788, 24297, 32530]
+    table = {
+        "order0": (lambda: w3.Order0(), lambda: oracle.Order0()),
+        "order1": (lambda: w3.Order1(), lambda: oracle.Order1()),
+        "order2": (lambda: w3.OrderN(27, 3), lambda: oracle.OrderN(27, 3)),
+        "ordern_12_0": (lambda: w3.OrderN(12, 0), lambda: oracle.OrderN(12, 0)),
+        "ordern_14_4": (lambda: w3.OrderN(14, 4), lambda: oracle.OrderN(14, 4)),
+        "ordern_9_1": (lambda: w3.OrderN(9, 1), lambda: oracle.OrderN(9, 1)),
+        "ordern_8_3": (lambda: w3.OrderN(8, 3), lambda: oracle.OrderN(8, 3)),
+        "ordern_22_2": (lambda: w3.OrderN(22, 2), lambda: oracle.OrderN(22, 2)),
+        "ordern_30_3": (lambda: w3.OrderN(30, 3), lambda: oracle.OrderN(30, 3)),
+        "raw_16_3": (lambda: w3.OrderNEntropy(16, 3, w3.RawHistory()), lambda: oracle.OrderNEntropy(16, 3, oracle.RawHistory())),
+        "main_default": (lambda: w3.init_model(),
+                         lambda: oracle.OrderNEntropy(11, 3, oracle.ACHistory(8, oracle.StationaryModel.from_table(book1)))),
+        "ac_19_3_enwik7": (lambda: w3.OrderNEntropy(19, 3, w3.ACHistory(16, w3.StationaryModel.for_enwik7())),
+                           lambda: oracle.OrderNEntropy(19, 3, oracle.ACHistory(16, oracle.StationaryModel.from_table(enwik7)))),
+        "ac_10_2_mb0": (lambda: w3.OrderNEntropy(10, 2, w3.ACHistory(0, w3.StationaryModel.for_book1())),
+                        lambda: oracle.OrderNEntropy(10, 2, oracle.ACHistory(0, oracle.StationaryModel.from_table(book1)))),
+        "frozen0": (lambda: w3.FrozenModel(w3.Order0()), lambda: oracle.FrozenModel(oracle.Order0())),
+        "best01": (lambda: w3.BestOfTwoModel(w3.Order0(), w3.Order1()), lambda: oracle.BestOfTwoModel(oracle.Order0(), oracle.Order1())),
+        "best012": (lambda: w3.BestOfTwoModel(w3.BestOfTwoModel(w3.Order0(), w3.Order1()), w3.OrderN(27, 3)),
+                    lambda: oracle.BestOfTwoModel(oracle.BestOfTwoModel(oracle.Order0(), oracle.Order1()), oracle.OrderN(27, 3))),
+        "best_right": (lambda: w3.BestOfTwoModel(w3.Order1(), w3.BestOfTwoModel(w3.FrozenModel(w3.Order0()), w3.Order0())),
+                       lambda: oracle.BestOfTwoModel(oracle.Order1(), oracle.BestOfTwoModel(oracle.FrozenModel(oracle.Order0()), oracle.Order0()))),
+    }
+    return table[name]
+
+
+def check_blocks(ctx, oracle, name, data, bs, path):
+    dev, orc = pair(oracle, name)
+    ctx.set_path(path)
+    try:
+        out, lens = ctx.encode_blocks(dev(), data, bs)
+    finally:
+        ctx.set_path("auto")
+    want, wlens = oracle.encode_blocks(orc(), data, bs, nthreads=8)
+    assert lens.tolist() == wlens.tolist(), (name, path)
+    assert out.tobytes() == want.tobytes(), (name, path)
+    return out, lens
+
+
+ALL = ["order0", "order1", "order2", "ordern_12_0", "ordern_14_4", "ordern_9_1", "ordern_8_3", "ordern_22_2", "ordern_30_3",
+       "raw_16_3", "main_default", "ac_19_3_enwik7", "ac_10_2_mb0", "frozen0", "best01", "best012", "best_right"]
+
+
+def test_counter_p_exhaustive(ctx):
+    import ctypes as C
+    bad = C.c_uint64(123)
+    assert ctx.lib.w3_selftest_counter_p(ctx.h, C.byref(bad)) == 0
+    assert bad.value == 0
+
+
+@pytest.mark.parametrize("name", ALL)
+def test_generic_path_all_models(ctx, oracle, name):
+    data = markov_text(40000, seed=11) + lcg_text(9000, seed=2)
+    out, lens = check_blocks(ctx, oracle, name, data, 4096, "generic")
+    dev, orc = pair(oracle, name)
+    back = ctx.decode_blocks(dev(), out, lens, 4096, len(data))
+    assert back.tobytes() == data
+
+
+def test_survey_digests_on_device(ctx, oracle):
+    d = lcg_text(65536)
+    for m, n, sha in [(w3.Order0(), 43693, "37791f2604aaa6d6a81de79dbeb80ef09e25581d28c95f5cd5b411848aa7c64d"),
+                      (w3.Order1(), 49588, "5bceb3081cb21048473d483534b6f1cc901e1ac04fb1858ea303c994cf1fb7dc"),
+                      (w3.BestOfTwoModel(w3.Order0(), w3.Order1()), 45259, "19da6b5f594baf1395037f6ea2c497a8a0740806e3ceede028d20e7b6c09b518")]:
+        out, lens = ctx.encode_blocks(m, d, 65536)
+        assert lens.tolist() == [n] and hashlib.sha256(out.tobytes()).hexdigest() == sha
+
+
+@pytest.mark.parametrize("path", ["generic"])
+def test_edge_blocks(ctx, oracle, path):
+    bs = 65536
+    cases = {
+        "zeros": bytes(bs),                 # Counter halving at 65535
+        "ones": b"\xff" * bs,
+        "alt55": b"\x55" * 5000,
+        "single": b"A",
+        "bs_plus_1": lcg_text(4097, seed=5),
+        "bs_minus_1": lcg_text(4095, seed=6),
+        "ragged": lcg_text(3 * 4096 + 17, seed=7),
+        "random": np.random.default_rng(1).integers(0, 256, 20000, dtype=np.uint8).tobytes(),
+    }
+    assert ctx.encode_blocks(w3.Order0(), bytes(bs), bs)[0].tobytes() == b"\xff" * 16
+    assert ctx.encode_blocks(w3.Order0(), b"\xff" * bs, bs)[0].tobytes() == b"\x00" * 16 + b"\x01"
+    for cname, data in cases.items():
+        b = bs if cname in ("zeros", "ones") else 4096
+        for name in ("order0", "best012"):
+            out, lens = check_blocks(ctx, oracle, name, data, b, path)
+            dev, _ = pair(oracle, name)
+            assert ctx.decode_blocks(dev(), out, lens, b, len(data)).tobytes() == data, (cname, name)
+    out, lens = ctx.encode_blocks(w3.Order0(), b"", 4096)
+    assert len(out) == 0 and len(lens) == 0
+    assert len(ctx.decode_blocks(w3.Order0(), b"", [], 4096, 0)) == 0
+
+
+def test_nospace_and_errors(ctx):
+    import ctypes as C
+    from weath3rb0i_amd import _lib as L
+    data = np.frombuffer(lcg_text(8192, seed=9), dtype=np.uint8)
+    spec = w3.Order0().spec()
+    out = np.zeros(100, dtype=np.uint8)
+    lens = np.zeros(2, dtype=np.uint32)
+    olen = C.c_size_t()
+    rc = ctx.lib.w3_encode_blocks(ctx.h, C.byref(spec), data.ctypes.data_as(C.c_void_p), len(data), 4096,
+                                  out.ctypes.data_as(C.c_void_p), 100, C.byref(olen), lens.ctypes.data_as(C.c_void_p))
+    assert rc == L.W3_E_NOSPACE and olen.value > 100 and lens.sum() == olen.value
+    with pytest.raises(w3.W3Error) as e:
+        ctx.encode_blocks(w3.Order0(), data, 0)
+    assert e.value.code == L.W3_E_INVALID
+
+
+def test_reference_container(ctx, oracle):
+    d = markov_text(6000, seed=3)
+    book1 = [1, 50188, 62497, 15819, 22545, 31499, 22988, 29616]
+    want = oracle.compress(oracle.OrderNEntropy(11, 3, oracle.ACHistory(8, oracle.StationaryModel.from_table(book1))), d)
+    got = ctx.compress(d)  # init_model() default, main.rs:151
+    assert got == want and got[:4] == b"w30i"
+    assert ctx.decompress(got) == d
+    assert ctx.compress(b"") == oracle.compress(oracle.Order0(), b"")
+    assert ctx.decompress(ctx.compress(b"")) == b""
+    with pytest.raises(w3.W3Error) as e:
+        ctx.decompress(b"w31i" + bytes(20))
+    from weath3rb0i_amd import _lib as L
+    assert e.value.code == L.W3_E_FORMAT
+
+
+def test_mixed_bytes_256k_blocks(ctx, oracle):
+    data = mixed_bytes(600000, seed=5)
+    check_blocks(ctx, oracle, "best01", data, 262144, "generic")
+
+
+def test_device_resident_api(ctx, oracle):
+    import torch
+    data = markov_text(50000, seed=21)
+    bs = 8192
+    nb = (len(data) + bs - 1) // bs
+    d_in = torch.frombuffer(bytearray(data), dtype=torch.uint8).cuda()
+    d_out = torch.empty(2 * len(data) + 1024, dtype=torch.uint8, device="cuda")
+    d_lens = torch.zeros(nb, dtype=torch.int32, device="cuda")
+    d_total = torch.zeros(1, dtype=torch.int64, device="cuda")
+    ctx.encode_blocks_device(w3.Order0(), d_in, bs, d_out, d_lens, d_total, stream=torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    want, wlens = oracle.encode_blocks(oracle.Order0(), data, bs)
+    assert d_lens.cpu().numpy().astype(np.uint32).tolist() == wlens.tolist()
+    tot = int(d_total.item())
+    assert d_out[:tot].cpu().numpy().tobytes() == want.tobytes()
+    d_back = torch.empty(len(data), dtype=torch.uint8, device="cuda")
+    ctx.decode_blocks_device(w3.Order0(), d_out, d_lens, bs, len(data), d_back)
+    assert d_back.cpu().numpy().tobytes() == data

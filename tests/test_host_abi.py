@@ -1,0 +1,101 @@
+"""CPU-side checks of the product: the C-ABI library loads and exports every symbol
+include/w3hip.h declares, the host mirror builds the right specs, and the product
+never touches the oracle.  No compute calls (no GPU here)."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+import weath3rb0i_amd as w3
+from weath3rb0i_amd import _lib as L
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from weath3rb0i_amd import build
+    build.build()
+    return L.load()
+
+
+def test_exports_match_header(lib):
+    hdr = open(os.path.join(ROOT, "include", "w3hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(w3_[a-z0-9_]+)\s*\(", hdr))
+    assert declared, "no declarations parsed"
+    for name in sorted(declared):
+        assert hasattr(lib, name), "libw3hip.so does not export %s" % name
+    assert declared == set(L.EXPORTS)
+    assert lib.w3_abi_version() == 1
+
+
+def test_struct_layout(lib):
+    assert C.sizeof(L.Node) == 24
+    assert C.sizeof(L.ModelSpec) == 4 + 24 * 31 + 0 or C.sizeof(L.ModelSpec) == 748
+
+
+def test_spec_building(lib):
+    m = w3.BestOfTwoModel.new(w3.BestOfTwoModel.new(w3.Order0.new(), w3.Order1.new()), w3.OrderN.new(27, 3))
+    s = m.spec()
+    kinds = [s.nodes[i].kind for i in range(s.n_nodes)]
+    assert kinds == [1, 1, 2, 1, 2]
+    assert [(s.nodes[i].bits, s.nodes[i].align) for i in (0, 1, 3)] == [(11, 3), (19, 3), (27, 3)]
+    d = w3.init_model().spec()  # main.rs:151
+    nd = d.nodes[0]
+    assert (nd.bits, nd.align, nd.history, nd.max_bits) == (11, 3, L.W3_HIST_AC, 8)
+    assert list(nd.table) == [1, 50188, 62497, 15819, 22545, 31499, 22988, 29616]
+    f = w3.FrozenModel.new(w3.Order0.new()).spec()
+    assert f.nodes[0].frozen == 1
+    with pytest.raises(TypeError):
+        w3.FrozenModel.new(w3.BestOfTwoModel.new(w3.Order0.new(), w3.Order0.new()))
+
+
+def test_spec_validation_errors(lib):
+    for bad in [w3.OrderN(0, 0), w3.OrderN(33, 3), w3.OrderN(8, 9), w3.OrderN(2, 3), w3.OrderN(32, 0),
+                w3.OrderNEntropy(11, 3, w3.ACHistory(33, w3.StationaryModel.for_book1()))]:
+        with pytest.raises(w3.W3Error) as e:
+            bad.spec()
+        assert e.value.code == L.W3_E_INVALID
+    s = L.ModelSpec()
+    s.n_nodes = 1
+    s.nodes[0].kind = L.W3_NODE_BEST_OF_TWO  # nothing to pop
+    assert lib.w3_spec_validate(C.byref(s)) == L.W3_E_INVALID
+    s.n_nodes = 0
+    assert lib.w3_spec_validate(C.byref(s)) == L.W3_E_INVALID
+    two = L.ModelSpec()
+    two.n_nodes = 2
+    two.nodes[0] = w3.Order0().spec().nodes[0]
+    two.nodes[1] = w3.Order0().spec().nodes[0]
+    assert lib.w3_spec_validate(C.byref(two)) == L.W3_E_INVALID  # two roots
+
+
+def test_stationary_table_matches_oracle(lib, oracle):
+    from tests.synth import lcg_text
+    buf = lcg_text(30000, seed=4) + bytes(70000)  # long enough to trigger Counter halving
+    assert w3.StationaryModel.new(buf).table == oracle.StationaryModel(buf).table
+
+
+def test_misc_host_helpers(lib):
+    assert lib.w3_max_compressed_size(65536, 65536) == 16 * 65536 + 8
+    assert lib.w3_max_compressed_size(10, 0) == 0
+    assert lib.w3_strerror(L.W3_E_NOSPACE) == b"output buffer too small"
+
+
+def test_no_gpu_fails_loudly(lib):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(w3.W3Error) as e:
+        w3.Context(0)
+    assert e.value.code == L.W3_E_HIP
+
+
+def test_product_never_imports_oracle():
+    pkg = os.path.join(ROOT, "weath3rb0i_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".h", ".hip", ".cpp", ".hpp")):
+                txt = open(os.path.join(dirpath, f), errors="ignore").read()
+                assert "pyoracle" not in txt and "w3_oracle" not in txt and "libw3oracle" not in txt, f

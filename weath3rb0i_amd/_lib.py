@@ -1,0 +1,75 @@
+"""Loads libw3hip.so (the HIP extension) through ctypes.  Fails loudly when the
+extension is missing: there is no CPU fallback in this package."""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SO = os.path.join(HERE, "libw3hip.so")
+
+W3_MAX_NODES = 31
+W3_NODE_ORDERN, W3_NODE_BEST_OF_TWO = 1, 2
+W3_HIST_NONE, W3_HIST_RAW, W3_HIST_AC = 0, 1, 2
+W3_OK, W3_E_INVALID, W3_E_NOSPACE, W3_E_HIP, W3_E_UNSUPPORTED, W3_E_NOMEM, W3_E_FORMAT = 0, -1, -2, -3, -4, -5, -6
+W3_OPT_PATH, W3_OPT_TIMING = 1, 2
+W3_PATH_AUTO, W3_PATH_GENERIC, W3_PATH_TWOPHASE = 0, 1, 2
+
+
+class Node(C.Structure):
+    _fields_ = [("kind", C.c_uint8), ("bits", C.c_uint8), ("align", C.c_uint8), ("history", C.c_uint8),
+                ("max_bits", C.c_uint8), ("frozen", C.c_uint8), ("reserved", C.c_uint8 * 2), ("table", C.c_uint16 * 8)]
+
+
+class ModelSpec(C.Structure):
+    _fields_ = [("n_nodes", C.c_uint32), ("nodes", Node * W3_MAX_NODES)]
+
+
+class Timing(C.Structure):
+    _fields_ = [("predict_ms", C.c_float), ("coder_ms", C.c_float), ("pack_ms", C.c_float), ("generic_ms", C.c_float),
+                ("total_ms", C.c_float), ("path", C.c_uint32), ("n_coder_launches", C.c_uint32),
+                ("coder_bytes", C.c_uint64), ("predict_bytes", C.c_uint64)]
+
+
+EXPORTS = [
+    "w3_abi_version", "w3_strerror", "w3_last_error", "w3_ctx_create", "w3_ctx_destroy", "w3_spec_validate",
+    "w3_ctx_set_option", "w3_max_compressed_size", "w3_encode_blocks", "w3_decode_blocks", "w3_encode_blocks_device",
+    "w3_decode_blocks_device", "w3_compress_stream", "w3_decompress_stream", "w3_predict_blocks", "w3_stationary_table",
+    "w3_get_timing", "w3_selftest_counter_p",
+]
+
+_lib = None
+
+
+def load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(SO):
+        raise ImportError(
+            "weath3rb0i_amd: HIP extension %s is missing - run `python -m weath3rb0i_amd.build` "
+            "(or __graft_entry__.build()).  There is no CPU fallback." % SO)
+    lib = C.CDLL(SO)
+    vp, sz = C.c_void_p, C.c_size_t
+    lib.w3_abi_version.restype = C.c_int
+    lib.w3_strerror.restype = C.c_char_p
+    lib.w3_strerror.argtypes = [C.c_int]
+    lib.w3_last_error.restype = C.c_char_p
+    lib.w3_last_error.argtypes = [vp]
+    lib.w3_ctx_create.argtypes = [C.c_int, C.POINTER(vp)]
+    lib.w3_ctx_destroy.argtypes = [vp]
+    lib.w3_ctx_destroy.restype = None
+    lib.w3_spec_validate.argtypes = [C.POINTER(ModelSpec)]
+    lib.w3_ctx_set_option.argtypes = [vp, C.c_int, C.c_int64]
+    lib.w3_max_compressed_size.restype = sz
+    lib.w3_max_compressed_size.argtypes = [sz, sz]
+    lib.w3_encode_blocks.argtypes = [vp, C.POINTER(ModelSpec), vp, sz, sz, vp, sz, C.POINTER(sz), vp]
+    lib.w3_decode_blocks.argtypes = [vp, C.POINTER(ModelSpec), vp, vp, sz, sz, C.c_uint64, vp]
+    lib.w3_encode_blocks_device.argtypes = [vp, C.POINTER(ModelSpec), vp, sz, sz, vp, sz, vp, vp, vp]
+    lib.w3_decode_blocks_device.argtypes = [vp, C.POINTER(ModelSpec), vp, vp, sz, sz, C.c_uint64, vp, vp]
+    lib.w3_compress_stream.argtypes = [vp, C.POINTER(ModelSpec), vp, sz, vp, sz, C.POINTER(sz)]
+    lib.w3_decompress_stream.argtypes = [vp, C.POINTER(ModelSpec), vp, sz, vp, sz, C.POINTER(sz)]
+    lib.w3_predict_blocks.argtypes = [vp, C.POINTER(ModelSpec), vp, sz, sz, vp]
+    lib.w3_stationary_table.argtypes = [vp, sz, vp]
+    lib.w3_selftest_counter_p.argtypes = [vp, C.POINTER(C.c_uint64)]
+    lib.w3_get_timing.argtypes = [vp, C.POINTER(Timing)]
+    _lib = lib
+    return lib

@@ -1,0 +1,141 @@
+"""compress / decompress entry points over the C ABI (include/w3hip.h).
+
+Context wraps one w3_ctx (one GPU).  Host-buffer calls take bytes / numpy
+arrays; *_device calls take torch CUDA tensors (PyTorch is only the owner of
+device memory and streams here)."""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib as L
+from .models import Model, W3Error, init_model
+
+MAGIC_STR = b"w30i"  # main.rs:14
+
+
+def _u8(data):
+    if isinstance(data, np.ndarray):
+        return np.ascontiguousarray(data, dtype=np.uint8)
+    return np.frombuffer(bytes(data), dtype=np.uint8)
+
+
+class Context:
+    def __init__(self, device=0):
+        self.lib = L.load()
+        h = C.c_void_p()
+        rc = self.lib.w3_ctx_create(device, C.byref(h))
+        if rc:
+            raise W3Error(rc, "w3_ctx_create(device=%d): no usable HIP device" % device)
+        self.h = h
+        self.device = device
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.w3_ctx_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def _chk(self, rc):
+        if rc:
+            raise W3Error(rc, self.lib.w3_last_error(self.h).decode())
+
+    def set_path(self, path):
+        self._chk(self.lib.w3_ctx_set_option(self.h, L.W3_OPT_PATH, {"auto": 0, "generic": 1, "twophase": 2}[path]))
+
+    def set_timing(self, on=True):
+        self._chk(self.lib.w3_ctx_set_option(self.h, L.W3_OPT_TIMING, int(on)))
+
+    def timing(self):
+        t = L.Timing()
+        self._chk(self.lib.w3_get_timing(self.h, C.byref(t)))
+        return {k: getattr(t, k) for k, _ in L.Timing._fields_}
+
+    # ---- host buffers ----------------------------------------------------
+    def encode_blocks(self, model, data, block_size, out_cap=None):
+        """-> (concatenated streams: np.uint8[], block_lens: np.uint32[])"""
+        spec = model.spec() if isinstance(model, Model) else model
+        a = _u8(data)
+        n = len(a)
+        nb = (n + block_size - 1) // block_size if block_size else 0
+        if out_cap is None:
+            out_cap = 2 * n + 64 * nb + 64
+        while True:
+            out = np.empty(max(out_cap, 1), dtype=np.uint8)
+            lens = np.zeros(max(nb, 1), dtype=np.uint32)
+            olen = C.c_size_t()
+            rc = self.lib.w3_encode_blocks(self.h, C.byref(spec), a.ctypes.data_as(C.c_void_p), n, block_size,
+                                           out.ctypes.data_as(C.c_void_p), out_cap, C.byref(olen), lens.ctypes.data_as(C.c_void_p))
+            if rc == L.W3_E_NOSPACE and olen.value > out_cap:
+                out_cap = olen.value
+                continue
+            self._chk(rc)
+            return out[: olen.value], lens[:nb]
+
+    def decode_blocks(self, model, comp, block_lens, block_size, orig_len):
+        spec = model.spec() if isinstance(model, Model) else model
+        a = _u8(comp)
+        lens = np.ascontiguousarray(block_lens, dtype=np.uint32)
+        out = np.empty(max(orig_len, 1), dtype=np.uint8)
+        rc = self.lib.w3_decode_blocks(self.h, C.byref(spec), a.ctypes.data_as(C.c_void_p), lens.ctypes.data_as(C.c_void_p),
+                                       len(lens), block_size, orig_len, out.ctypes.data_as(C.c_void_p))
+        self._chk(rc)
+        return out[:orig_len]
+
+    def predict_blocks(self, model, data, block_size):
+        spec = model.spec()
+        a = _u8(data)
+        p = np.empty(max(len(a) * 8, 1), dtype=np.uint16)
+        self._chk(self.lib.w3_predict_blocks(self.h, C.byref(spec), a.ctypes.data_as(C.c_void_p), len(a), block_size,
+                                             p.ctypes.data_as(C.c_void_p)))
+        return p[: len(a) * 8]
+
+    # ---- reference container (main.rs:89-144) ------------------------------
+    def compress(self, data, model=None):
+        """compress(): b"w30i" + u64 BE len + one stream."""
+        model = model or init_model()
+        spec = model.spec()
+        a = _u8(data)
+        cap = 2 * len(a) + 128
+        while True:
+            out = np.empty(cap, dtype=np.uint8)
+            olen = C.c_size_t()
+            rc = self.lib.w3_compress_stream(self.h, C.byref(spec), a.ctypes.data_as(C.c_void_p), len(a),
+                                             out.ctypes.data_as(C.c_void_p), cap, C.byref(olen))
+            if rc == L.W3_E_NOSPACE and olen.value > cap:
+                cap = olen.value
+                continue
+            self._chk(rc)
+            return out[: olen.value].tobytes()
+
+    def decompress(self, data, model=None):
+        model = model or init_model()
+        spec = model.spec()
+        a = _u8(data)
+        if len(a) >= 12 and a[:4].tobytes() == MAGIC_STR:
+            n = int.from_bytes(a[4:12].tobytes(), "big")
+        else:
+            n = 0
+        out = np.empty(max(n, 1), dtype=np.uint8)
+        olen = C.c_size_t()
+        rc = self.lib.w3_decompress_stream(self.h, C.byref(spec), a.ctypes.data_as(C.c_void_p), len(a),
+                                           out.ctypes.data_as(C.c_void_p), n, C.byref(olen))
+        self._chk(rc)
+        return out[: olen.value].tobytes()
+
+    # ---- device-resident (torch tensors own the memory) ------------------------
+    def encode_blocks_device(self, model, d_in, block_size, d_out, d_lens, d_total, stream=None):
+        """d_in/d_out: torch.uint8 CUDA tensors, d_lens: int32/uint32[nb], d_total: int64[1].  Returns rc-checked None."""
+        spec = model.spec() if isinstance(model, Model) else model
+        st = C.c_void_p(stream) if stream else None
+        rc = self.lib.w3_encode_blocks_device(self.h, C.byref(spec), C.c_void_p(d_in.data_ptr()), d_in.numel(), block_size,
+                                              C.c_void_p(d_out.data_ptr()), d_out.numel(), C.c_void_p(d_lens.data_ptr()),
+                                              C.c_void_p(d_total.data_ptr()), st)
+        self._chk(rc)
+
+    def decode_blocks_device(self, model, d_comp, d_lens, block_size, orig_len, d_out, stream=None):
+        spec = model.spec() if isinstance(model, Model) else model
+        st = C.c_void_p(stream) if stream else None
+        rc = self.lib.w3_decode_blocks_device(self.h, C.byref(spec), C.c_void_p(d_comp.data_ptr()), C.c_void_p(d_lens.data_ptr()),
+                                              d_lens.numel(), block_size, orig_len, C.c_void_p(d_out.data_ptr()), st)
+        self._chk(rc)

@@ -1,0 +1,37 @@
+"""In-tree build of the HIP extension (libw3hip.so) for gfx950 with hipcc."""
+import os
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SO = os.path.join(HERE, "libw3hip.so")
+SRC = os.path.join(HERE, "csrc", "w3hip.hip")
+
+
+def sources():
+    d = os.path.join(HERE, "csrc")
+    out = [os.path.join(d, f) for f in sorted(os.listdir(d))]
+    out.append(os.path.join(os.path.dirname(HERE), "include", "w3hip.h"))
+    return out
+
+
+def stale():
+    if not os.path.exists(SO):
+        return True
+    t = os.path.getmtime(SO)
+    return any(os.path.getmtime(s) > t for s in sources())
+
+
+def build(force=False, verbose=False):
+    if not force and not stale():
+        return SO
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall",
+           "-Wno-unused-function", "-o", SO, SRC]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return SO
+
+
+if __name__ == "__main__":
+    build(force=True, verbose=True)

@@ -1,0 +1,224 @@
+// w3_device.h — device-side primitives of the weath3rb0i hot path for gfx950.
+// Integer-only, bit-exact restatements for one wavefront lane; every function
+// cites the reference file:line (under /root/reference/src) whose arithmetic
+// it reproduces.  No CUDA paths, no portability layer: CDNA4 only.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace w3 {
+
+// ---------------------------------------------------------------------------
+// Counter  (models/counter.rs:4-26)
+// ---------------------------------------------------------------------------
+// p = round_half_up( 2^17*(c1+1) / (c0+c1+2) ) without a 64-bit divide:
+// f32 reciprocal estimate (|err| < 0.1) + one exact integer correction step.
+// Exact for every reachable Counter state (c0,c1 <= 65535); verified
+// exhaustively on device by tests/test_gpu_primitives.py.
+__device__ __forceinline__ uint32_t counter_p(uint32_t c0, uint32_t c1) {
+    const uint32_t d = c0 + c1 + 2u;
+    const uint32_t a = c1 + 1u;
+    float est = (float)a * 131072.0f * __builtin_amdgcn_rcpf((float)d);
+    uint32_t q = (uint32_t)est;
+    int32_t rem = (int32_t)((a << 17) - q * d);  // true remainder is tiny: mod-2^32 arithmetic is exact
+    if (rem < 0) q -= 1u;
+    else if (rem >= (int32_t)d) q += 1u;
+    return (q >> 1) + (q & 1u);
+}
+
+// packed counter: low 16 = data[0], high 16 = data[1]
+__device__ __forceinline__ uint32_t counter_p_packed(uint32_t c) { return counter_p(c & 0xFFFFu, c >> 16); }
+
+__device__ __forceinline__ uint32_t counter_update_packed(uint32_t c, uint32_t bit) {  // counter.rs:20-26
+    uint32_t c0 = c & 0xFFFFu, c1 = c >> 16;
+    if (bit) c1 += 1u; else c0 += 1u;
+    if ((bit ? c1 : c0) == 0xFFFFu) {
+        c0 = (c0 >> 1) + (c0 & 1u);
+        c1 = (c1 >> 1) + (c1 & 1u);
+    }
+    return c0 | (c1 << 16);
+}
+
+// OpinionMixer2::mix distance (mixers/opinion_mixer2.rs:5-10).  A BestOfTwo
+// tree of any shape returns the LEFTMOST leaf (in-order) of maximal distance,
+// because mix() keeps p1 on ties; callers scan leaves left to right with '>'.
+__device__ __forceinline__ uint32_t opinion_dist(uint32_t p) { return p >= 32768u ? p - 32768u : 32768u - p; }
+
+// ---------------------------------------------------------------------------
+// Bit sink of one lane: ACWriter (entropy_coding/io.rs:52-101) with the
+// per-bit packing replaced by a 64-bit accumulator flushed 32 bits at a time.
+// ---------------------------------------------------------------------------
+struct BitSink {
+    uint64_t acc;   // newest bit at LSB; only the low `nb` bits are meaningful
+    uint32_t nb;    // < 32 between calls
+    uint8_t *base;  // 4-byte aligned stripe of this lane
+    uint32_t pos;   // bytes produced so far (keeps counting past cap)
+    uint32_t cap;
+
+    __device__ __forceinline__ void init(uint8_t *b, uint32_t c) { acc = 0; nb = 0; base = b; pos = 0; cap = c; }
+
+    __device__ __forceinline__ void put(uint32_t val, uint32_t k) {  // k in 0..32, val < 2^k
+        acc = (acc << k) | val;
+        nb += k;
+        if (nb >= 32u) {
+            uint32_t w = (uint32_t)(acc >> (nb - 32u));
+            if (pos + 4u <= cap) *reinterpret_cast<uint32_t *>(base + pos) = __builtin_bswap32(w);
+            pos += 4u;
+            nb -= 32u;
+        }
+    }
+    // after the stream is byte aligned: write the nb/8 tail bytes
+    __device__ __forceinline__ void finish() {
+        while (nb >= 8u) {
+            uint8_t b = (uint8_t)(acc >> (nb - 8u));
+            if (pos < cap) base[pos] = b;
+            pos += 1u;
+            nb -= 8u;
+        }
+    }
+};
+
+// ---------------------------------------------------------------------------
+// ArithmeticCoder, encoder side (entropy_coding/arithmetic_coder.rs:37-71,109-119)
+// The two renormalisation while-loops are collapsed with clz:
+//   loop 1 (:51-55) runs n = clz(x1^x2) times and emits the top n bits of x1;
+//   loop 2 (:58-62, E3) runs m = clo(((x1 & ~x2) << 1)) times.
+// write_bit's pending-parity rule (io.rs:70-89): first bit b, then rev_bits
+// copies of !b, then the rest.
+// ---------------------------------------------------------------------------
+struct Encoder {
+    uint32_t x1, x2, rev;
+    BitSink out;
+
+    __device__ __forceinline__ void init(uint8_t *stripe, uint32_t cap) { x1 = 0; x2 = 0xFFFFFFFFu; rev = 0; out.init(stripe, cap); }
+
+    __device__ __forceinline__ void emit(uint32_t v, uint32_t n) {  // n in 1..32, v = top n bits of x1
+        if (rev == 0u) { out.put(v, n); return; }
+        const uint32_t b = (v >> (n - 1u)) & 1u;
+        const uint32_t fill = b ? 0u : 0xFFFFFFFFu;
+        if (n + rev <= 32u) {
+            uint32_t rest = v & ((1u << (n - 1u)) - 1u);
+            uint32_t mid = (fill & ((1u << rev) - 1u)) << (n - 1u);
+            out.put((b << (n + rev - 1u)) | mid | rest, n + rev);
+        } else {
+            out.put(b, 1u);
+            uint32_t r = rev;
+            while (r > 0u) {
+                uint32_t k = r < 32u ? r : 32u;
+                out.put(k == 32u ? fill : (fill & ((1u << k) - 1u)), k);
+                r -= k;
+            }
+            if (n > 1u) out.put(v & ((1u << (n - 1u)) - 1u), n - 1u);
+        }
+        rev = 0u;
+    }
+
+    __device__ __forceinline__ void encode(uint32_t bit, uint32_t prob) {
+        const uint32_t p32 = prob ? (prob << 16) : 1u;              // lerp :111
+        const uint32_t xmid = x1 + __umulhi(x2 - x1, p32);          // :112-116
+        if (bit) x2 = xmid; else x1 = xmid + 1u;                    // :45-48
+        const uint32_t n = (uint32_t)__clz((int)(x1 ^ x2));         // 32 when x1 == x2
+        if (n) {
+            if (n == 32u) { emit(x1, 32u); x1 = 0u; x2 = 0xFFFFFFFFu; }
+            else { emit(x1 >> (32u - n), n); x1 <<= n; x2 = (x2 << n) | ((1u << n) - 1u); }
+        }
+        const uint32_t m = (uint32_t)__clz((int)~((x1 & ~x2) << 1)); // 0..31
+        x1 = (x1 << m) & 0x7FFFFFFFu;
+        x2 = (x2 << m) | 0x80000000u | ((1u << m) - 1u);
+        rev += m;
+    }
+
+    // ArithmeticCoder::flush -> ACWriter::flush(x2)  (arithmetic_coder.rs:67-71, io.rs:91-100)
+    __device__ __forceinline__ uint32_t flush() {
+        emit(x2 >> 31, 1u);
+        const uint32_t idx = out.nb & 7u;
+        if (idx) {
+            const uint32_t k = 8u - idx;
+            out.put((x2 << 1) >> (32u - k), k);
+        }
+        out.finish();
+        return out.pos;
+    }
+};
+
+// ---------------------------------------------------------------------------
+// ACReader + decoder side (io.rs:7-49, arithmetic_coder.rs:74-106)
+// ---------------------------------------------------------------------------
+struct BitSource {
+    const uint8_t *p; uint32_t len, pos; uint64_t win; uint32_t navail;
+    __device__ __forceinline__ void init(const uint8_t *s, uint32_t l) { p = s; len = l; pos = 0; win = 0; navail = 0; }
+    __device__ __forceinline__ uint32_t get(uint32_t k) {  // k in 0..32; zeros past EOF (io.rs:23-26)
+        while (navail <= 32u) {
+            uint32_t b = pos < len ? p[pos] : 0u;
+            pos++;
+            win = (win << 8) | b;
+            navail += 8u;
+        }
+        uint32_t v = (uint32_t)(win >> (navail - k));
+        if (k < 32u) v &= (1u << k) - 1u;
+        navail -= k;
+        return v;
+    }
+};
+
+struct Decoder {
+    uint32_t x1, x2, x;
+    BitSource in;
+    __device__ __forceinline__ void init(const uint8_t *s, uint32_t l) { in.init(s, l); x1 = 0; x2 = 0xFFFFFFFFu; x = in.get(32u); }
+    __device__ __forceinline__ uint32_t decode(uint32_t prob) {
+        const uint32_t p32 = prob ? (prob << 16) : 1u;
+        const uint32_t xmid = x1 + __umulhi(x2 - x1, p32);
+        const uint32_t bit = x <= xmid;                                // :82
+        if (bit) x2 = xmid; else x1 = xmid + 1u;
+        const uint32_t n = (uint32_t)__clz((int)(x1 ^ x2));
+        if (n == 32u) { x = in.get(32u); x1 = 0u; x2 = 0xFFFFFFFFu; }
+        else if (n) { x = (x << n) | in.get(n); x1 <<= n; x2 = (x2 << n) | ((1u << n) - 1u); }
+        const uint32_t m = (uint32_t)__clz((int)~((x1 & ~x2) << 1));
+        if (m) {
+            // m iterations of x = ((x<<1) ^ Q2) | bit : only the last XOR survives the shifts
+            x = ((x << m) | in.get(m)) ^ 0x80000000u;
+            x1 = (x1 << m) & 0x7FFFFFFFu;
+            x2 = (x2 << m) | 0x80000000u | ((1u << m) - 1u);
+        }
+        return bit;
+    }
+};
+
+// ---------------------------------------------------------------------------
+// ACHistory::hash (history/ac_history.rs:28-46) with EntropyWriter (:50-89).
+// The writer shifts bits in from the top and the result is state>>(32-idx),
+// i.e. the k-th written bit lands at bit k: accumulate LSB-first.  An Err from
+// the writer (idx == max_bits) ends the loop; max_bits == 0 or idx == 0 -> 0.
+// `bits` = last 64 input bits (newest at bit 0), `pos` = bits seen so far.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t ac_history_hash(uint64_t bits, uint32_t pos, uint32_t max_bits, const uint16_t *table) {
+    uint32_t x1 = 0u, x2 = 0xFFFFFFFFu, hash = 0u, idx = 0u, rev = 0u;
+    uint32_t al = pos & 7u;                                            // model.align(pos & 7)  :36
+    for (int i = 0; i < 64; i++) {
+        const uint32_t bit = (uint32_t)(bits >> i) & 1u;               // most recent bit first :38
+        al = (al + 7u) & 7u;                                           // stationary.rs:54-57
+        const uint32_t prob = table[al];
+        const uint32_t p32 = prob ? (prob << 16) : 1u;
+        const uint32_t xmid = x1 + __umulhi(x2 - x1, p32);
+        if (bit) x2 = xmid; else x1 = xmid + 1u;
+        while (((x1 ^ x2) >> 31) == 0u) {
+            const uint32_t b = x1 >> 31;
+            if (idx == max_bits) return hash;
+            hash |= b << idx; idx++;
+            while (rev > 0u) {
+                rev--;
+                if (idx == max_bits) return hash;
+                hash |= (b ^ 1u) << idx; idx++;
+            }
+            x1 <<= 1; x2 = (x2 << 1) | 1u;
+        }
+        while (x1 >= 0x40000000u && x2 < 0xC0000000u) {
+            rev++;
+            x1 = (x1 << 1) & 0x7FFFFFFFu;
+            x2 = (x2 << 1) | 0x80000001u;
+        }
+    }
+    return hash;
+}
+
+}  // namespace w3

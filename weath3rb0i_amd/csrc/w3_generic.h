@@ -1,0 +1,125 @@
+// w3_generic.h — GENERIC device path: one wavefront lane runs the reference's
+// bit loop (main.rs:103-109 encode, :131-140 decode) for one block, with its
+// model state (Counter tables) in HBM.  Handles every model spec, including
+// the ones the two-phase fast path does not cover, and is the only decoder
+// (decoding is serial by nature: the next context depends on the decoded bit).
+#pragma once
+#include "w3_device.h"
+
+namespace w3 {
+
+struct LeafParam {
+    uint8_t  bits, align, hist, max_bits, frozen, use_hash, pad[2];
+    uint16_t table[8];       // StationaryModel table (ACHistory)
+    uint64_t tbl_off;        // byte offset of this leaf's table inside the lane's region
+    uint32_t hash_mask;      // slots-1 when use_hash
+    uint32_t hist_mask;      // (1<<(bits-align))-1
+};
+
+struct GenericArgs {
+    int       n_leaves;
+    LeafParam leaf[16];
+    // geometry
+    uint64_t  n;             // total original bytes
+    uint32_t  block_size;
+    uint32_t  first_block, n_lanes;
+    // model tables: lane l owns [tables + l*lane_stride, +lane_stride)
+    uint8_t  *tables;
+    uint64_t  lane_stride;
+    // encode
+    const uint8_t *in;       // original bytes
+    uint8_t  *stripes;       // lane-major output stripes (encode)
+    uint32_t  stripe_cap;
+    uint32_t *out_len;       // [nblocks] bytes produced
+    uint32_t *overflow;      // set to 1 if any stripe overflowed
+    // decode
+    const uint8_t  *cin;     // concatenated block streams
+    const uint64_t *coffs;   // [nblocks] offsets into cin
+    const uint32_t *clens;   // [nblocks]
+    uint8_t  *dout;          // original bytes out
+};
+
+// Context of a leaf at step t, given the lane's common 64-bit history (newest
+// bit at bit 0) — OrderN::update (models/ordern.rs:35-43) and
+// OrderNEntropy::update (models/ordern_entropy.rs:36-45) in closed form:
+//   history  = last (bits-align) input bits      (zeros before the block start)
+//   alignment= t mod 2^align                     (incremented once per update)
+// Both models start with ctx = 0 and only form ctx inside update(), so t == 0
+// is ctx 0 even for ACHistory (whose hash of an empty history is not 0).
+__device__ __forceinline__ uint32_t leaf_ctx(const LeafParam &lp, uint64_t hist64, uint32_t t) {
+    if (t == 0u) return 0u;
+    uint32_t h;
+    if (lp.hist == 2) h = ac_history_hash(hist64, t, lp.max_bits, lp.table);
+    else h = (uint32_t)hist64;
+    h &= lp.hist_mask;
+    return (h << lp.align) | (t & ((1u << lp.align) - 1u));
+}
+
+// Exact-keyed counter slot for wide contexts: the reference tables are
+// direct-indexed and collision free, so a device table for 2^bits > budget
+// must be an exact map.  Open addressing, key+1 stored (0 = empty), one
+// writer (the owning lane).
+__device__ __forceinline__ uint32_t *leaf_slot(const LeafParam &lp, uint8_t *lane_tbl, uint32_t ctx) {
+    uint32_t *tbl = reinterpret_cast<uint32_t *>(lane_tbl + lp.tbl_off);
+    if (!lp.use_hash) return tbl + ctx;
+    uint32_t h = (ctx * 2654435761u) ^ (ctx >> 15);
+    for (;;) {
+        h &= lp.hash_mask;
+        uint32_t k = tbl[2u * h];
+        if (k == ctx + 1u) return tbl + 2u * h + 1u;
+        if (k == 0u) { tbl[2u * h] = ctx + 1u; return tbl + 2u * h + 1u; }
+        h++;
+    }
+}
+
+template <bool DECODE>
+__global__ void __launch_bounds__(64) k_generic(GenericArgs a) {
+    const uint32_t lane = blockIdx.x * blockDim.x + threadIdx.x;
+    if (lane >= a.n_lanes) return;
+    const uint32_t b = a.first_block + lane;
+    const uint64_t off = (uint64_t)b * a.block_size;
+    const uint32_t len = (uint32_t)((a.n - off) < a.block_size ? (a.n - off) : a.block_size);
+    uint8_t *lane_tbl = a.tables + (uint64_t)lane * a.lane_stride;
+
+    Encoder enc; Decoder dec;
+    if (DECODE) dec.init(a.cin + a.coffs[b], a.clens[b]);
+    else enc.init(a.stripes + (uint64_t)lane * a.stripe_cap, a.stripe_cap);
+
+    uint64_t hist64 = 0; uint32_t t = 0;
+    for (uint32_t i = 0; i < len; i++) {
+        uint32_t byte = DECODE ? 0u : a.in[off + i];
+        for (int s = 7; s >= 0; s--) {
+            // predict: leftmost leaf of maximal |p - 1/2| (BestOfTwo tree, models/mod.rs:67-69)
+            uint32_t p = 32768u, best = 0u; bool first = true;
+            uint32_t *slot[16];
+            for (int l = 0; l < a.n_leaves; l++) {
+                const LeafParam &lp = a.leaf[l];
+                uint32_t pl = 32768u;
+                slot[l] = nullptr;
+                if (!lp.frozen) {                       // FrozenModel never adapts: Counter stays (0,0)
+                    slot[l] = leaf_slot(lp, lane_tbl, leaf_ctx(lp, hist64, t));
+                    pl = counter_p_packed(*slot[l]);
+                }
+                uint32_t d = opinion_dist(pl);
+                if (first || d > best) { p = pl; best = d; first = false; }
+            }
+            uint32_t bit;
+            if (DECODE) { bit = dec.decode(p); byte = (byte << 1) | bit; }
+            else bit = (byte >> s) & 1u;
+            // Model::update = adapt (train current ctx) then update (advance)  models/mod.rs:28-31
+            for (int l = 0; l < a.n_leaves; l++)
+                if (slot[l]) *slot[l] = counter_update_packed(*slot[l], bit);
+            hist64 = (hist64 << 1) | bit;
+            t++;
+            if (!DECODE) enc.encode(bit, p);
+        }
+        if (DECODE) a.dout[off + i] = (uint8_t)byte;
+    }
+    if (!DECODE) {
+        uint32_t produced = enc.flush();
+        a.out_len[b] = produced;
+        if (produced > a.stripe_cap) atomicOr(a.overflow, 1u);
+    }
+}
+
+}  // namespace w3

@@ -1,0 +1,565 @@
+// w3hip.hip — host side of the C ABI declared in include/w3hip.h, plus the
+// kernel launches.  MI355X (gfx950) only.  No CPU fallback anywhere in this
+// file: without a device every entry point fails with W3_E_HIP.
+#include "../../include/w3hip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "w3_spec.h"
+#include "w3_generic.h"
+#include "w3_pack.h"
+#include "w3_twophase.h"
+#include "w3_selftest.h"
+
+using namespace w3;
+
+// ---------------------------------------------------------------------------
+// ctx
+// ---------------------------------------------------------------------------
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+};
+
+struct w3_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+    int opt_path = W3_PATH_AUTO;
+    int opt_timing = 0;
+    w3_timing timing{};
+    hipEvent_t ev[8]{};
+    // workspace
+    DevBuf tables, stripes, lens, offs, total, flag, io_in, io_out, coffs, misc;
+    TwoPhaseWs tp;
+};
+
+#define HIPCHK(ctx, expr)                                                                       \
+    do {                                                                                        \
+        hipError_t e_ = (expr);                                                                 \
+        if (e_ != hipSuccess) {                                                                 \
+            (ctx)->err = std::string(#expr) + ": " + hipGetErrorString(e_);                     \
+            return W3_E_HIP;                                                                    \
+        }                                                                                       \
+    } while (0)
+
+static int ensure(w3_ctx *ctx, DevBuf &b, size_t bytes) {
+    if (bytes <= b.cap && b.p) return W3_OK;
+    if (b.p) { HIPCHK(ctx, hipFree(b.p)); b.p = nullptr; b.cap = 0; }
+    size_t want = std::max<size_t>(bytes, 256);
+    hipError_t e = hipMalloc(&b.p, want);
+    if (e != hipSuccess) {
+        b.p = nullptr;
+        ctx->err = "hipMalloc(" + std::to_string(want) + "): " + hipGetErrorString(e);
+        (void)hipGetLastError();
+        return W3_E_NOMEM;
+    }
+    b.cap = want;
+    return W3_OK;
+}
+#define ENSURE(ctx, buf, bytes) do { int r_ = ensure(ctx, buf, bytes); if (r_) return r_; } while (0)
+
+extern "C" int w3_abi_version(void) { return W3_ABI_VERSION; }
+
+extern "C" const char *w3_strerror(int code) {
+    switch (code) {
+    case W3_OK: return "ok";
+    case W3_E_INVALID: return "invalid argument or malformed model spec";
+    case W3_E_NOSPACE: return "output buffer too small";
+    case W3_E_HIP: return "HIP runtime error";
+    case W3_E_UNSUPPORTED: return "model spec not implemented on the device";
+    case W3_E_NOMEM: return "device workspace does not fit";
+    case W3_E_FORMAT: return "bad container magic";
+    default: return "unknown error";
+    }
+}
+
+extern "C" const char *w3_last_error(const w3_ctx *ctx) { return ctx ? ctx->err.c_str() : "null ctx"; }
+
+extern "C" int w3_ctx_create(int device, w3_ctx **out) {
+    if (!out) return W3_E_INVALID;
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) return W3_E_HIP;
+    if (hipSetDevice(device) != hipSuccess) return W3_E_HIP;
+    w3_ctx *c = new w3_ctx();
+    c->device = device;
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return W3_E_HIP; }
+    for (auto &e : c->ev)
+        if (hipEventCreate(&e) != hipSuccess) { delete c; return W3_E_HIP; }
+    *out = c;
+    return W3_OK;
+}
+
+extern "C" void w3_ctx_destroy(w3_ctx *ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipDeviceSynchronize();
+    DevBuf *bufs[] = {&ctx->tables, &ctx->stripes, &ctx->lens, &ctx->offs, &ctx->total, &ctx->flag,
+                      &ctx->io_in, &ctx->io_out, &ctx->coffs, &ctx->misc};
+    for (DevBuf *b : bufs)
+        if (b->p) (void)hipFree(b->p);
+    ctx->tp.release();
+    for (auto &e : ctx->ev)
+        if (e) (void)hipEventDestroy(e);
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+extern "C" int w3_ctx_set_option(w3_ctx *ctx, int opt, int64_t value) {
+    if (!ctx) return W3_E_INVALID;
+    switch (opt) {
+    case W3_OPT_PATH:
+        if (value < W3_PATH_AUTO || value > W3_PATH_TWOPHASE) return W3_E_INVALID;
+        ctx->opt_path = (int)value;
+        return W3_OK;
+    case W3_OPT_TIMING: ctx->opt_timing = value ? 1 : 0; return W3_OK;
+    default: return W3_E_INVALID;
+    }
+}
+
+extern "C" int w3_get_timing(const w3_ctx *ctx, w3_timing *out) {
+    if (!ctx || !out) return W3_E_INVALID;
+    *out = ctx->timing;
+    return W3_OK;
+}
+
+// Hard bound: Counter probabilities lie in [1, 65535] so one bit-step costs at
+// most 16 output bits (SURVEY §7 hard part 4): 16 bytes per input byte, plus
+// the flush byte(s) per block.
+extern "C" size_t w3_max_compressed_size(size_t n, size_t block_size) {
+    if (block_size == 0) return 0;
+    size_t nb = (n + block_size - 1) / block_size;
+    return 16 * n + 8 * nb;
+}
+
+// ---------------------------------------------------------------------------
+// model spec -> ordered leaf list
+// ---------------------------------------------------------------------------
+static int parse_spec(const w3_model_spec *spec, ParsedSpec &ps) {
+    if (!spec || spec->n_nodes == 0 || spec->n_nodes > W3_MAX_NODES) return W3_E_INVALID;
+    int depth = 0;
+    ps.n_leaves = 0;
+    for (uint32_t i = 0; i < spec->n_nodes; i++) {
+        const w3_node &nd = spec->nodes[i];
+        if (nd.kind == W3_NODE_ORDERN) {
+            // OrderN::new allocates 1<<bits counters; masks are u32/u8 (ordern.rs:35-43)
+            if (nd.bits < 1 || nd.bits > 32 || nd.align > 7 || nd.align > nd.bits) return W3_E_INVALID;
+            if ((int)nd.bits - (int)nd.align > 31) return W3_E_INVALID;
+            if (nd.history > W3_HIST_AC) return W3_E_INVALID;
+            if (nd.history == W3_HIST_AC && nd.max_bits > 32) return W3_E_INVALID;
+            if (ps.n_leaves == W3_MAX_LEAVES) return W3_E_UNSUPPORTED;
+            ps.leaf[ps.n_leaves++] = nd;
+            depth++;
+        } else if (nd.kind == W3_NODE_BEST_OF_TWO) {
+            if (depth < 2) return W3_E_INVALID;
+            depth--;
+        } else {
+            return W3_E_INVALID;
+        }
+    }
+    return depth == 1 ? W3_OK : W3_E_INVALID;
+}
+
+extern "C" int w3_spec_validate(const w3_model_spec *spec) {
+    ParsedSpec ps;
+    return parse_spec(spec, ps);
+}
+
+static uint64_t next_pow2(uint64_t v) {
+    uint64_t p = 1;
+    while (p < v) p <<= 1;
+    return p;
+}
+
+// Lay out the per-lane model tables of the generic path.
+static uint64_t layout_generic(const ParsedSpec &ps, size_t block_size, GenericArgs &ga) {
+    const uint64_t steps = (uint64_t)block_size * 8;
+    const uint64_t hash_slots = std::max<uint64_t>(1024, next_pow2(2 * steps));
+    const uint64_t hash_bytes = hash_slots * 8;
+    uint64_t off = 0;
+    ga.n_leaves = ps.n_leaves;
+    for (int l = 0; l < ps.n_leaves; l++) {
+        const w3_node &nd = ps.leaf[l];
+        LeafParam &lp = ga.leaf[l];
+        memset(&lp, 0, sizeof lp);
+        lp.bits = nd.bits; lp.align = nd.align; lp.hist = nd.history; lp.max_bits = nd.max_bits; lp.frozen = nd.frozen;
+        memcpy(lp.table, nd.table, sizeof lp.table);
+        lp.hist_mask = (uint32_t)((1ull << (nd.bits - nd.align)) - 1ull);
+        lp.tbl_off = off;
+        if (nd.frozen) continue;
+        const uint64_t direct_bytes = 4ull << nd.bits;
+        if (direct_bytes <= hash_bytes) { lp.use_hash = 0; off += direct_bytes; }
+        else { lp.use_hash = 1; lp.hash_mask = (uint32_t)(hash_slots - 1); off += hash_bytes; }
+    }
+    return std::max<uint64_t>(off, 16);
+}
+
+// ---------------------------------------------------------------------------
+// timing helpers
+// ---------------------------------------------------------------------------
+struct Timer {
+    w3_ctx *c; hipStream_t s; int i;
+    void start(int slot) { i = slot; if (c->opt_timing) (void)hipEventRecord(c->ev[2 * slot], s); }
+    void stop() { if (c->opt_timing) (void)hipEventRecord(c->ev[2 * i + 1], s); }
+};
+static float elapsed(w3_ctx *c, int slot) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, c->ev[2 * slot], c->ev[2 * slot + 1]) != hipSuccess) { (void)hipGetLastError(); return 0.f; }
+    return ms;
+}
+
+// ---------------------------------------------------------------------------
+// pack: scan block lengths, compact stripes into d_out
+// ---------------------------------------------------------------------------
+static int run_pack(w3_ctx *ctx, hipStream_t s, const uint8_t *stripes, uint64_t stride, const uint32_t *d_lens, uint32_t nb,
+                    uint8_t *d_out, size_t out_cap, uint64_t *d_total) {
+    ENSURE(ctx, ctx->offs, (size_t)nb * 8);
+    hipLaunchKernelGGL(k_scan_lens, dim3(1), dim3(1024), 0, s, d_lens, (uint64_t *)ctx->offs.p, d_total, nb);
+    uint32_t grid = std::min<uint32_t>(nb, 256 * 8);
+    hipLaunchKernelGGL(k_pack, dim3(grid), dim3(256), 0, s, stripes, stride, d_lens, (const uint64_t *)ctx->offs.p, d_out,
+                       (uint64_t)out_cap, nb);
+    HIPCHK(ctx, hipGetLastError());
+    return W3_OK;
+}
+
+// ---------------------------------------------------------------------------
+// generic path
+// ---------------------------------------------------------------------------
+static int table_budget(w3_ctx *ctx, uint64_t lane_stride, uint32_t want_lanes, uint32_t &lanes_out) {
+    size_t free_b = 0, total_b = 0;
+    HIPCHK(ctx, hipMemGetInfo(&free_b, &total_b));
+    uint64_t budget = std::min<uint64_t>((uint64_t)(free_b + ctx->tables.cap) / 2, 96ull << 30);
+    uint64_t lanes = budget / lane_stride;
+    if (lanes >= want_lanes) lanes = want_lanes;
+    else lanes = lanes / 64 * 64;
+    if (lanes == 0) {
+        ctx->err = "model tables of one wavefront (" + std::to_string(lane_stride * 64) + " B) exceed the device budget";
+        return W3_E_NOMEM;
+    }
+    lanes_out = (uint32_t)lanes;
+    return W3_OK;
+}
+
+static int generic_encode(w3_ctx *ctx, hipStream_t s, const ParsedSpec &ps, const uint8_t *d_in, size_t n, size_t block_size,
+                          uint32_t nb, uint32_t stripe_cap, uint32_t *d_lens) {
+    GenericArgs ga;
+    memset(&ga, 0, sizeof ga);
+    const uint64_t lane_stride = layout_generic(ps, block_size, ga);
+    uint32_t lanes = 0;
+    int rc = table_budget(ctx, lane_stride, nb, lanes);
+    if (rc) return rc;
+    ENSURE(ctx, ctx->tables, (size_t)lanes * lane_stride);
+    ga.n = n; ga.block_size = (uint32_t)block_size;
+    ga.tables = (uint8_t *)ctx->tables.p; ga.lane_stride = lane_stride;
+    ga.in = d_in; ga.stripe_cap = stripe_cap; ga.out_len = d_lens; ga.overflow = (uint32_t *)ctx->flag.p;
+    for (uint32_t first = 0; first < nb; first += lanes) {
+        uint32_t cnt = std::min(lanes, nb - first);
+        ga.first_block = first; ga.n_lanes = cnt;
+        ga.stripes = (uint8_t *)ctx->stripes.p + (uint64_t)first * stripe_cap;
+        HIPCHK(ctx, hipMemsetAsync(ctx->tables.p, 0, (size_t)cnt * lane_stride, s));
+        hipLaunchKernelGGL(k_generic<false>, dim3((cnt + 63) / 64), dim3(64), 0, s, ga);
+        HIPCHK(ctx, hipGetLastError());
+    }
+    return W3_OK;
+}
+
+static int generic_decode(w3_ctx *ctx, hipStream_t s, const ParsedSpec &ps, const uint8_t *d_cin, const uint32_t *d_lens, uint32_t nb,
+                          size_t block_size, uint64_t orig_len, uint8_t *d_out) {
+    GenericArgs ga;
+    memset(&ga, 0, sizeof ga);
+    const uint64_t lane_stride = layout_generic(ps, block_size, ga);
+    uint32_t lanes = 0;
+    int rc = table_budget(ctx, lane_stride, nb, lanes);
+    if (rc) return rc;
+    ENSURE(ctx, ctx->tables, (size_t)lanes * lane_stride);
+    ENSURE(ctx, ctx->coffs, (size_t)nb * 8);
+    ENSURE(ctx, ctx->total, 8);
+    hipLaunchKernelGGL(k_scan_lens, dim3(1), dim3(1024), 0, s, d_lens, (uint64_t *)ctx->coffs.p, (uint64_t *)ctx->total.p, nb);
+    ga.n = orig_len; ga.block_size = (uint32_t)block_size;
+    ga.tables = (uint8_t *)ctx->tables.p; ga.lane_stride = lane_stride;
+    ga.cin = d_cin; ga.coffs = (const uint64_t *)ctx->coffs.p; ga.clens = d_lens; ga.dout = d_out;
+    for (uint32_t first = 0; first < nb; first += lanes) {
+        uint32_t cnt = std::min(lanes, nb - first);
+        ga.first_block = first; ga.n_lanes = cnt;
+        HIPCHK(ctx, hipMemsetAsync(ctx->tables.p, 0, (size_t)cnt * lane_stride, s));
+        hipLaunchKernelGGL(k_generic<true>, dim3((cnt + 63) / 64), dim3(64), 0, s, ga);
+        HIPCHK(ctx, hipGetLastError());
+    }
+    return W3_OK;
+}
+
+// ---------------------------------------------------------------------------
+// encode (device-resident)
+// ---------------------------------------------------------------------------
+static uint32_t default_stripe_cap(size_t block_size) {
+    // realistic bound 2N+64 (adaptive Counter regret is small); the exact bound 16N+8 is the retry size
+    uint64_t c = 2 * (uint64_t)block_size + 64;
+    return (uint32_t)((c + 15) / 16 * 16);
+}
+static uint32_t worst_stripe_cap(size_t block_size) {
+    uint64_t c = 16 * (uint64_t)block_size + 16;
+    return (uint32_t)((c + 15) / 16 * 16);
+}
+
+static int check_args(w3_ctx *ctx, size_t n, size_t block_size) {
+    if (!ctx) return W3_E_INVALID;
+    if (block_size == 0 || block_size > (1u << 28)) { ctx->err = "block_size must be in 1..2^28"; return W3_E_INVALID; }
+    if ((n + block_size - 1) / block_size > 0x7FFFFFFFull) { ctx->err = "too many blocks"; return W3_E_INVALID; }
+    return W3_OK;
+}
+
+extern "C" int w3_encode_blocks_device(w3_ctx *ctx, const w3_model_spec *spec, const uint8_t *d_in, size_t n, size_t block_size,
+                                       uint8_t *d_out, size_t out_cap, uint32_t *d_block_lens, uint64_t *d_total, void *stream) {
+    int rc = check_args(ctx, n, block_size);
+    if (rc) return rc;
+    ParsedSpec ps;
+    if ((rc = parse_spec(spec, ps))) { ctx->err = "malformed model spec"; return rc; }
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
+    const uint32_t nb = (uint32_t)((n + block_size - 1) / block_size);
+    memset(&ctx->timing, 0, sizeof ctx->timing);
+    ENSURE(ctx, ctx->total, 8);
+    uint64_t *total_p = d_total ? d_total : (uint64_t *)ctx->total.p;
+    if (nb == 0) {
+        HIPCHK(ctx, hipMemsetAsync(total_p, 0, 8, s));
+        HIPCHK(ctx, hipStreamSynchronize(s));
+        return W3_OK;
+    }
+    if (!d_in || !d_out || !d_block_lens) return W3_E_INVALID;
+    ENSURE(ctx, ctx->flag, 16);
+
+    bool two = twophase_supported(ps, block_size);
+    if (ctx->opt_path == W3_PATH_GENERIC) two = false;
+    if (ctx->opt_path == W3_PATH_TWOPHASE && !two) { ctx->err = "spec/block size not covered by the two-phase path"; return W3_E_UNSUPPORTED; }
+
+    Timer tm{ctx, s, 0};
+    uint32_t cap = default_stripe_cap(block_size);
+    for (int attempt = 0; attempt < 2; attempt++) {
+        ENSURE(ctx, ctx->stripes, (size_t)nb * cap);
+        HIPCHK(ctx, hipMemsetAsync(ctx->flag.p, 0, 16, s));
+        tm.start(3);
+        if (two) {
+            rc = twophase_encode(ctx->tp, s, ps, d_in, n, block_size, nb, (uint8_t *)ctx->stripes.p, cap, d_block_lens,
+                                 (uint32_t *)ctx->flag.p, ctx->opt_timing ? ctx->ev : nullptr, &ctx->timing, ctx->err);
+            ctx->timing.path = W3_PATH_TWOPHASE;
+        } else {
+            tm.start(0);
+            rc = generic_encode(ctx, s, ps, d_in, n, block_size, nb, cap, d_block_lens);
+            tm.stop();
+            ctx->timing.path = W3_PATH_GENERIC;
+        }
+        if (rc) return rc;
+        uint32_t ovf = 0;
+        HIPCHK(ctx, hipMemcpyAsync(&ovf, ctx->flag.p, 4, hipMemcpyDeviceToHost, s));
+        HIPCHK(ctx, hipStreamSynchronize(s));
+        if (!ovf) break;
+        if (attempt == 1) { ctx->err = "stripe overflow at the worst-case bound (internal error)"; return W3_E_HIP; }
+        cap = worst_stripe_cap(block_size);  // rare: a block expanded past 2N+64
+    }
+    Timer tp{ctx, s, 0};
+    tp.start(2);
+    rc = run_pack(ctx, s, (const uint8_t *)ctx->stripes.p, cap, d_block_lens, nb, d_out, out_cap, total_p);
+    tp.stop();
+    tm.i = 3; tm.stop();
+    if (rc) return rc;
+    uint64_t total = 0;
+    HIPCHK(ctx, hipMemcpyAsync(&total, total_p, 8, hipMemcpyDeviceToHost, s));
+    HIPCHK(ctx, hipStreamSynchronize(s));
+    if (ctx->opt_timing) {
+        if (!two) ctx->timing.generic_ms = elapsed(ctx, 0);
+        ctx->timing.pack_ms = elapsed(ctx, 2);
+        ctx->timing.total_ms = elapsed(ctx, 3);
+    }
+    if (total > out_cap) { ctx->err = "out_cap too small"; return W3_E_NOSPACE; }
+    return W3_OK;
+}
+
+extern "C" int w3_decode_blocks_device(w3_ctx *ctx, const w3_model_spec *spec, const uint8_t *d_in, const uint32_t *d_block_lens,
+                                       size_t nblocks, size_t block_size, uint64_t orig_len, uint8_t *d_out, void *stream) {
+    int rc = check_args(ctx, (size_t)orig_len, block_size);
+    if (rc) return rc;
+    ParsedSpec ps;
+    if ((rc = parse_spec(spec, ps))) { ctx->err = "malformed model spec"; return rc; }
+    const uint64_t nb = (orig_len + block_size - 1) / block_size;
+    if (nb != nblocks) { ctx->err = "nblocks does not match orig_len/block_size"; return W3_E_INVALID; }
+    if (nb == 0) return W3_OK;
+    if (!d_in || !d_block_lens || !d_out) return W3_E_INVALID;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
+    rc = generic_decode(ctx, s, ps, d_in, d_block_lens, (uint32_t)nb, block_size, orig_len, d_out);
+    if (rc) return rc;
+    HIPCHK(ctx, hipStreamSynchronize(s));
+    return W3_OK;
+}
+
+// ---------------------------------------------------------------------------
+// host-buffer entry points
+// ---------------------------------------------------------------------------
+extern "C" int w3_encode_blocks(w3_ctx *ctx, const w3_model_spec *spec, const uint8_t *in, size_t n, size_t block_size, uint8_t *out,
+                                size_t out_cap, size_t *out_len, uint32_t *block_lens) {
+    int rc = check_args(ctx, n, block_size);
+    if (rc) return rc;
+    if (out_len) *out_len = 0;
+    const size_t nb = (n + block_size - 1) / block_size;
+    if (nb == 0) return w3_spec_validate(spec);
+    if (!in || !block_lens || !out_len) return W3_E_INVALID;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    // device output capacity: what the caller can take, but never more than the hard bound
+    size_t dcap = std::min(out_cap, w3_max_compressed_size(n, block_size));
+    ENSURE(ctx, ctx->io_in, n);
+    ENSURE(ctx, ctx->io_out, std::max<size_t>(dcap, 16));
+    ENSURE(ctx, ctx->lens, nb * 4);
+    ENSURE(ctx, ctx->total, 8);
+    HIPCHK(ctx, hipMemcpyAsync(ctx->io_in.p, in, n, hipMemcpyHostToDevice, s));
+    rc = w3_encode_blocks_device(ctx, spec, (const uint8_t *)ctx->io_in.p, n, block_size, (uint8_t *)ctx->io_out.p, dcap,
+                                 (uint32_t *)ctx->lens.p, (uint64_t *)ctx->total.p, s);
+    if (rc && rc != W3_E_NOSPACE) return rc;
+    uint64_t total = 0;
+    HIPCHK(ctx, hipMemcpy(&total, ctx->total.p, 8, hipMemcpyDeviceToHost));
+    *out_len = (size_t)total;
+    HIPCHK(ctx, hipMemcpy(block_lens, ctx->lens.p, nb * 4, hipMemcpyDeviceToHost));
+    if (rc == W3_E_NOSPACE || total > out_cap || !out) return W3_E_NOSPACE;
+    HIPCHK(ctx, hipMemcpy(out, ctx->io_out.p, (size_t)total, hipMemcpyDeviceToHost));
+    return W3_OK;
+}
+
+extern "C" int w3_decode_blocks(w3_ctx *ctx, const w3_model_spec *spec, const uint8_t *in, const uint32_t *block_lens, size_t nblocks,
+                                size_t block_size, uint64_t orig_len, uint8_t *out) {
+    int rc = check_args(ctx, (size_t)orig_len, block_size);
+    if (rc) return rc;
+    if (nblocks == 0 && orig_len == 0) return w3_spec_validate(spec);
+    if (!in || !block_lens || !out) return W3_E_INVALID;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    size_t total = 0;
+    for (size_t b = 0; b < nblocks; b++) total += block_lens[b];
+    ENSURE(ctx, ctx->io_in, std::max<size_t>(total, 16));
+    ENSURE(ctx, ctx->io_out, (size_t)orig_len);
+    ENSURE(ctx, ctx->lens, nblocks * 4);
+    HIPCHK(ctx, hipMemcpy(ctx->io_in.p, in, total, hipMemcpyHostToDevice));
+    HIPCHK(ctx, hipMemcpy(ctx->lens.p, block_lens, nblocks * 4, hipMemcpyHostToDevice));
+    rc = w3_decode_blocks_device(ctx, spec, (const uint8_t *)ctx->io_in.p, (const uint32_t *)ctx->lens.p, nblocks, block_size, orig_len,
+                                 (uint8_t *)ctx->io_out.p, ctx->stream);
+    if (rc) return rc;
+    HIPCHK(ctx, hipMemcpy(out, ctx->io_out.p, (size_t)orig_len, hipMemcpyDeviceToHost));
+    return W3_OK;
+}
+
+// ---------------------------------------------------------------------------
+// reference container: b"w30i" + u64 BE len + one stream  (main.rs:14-15, 89-144)
+// ---------------------------------------------------------------------------
+extern "C" int w3_compress_stream(w3_ctx *ctx, const w3_model_spec *spec, const uint8_t *in, size_t n, uint8_t *out, size_t out_cap,
+                                  size_t *out_len) {
+    if (!ctx || !out_len) return W3_E_INVALID;
+    *out_len = 0;
+    if (n > (1u << 28)) { ctx->err = "single-stream container limited to 2^28 bytes on the device"; return W3_E_UNSUPPORTED; }
+    int rc = w3_spec_validate(spec);
+    if (rc) return rc;
+    uint8_t hdr[12] = {'w', '3', '0', 'i'};
+    for (int i = 0; i < 8; i++) hdr[4 + i] = (uint8_t)((uint64_t)n >> (8 * (7 - i)));
+    size_t body = 0;
+    if (n == 0) {
+        // empty file: the coder still flushes x2 = 0xFFFFFFFF -> one 0xFF byte (io.rs:91-100)
+        *out_len = 13;
+        if (out_cap < 13 || !out) return W3_E_NOSPACE;
+        memcpy(out, hdr, 12);
+        out[12] = 0xFF;
+        return W3_OK;
+    }
+    uint32_t blen = 0;
+    rc = w3_encode_blocks(ctx, spec, in, n, n, out_cap > 12 && out ? out + 12 : nullptr, out_cap > 12 ? out_cap - 12 : 0, &body, &blen);
+    *out_len = body + 12;
+    if (rc) return rc;
+    memcpy(out, hdr, 12);
+    return W3_OK;
+}
+
+extern "C" int w3_decompress_stream(w3_ctx *ctx, const w3_model_spec *spec, const uint8_t *in, size_t in_len, uint8_t *out,
+                                    size_t out_cap, size_t *out_len) {
+    if (!ctx || !in || !out_len) return W3_E_INVALID;
+    *out_len = 0;
+    if (in_len < 12) { ctx->err = "truncated header"; return W3_E_FORMAT; }
+    if (memcmp(in, "w30i", 4) != 0) { ctx->err = "Magic numbers don't match up"; return W3_E_FORMAT; }
+    uint64_t len = 0;
+    for (int i = 0; i < 8; i++) len = (len << 8) | in[4 + i];
+    *out_len = (size_t)len;
+    if (len == 0) return w3_spec_validate(spec);
+    if (len > (1u << 28)) { ctx->err = "single-stream container limited to 2^28 bytes on the device"; return W3_E_UNSUPPORTED; }
+    if (len > out_cap || !out) return W3_E_NOSPACE;
+    uint32_t blen = (uint32_t)(in_len - 12);
+    uint8_t zero = 0;
+    const uint8_t *body = blen ? in + 12 : &zero;  // ACReader pads with zeros past EOF (io.rs:23-26)
+    return w3_decode_blocks(ctx, spec, body, &blen, 1, (size_t)len, len, out);
+}
+
+// ---------------------------------------------------------------------------
+// StationaryModel::new (models/ac_hash/stationary.rs:14-34): constructor-time
+// table prep on the host (8 Counters, one per bit position, index 0 = MSB).
+// ---------------------------------------------------------------------------
+extern "C" int w3_stationary_table(const uint8_t *buf, size_t n, uint16_t table[8]) {
+    if ((!buf && n) || !table) return W3_E_INVALID;
+    uint32_t c0[8] = {0}, c1[8] = {0};
+    for (size_t k = 0; k < n; k++) {
+        for (int i = 0; i < 8; i++) {
+            uint32_t bit = (buf[k] >> (7 - i)) & 1u;
+            uint32_t &c = bit ? c1[i] : c0[i];
+            if (++c == 0xFFFFu) {  // Counter::update halves BOTH counts (counter.rs:22-25)
+                c0[i] = (c0[i] >> 1) + (c0[i] & 1u);
+                c1[i] = (c1[i] >> 1) + (c1[i] & 1u);
+            }
+        }
+    }
+    for (int i = 0; i < 8; i++) {
+        uint64_t p = (1ull << 17) * ((uint64_t)c1[i] + 1) / ((uint64_t)c0[i] + c1[i] + 2);
+        table[i] = (uint16_t)((p >> 1) + (p & 1));
+    }
+    return W3_OK;
+}
+
+// ---------------------------------------------------------------------------
+// Model::predict for every step (two-phase predict kernels only)
+// ---------------------------------------------------------------------------
+extern "C" int w3_predict_blocks(w3_ctx *ctx, const w3_model_spec *spec, const uint8_t *in, size_t n, size_t block_size, uint16_t *p_out) {
+    int rc = check_args(ctx, n, block_size);
+    if (rc) return rc;
+    ParsedSpec ps;
+    if ((rc = parse_spec(spec, ps))) return rc;
+    if (n == 0) return W3_OK;
+    if (!in || !p_out) return W3_E_INVALID;
+    if (!twophase_supported(ps, block_size)) { ctx->err = "spec not covered by the two-phase predict kernels"; return W3_E_UNSUPPORTED; }
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    const uint32_t nb = (uint32_t)((n + block_size - 1) / block_size);
+    ENSURE(ctx, ctx->io_in, n);
+    HIPCHK(ctx, hipMemcpyAsync(ctx->io_in.p, in, n, hipMemcpyHostToDevice, s));
+    const uint16_t *d_p = nullptr;
+    rc = twophase_predict(ctx->tp, s, ps, (const uint8_t *)ctx->io_in.p, n, block_size, nb, &d_p, nullptr, &ctx->timing, ctx->err);
+    if (rc) return rc;
+    HIPCHK(ctx, hipStreamSynchronize(s));
+    HIPCHK(ctx, hipMemcpy(p_out, d_p, n * 16, hipMemcpyDeviceToHost));
+    return W3_OK;
+}
+
+// ---------------------------------------------------------------------------
+// device self-test
+// ---------------------------------------------------------------------------
+extern "C" int w3_selftest_counter_p(w3_ctx *ctx, uint64_t *mismatches) {
+    if (!ctx || !mismatches) return W3_E_INVALID;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    ENSURE(ctx, ctx->total, 8);
+    HIPCHK(ctx, hipMemsetAsync(ctx->total.p, 0, 8, ctx->stream));
+    for (uint32_t lo = 0; lo < 65536; lo += 4096) {
+        hipLaunchKernelGGL(k_selftest_counter_p, dim3(256 * 16), dim3(256), 0, ctx->stream, (unsigned long long *)ctx->total.p, lo, lo + 4096);
+        HIPCHK(ctx, hipGetLastError());
+    }
+    HIPCHK(ctx, hipMemcpyAsync(mismatches, ctx->total.p, 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return W3_OK;
+}

@@ -1,0 +1,198 @@
+"""Host-side mirror of the reference's model surface (src/models, src/history,
+src/mixers): same names and argument meaning, but each object only DESCRIBES a
+model — it builds the w3_model_spec the HIP kernels execute.  There is no
+per-bit Python arithmetic here; predict/update happen on the GPU."""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib as L
+
+
+class W3Error(RuntimeError):
+    def __init__(self, code, msg=""):
+        self.code = code
+        super().__init__("w3hip error %d (%s) %s" % (code, L.load().w3_strerror(code).decode(), msg))
+
+
+class StationaryModel:
+    """models/ac_hash/stationary.rs:8-58 — per-bit-position static probabilities."""
+
+    def __init__(self, buf):
+        a = np.frombuffer(bytes(buf), dtype=np.uint8)
+        t = (C.c_uint16 * 8)()
+        rc = L.load().w3_stationary_table(a.ctypes.data_as(C.c_void_p), len(a), t)
+        if rc:
+            raise W3Error(rc)
+        self.table = list(t)
+
+    @classmethod
+    def new(cls, buf):
+        return cls(buf)
+
+    @classmethod
+    def from_table(cls, table):
+        o = cls.__new__(cls)
+        o.table = [int(x) for x in table]
+        assert len(o.table) == 8
+        return o
+
+    @classmethod
+    def for_book1(cls):  # stationary.rs:40-42
+        return cls.from_table([1, 50188, 62497, 15819, 22545, 31499, 22988, 29616])
+
+    @classmethod
+    def for_enwik7(cls):  # stationary.rs:44-46
+        return cls.from_table([752, 50314, 58928, 21421, 24680, 30788, 24297, 32530])
+
+
+class RawHistory:
+    """history/raw_history.rs — last 32 bits."""
+    kind = L.W3_HIST_RAW
+    max_bits = 0
+    table = [0] * 8
+
+    @classmethod
+    def new(cls):
+        return cls()
+
+
+class ACHistory:
+    """history/ac_history.rs:9-47 — first max_bits arithmetic-coder output bits of the reversed 64-bit history."""
+    kind = L.W3_HIST_AC
+
+    def __init__(self, max_bits, model):
+        self.max_bits = int(max_bits)
+        self.table = list(model.table)
+
+    @classmethod
+    def new(cls, max_bits, model):
+        return cls(max_bits, model)
+
+
+class Model:
+    """trait Model (models/mod.rs:12-15), as a spec tree."""
+
+    def _nodes(self):
+        raise NotImplementedError
+
+    def spec(self):
+        nodes = self._nodes()
+        if len(nodes) > L.W3_MAX_NODES:
+            raise W3Error(L.W3_E_UNSUPPORTED, "model tree too large")
+        s = L.ModelSpec()
+        s.n_nodes = len(nodes)
+        for i, nd in enumerate(nodes):
+            s.nodes[i] = nd
+        rc = L.load().w3_spec_validate(C.byref(s))
+        if rc:
+            raise W3Error(rc, "model spec rejected")
+        return s
+
+
+def _leaf(bits, align, history=L.W3_HIST_NONE, max_bits=0, table=None, frozen=0):
+    nd = L.Node()
+    nd.kind = L.W3_NODE_ORDERN
+    if not (0 <= bits <= 255 and 0 <= align <= 255 and 0 <= max_bits <= 255):
+        raise W3Error(L.W3_E_INVALID, "u8 parameter out of range")  # the reference takes u8s
+    nd.bits, nd.align, nd.history, nd.max_bits, nd.frozen = bits, align, history, max_bits, frozen
+    for i, v in enumerate(table or [0] * 8):
+        nd.table[i] = v
+    return nd
+
+
+class AdaptiveModel(Model):
+    """trait AdaptiveModel (models/mod.rs:17-21): leaves that FrozenModel can wrap."""
+
+    def __init__(self, bits, align, history=None):
+        self.bits, self.align, self.history = int(bits), int(align), history
+
+    def _leaf(self, frozen=0):
+        h = self.history
+        if h is None:
+            return _leaf(self.bits, self.align, frozen=frozen)
+        return _leaf(self.bits, self.align, h.kind, h.max_bits, h.table, frozen=frozen)
+
+    def _nodes(self):
+        return [self._leaf()]
+
+
+class OrderN(AdaptiveModel):
+    """models/ordern.rs — OrderN::new(bits_in_context, alignment_bits)."""
+
+    def __init__(self, bits_in_context, alignment_bits):
+        super().__init__(bits_in_context, alignment_bits)
+
+    @classmethod
+    def new(cls, bits_in_context, alignment_bits):
+        return cls(bits_in_context, alignment_bits)
+
+
+class Order0(AdaptiveModel):
+    """models/order0.rs — 2^11 counters, ctx = alignment<<8 | last 8 bits (== OrderN(11,3), bin/cmp/main.rs:14-24)."""
+
+    def __init__(self):
+        super().__init__(11, 3)
+
+    @classmethod
+    def new(cls):
+        return cls()
+
+
+class Order1(AdaptiveModel):
+    """models/order1.rs — 2^19 counters (== OrderN(19,3))."""
+
+    def __init__(self):
+        super().__init__(19, 3)
+
+    @classmethod
+    def new(cls):
+        return cls()
+
+
+class OrderNEntropy(AdaptiveModel):
+    """models/ordern_entropy.rs — OrderNEntropy::new(bits, align, history)."""
+
+    def __init__(self, bits_in_context, alignment_bits, history):
+        super().__init__(bits_in_context, alignment_bits, history)
+
+    @classmethod
+    def new(cls, bits_in_context, alignment_bits, history):
+        return cls(bits_in_context, alignment_bits, history)
+
+
+class FrozenModel(Model):
+    """models/frozen.rs — update() advances the context but never adapts."""
+
+    def __init__(self, model):
+        if not isinstance(model, AdaptiveModel):
+            raise TypeError("FrozenModel<T: AdaptiveModel> (models/frozen.rs:3)")
+        self.model = model
+
+    @classmethod
+    def new(cls, model):
+        return cls(model)
+
+    def _nodes(self):
+        return [self.model._leaf(frozen=1)]
+
+
+class BestOfTwoModel(Model):
+    """models/mod.rs:42-75 with OpinionMixer2 (mixers/opinion_mixer2.rs)."""
+
+    def __init__(self, m1, m2):
+        self.m1, self.m2 = m1, m2
+
+    @classmethod
+    def new(cls, m1, m2):
+        return cls(m1, m2)
+
+    def _nodes(self):
+        nd = L.Node()
+        nd.kind = L.W3_NODE_BEST_OF_TWO
+        return self.m1._nodes() + self.m2._nodes() + [nd]
+
+
+def init_model():
+    """main.rs:146-152 — the main binary's default model."""
+    return OrderNEntropy.new(11, 3, ACHistory.new(8, StationaryModel.for_book1()))
