@@ -50,6 +50,7 @@ def cpu_baseline(name, sample, block_size, budget_s=15.0):
     """Oracle (kind="port": C restatement of the reference CPU path) on a bounded sample, all host cores."""
     from oracle import pyoracle as orc
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cores = min(cores, int(os.environ.get("W3_CPU_THREADS", "16")))  # a 1-GPU box's CPU share is 16 cores
     m = make_oracle_model(orc, name)
     # calibrate on 8 blocks, then size the sample for ~budget_s
     probe = sample[: 8 * block_size * max(1, cores // 8)]
@@ -106,7 +107,7 @@ def main():
 
     # rank r owns chunks [r*chunks, (r+1)*chunks) of one global seeded stream (weak scaling: n bytes per GPU)
     chunks_per_rank = (n + (1 << 20) - 1) >> 20
-    host = synth.text(n, seed=args.seed, chunk0=rank * chunks_per_rank, nthreads=max(1, (os.cpu_count() or 8) // max(1, world)))
+    host = synth.text(n, seed=args.seed, chunk0=rank * chunks_per_rank, nthreads=max(1, min(16, (os.cpu_count() or 8) // max(1, world))))
     d_in = torch.from_numpy(host).cuda()
     d_out = torch.empty(n + n // 4 + 64 * nb + 1024, dtype=torch.uint8, device="cuda")
     d_lens = torch.zeros(nb, dtype=torch.int32, device="cuda")

@@ -38,6 +38,18 @@ def pair(oracle, name):
                            lambda: oracle.OrderNEntropy(19, 3, oracle.ACHistory(16, oracle.StationaryModel.from_table(enwik7)))),
         "ac_10_2_mb0": (lambda: w3.OrderNEntropy(10, 2, w3.ACHistory(0, w3.StationaryModel.for_book1())),
                         lambda: oracle.OrderNEntropy(10, 2, oracle.ACHistory(0, oracle.StationaryModel.from_table(book1)))),
+        "ordern_5_3": (lambda: w3.OrderN(5, 3), lambda: oracle.OrderN(5, 3)),
+        "ordern_3_3": (lambda: w3.OrderN(3, 3), lambda: oracle.OrderN(3, 3)),
+        "ordern_10_3": (lambda: w3.OrderN(10, 3), lambda: oracle.OrderN(10, 3)),
+        "ac_7_3_mb4": (lambda: w3.OrderNEntropy(7, 3, w3.ACHistory(4, w3.StationaryModel.for_enwik7())),
+                       lambda: oracle.OrderNEntropy(7, 3, oracle.ACHistory(4, oracle.StationaryModel.from_table(enwik7)))),
+        "ac_11_3_mb16": (lambda: w3.OrderNEntropy(11, 3, w3.ACHistory(16, w3.StationaryModel.for_book1())),
+                         lambda: oracle.OrderNEntropy(11, 3, oracle.ACHistory(16, oracle.StationaryModel.from_table(book1)))),
+        "best_frozen_first": (lambda: w3.BestOfTwoModel(w3.FrozenModel(w3.Order1()), w3.Order0()),
+                              lambda: oracle.BestOfTwoModel(oracle.FrozenModel(oracle.Order1()), oracle.Order0())),
+        "best_ac_wide": (lambda: w3.BestOfTwoModel(w3.init_model(), w3.BestOfTwoModel(w3.OrderN(27, 3), w3.Order1())),
+                         lambda: oracle.BestOfTwoModel(oracle.OrderNEntropy(11, 3, oracle.ACHistory(8, oracle.StationaryModel.from_table(book1))),
+                                                       oracle.BestOfTwoModel(oracle.OrderN(27, 3), oracle.Order1()))),
         "frozen0": (lambda: w3.FrozenModel(w3.Order0()), lambda: oracle.FrozenModel(oracle.Order0())),
         "best01": (lambda: w3.BestOfTwoModel(w3.Order0(), w3.Order1()), lambda: oracle.BestOfTwoModel(oracle.Order0(), oracle.Order1())),
         "best012": (lambda: w3.BestOfTwoModel(w3.BestOfTwoModel(w3.Order0(), w3.Order1()), w3.OrderN(27, 3)),
@@ -65,6 +77,11 @@ ALL = ["order0", "order1", "order2", "ordern_12_0", "ordern_14_4", "ordern_9_1",
        "raw_16_3", "main_default", "ac_19_3_enwik7", "ac_10_2_mb0", "frozen0", "best01", "best012", "best_right"]
 
 
+TWOPHASE = ["order0", "order1", "order2", "ordern_8_3", "ordern_5_3", "ordern_3_3", "ordern_10_3", "main_default", "ac_7_3_mb4",
+            "ac_11_3_mb16", "frozen0", "best01", "best012", "best_right", "best_frozen_first", "best_ac_wide"]
+NOT_TWOPHASE = ["ordern_12_0", "ordern_14_4", "ordern_22_2", "ordern_30_3", "raw_16_3", "ac_19_3_enwik7"]
+
+
 def test_counter_p_exhaustive(ctx):
     import ctypes as C
     bad = C.c_uint64(123)
@@ -81,6 +98,50 @@ def test_generic_path_all_models(ctx, oracle, name):
     assert back.tobytes() == data
 
 
+@pytest.mark.parametrize("name", TWOPHASE)
+def test_twophase_path_models(ctx, oracle, name):
+    data = markov_text(70000, seed=12) + lcg_text(9000, seed=3) + bytes(3000) + markov_text(5000, seed=13)
+    out, lens = check_blocks(ctx, oracle, name, data, 16384, "twophase")
+    assert ctx.timing()["path"] == 2
+    # Model::predict for every step, straight from the predict kernels
+    dev, orc = pair(oracle, name)
+    p = ctx.predict_blocks(dev(), data[:40000], 16384)
+    want = np.concatenate([oracle.predict_all(orc(), data[o:min(o + 16384, 40000)]) for o in range(0, 40000, 16384)])
+    assert np.array_equal(p, want)
+
+
+@pytest.mark.parametrize("name", NOT_TWOPHASE)
+def test_twophase_rejects_uncovered_specs(ctx, oracle, name):
+    from weath3rb0i_amd import _lib as L
+    dev, _ = pair(oracle, name)
+    ctx.set_path("twophase")
+    try:
+        with pytest.raises(w3.W3Error) as e:
+            ctx.encode_blocks(dev(), b"abc" * 100, 64)
+        assert e.value.code == L.W3_E_UNSUPPORTED
+    finally:
+        ctx.set_path("auto")
+    out, lens = ctx.encode_blocks(dev(), b"abc" * 100, 64)  # auto falls to the generic kernel
+    assert ctx.timing()["path"] == 1
+
+
+def test_twophase_counter_saturation(ctx, oracle):
+    """Counter::update halves both counts at 65535 (counter.rs:22-25): long constant runs, incl. multiple halvings."""
+    rng = np.random.default_rng(5)
+    z = bytearray(300000)
+    for k in (70000, 140000, 141000, 290000):
+        z[k] = 0x41
+    cases = {
+        "zeros64k": (bytes(65536), 65536), "ones64k": (b"\xff" * 65536, 65536), "zeros256k": (bytes(262144), 262144),
+        "ones256k_ragged": (b"\xff" * 300001, 262144), "sparse": (bytes(z), 262144),
+        "aa": (b"\xaa" * 200000, 131072), "ab": (b"ab" * 150000, 262144),
+        "noisy_zero": (bytes(np.where(rng.random(262144) < 0.0005, 1, 0).astype(np.uint8)), 262144),
+    }
+    for cname, (data, bs) in cases.items():
+        for name in ("order0", "best012", "main_default"):
+            check_blocks(ctx, oracle, name, data, bs, "twophase")
+
+
 def test_survey_digests_on_device(ctx, oracle):
     d = lcg_text(65536)
     for m, n, sha in [(w3.Order0(), 43693, "37791f2604aaa6d6a81de79dbeb80ef09e25581d28c95f5cd5b411848aa7c64d"),
@@ -90,7 +151,7 @@ def test_survey_digests_on_device(ctx, oracle):
         assert lens.tolist() == [n] and hashlib.sha256(out.tobytes()).hexdigest() == sha
 
 
-@pytest.mark.parametrize("path", ["generic"])
+@pytest.mark.parametrize("path", ["generic", "twophase"])
 def test_edge_blocks(ctx, oracle, path):
     bs = 65536
     cases = {
@@ -150,6 +211,7 @@ def test_reference_container(ctx, oracle):
 def test_mixed_bytes_256k_blocks(ctx, oracle):
     data = mixed_bytes(600000, seed=5)
     check_blocks(ctx, oracle, "best01", data, 262144, "generic")
+    check_blocks(ctx, oracle, "best012", data, 262144, "twophase")
 
 
 def test_device_resident_api(ctx, oracle):

@@ -47,6 +47,13 @@ def load():
         raise ImportError(
             "weath3rb0i_amd: HIP extension %s is missing - run `python -m weath3rb0i_amd.build` "
             "(or __graft_entry__.build()).  There is no CPU fallback." % SO)
+    # torch bundles its own libamdhip64/libhsa-runtime64 (same sonames as /opt/rocm's).  Two HIP runtimes in one
+    # process do not work, so let torch load its copy FIRST; libw3hip.so then binds to that already-loaded runtime.
+    # Without torch (pure C/C++ hosts) the RUNPATH resolves /opt/rocm/lib.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = C.CDLL(SO)
     vp, sz = C.c_void_p, C.c_size_t
     lib.w3_abi_version.restype = C.c_int

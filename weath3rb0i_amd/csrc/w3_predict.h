@@ -1,0 +1,384 @@
+// w3_predict.h — PREDICT phase of the two-phase encoder (gfx950).
+//
+// The encoder knows every future context: a Counter-table model's context at
+// step t is a function of the input bits only (models/ordern.rs:35-43), and
+// the Counter state it will find there is the running count of the bits seen
+// earlier in that context (models/counter.rs:20-26).  So Model::predict for
+// ALL steps of a block is a "rank among equal keys" problem, solved here by one
+// wavefront per block with ballot-match ranking, 64 byte positions per round
+// and all 8 bit positions of a byte per lane:
+//
+//   key_j(i)  = last H bits before bit j of byte i      (alignment_bits == 3)
+//   state     = LDS table[j][key]  (+ the lanes below me with the same key)
+//   p_j(i)    = Counter::p(state)
+//
+// H <= 8  : one table, positions in time order                 (Order0, OrderN(<=11,3),
+//           OrderNEntropy(<=11,3,h) with keys from k_achash)
+// H == 16 : positions stably partitioned by the previous byte c1, then ranked by
+// H == 24 : the remaining 8 key bits inside each (c1[,c2]) group (Order1, OrderN(27,3)).
+//           Table entries carry the group tag, so moving to the next group is free.
+//
+// Counter saturation (the halve-both rule at 65535) is handled exactly: the
+// table holds the true Counter state, and a context that would saturate inside
+// a round is replayed serially with scalar code (rare).
+//
+// Probabilities of the leaves are merged on the fly into ONE u16 stream P with
+// OpinionMixer2's rule (leftmost leaf of maximal |p-1/2|; see w3_device.h).
+#pragma once
+#include "w3_device.h"
+
+namespace w3 {
+
+struct PredictArgs {
+    const uint8_t *in;      // original bytes (device)
+    uint64_t n;
+    uint32_t block_size, nblocks;
+    uint4 *P;               // [n] 8 x u16 per input byte, block-major (same index as `in`)
+    const uint2 *keys;      // [n] 8 x u8 precomputed keys per byte (k_achash) or null
+    uint32_t *perm;         // wide: per-wave scratch, 2 * block_size u32 each
+    uint32_t hbits;         // H = bits_in_context - 3
+    uint32_t first;         // 1 = this leaf initialises P, 0 = merge into P
+};
+
+__device__ __forceinline__ uint64_t lane_lt_mask() { return (1ull << (threadIdx.x & 63)) - 1ull; }
+__device__ __forceinline__ uint64_t lane_gt_mask() { return ~((2ull << (threadIdx.x & 63)) - 1ull); }
+
+__device__ __forceinline__ uint32_t readlane_u32(uint32_t v, int k) { return (uint32_t)__builtin_amdgcn_readlane((int)v, k); }
+__device__ __forceinline__ uint64_t readlane_u64(uint64_t v, int k) {
+    uint32_t lo = readlane_u32((uint32_t)v, k), hi = readlane_u32((uint32_t)(v >> 32), k);
+    return ((uint64_t)hi << 32) | lo;
+}
+
+// Match masks of the 8 sliding H-bit windows of w16 (window j = bits [8-j, 8-j+H) ).
+template <int H>
+__device__ __forceinline__ void match_windows(uint32_t w16, uint64_t M[8]) {
+    uint64_t X[16];
+#pragma unroll
+    for (int b = 1; b < 16; b++) {
+        if (b >= 1 && b <= 7 + H) {
+            const bool mybit = (w16 >> b) & 1u;
+            const uint64_t B = __ballot(mybit);
+            X[b] = mybit ? B : ~B;
+        }
+    }
+    if constexpr (H == 8) {
+        uint64_t A2[15], A4[13];
+#pragma unroll
+        for (int b = 1; b <= 14; b++) A2[b] = X[b] & X[b + 1];
+#pragma unroll
+        for (int b = 1; b <= 12; b++) A4[b] = A2[b] & A2[b + 2];
+#pragma unroll
+        for (int j = 0; j < 8; j++) M[j] = A4[8 - j] & A4[12 - j];
+    } else {
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            uint64_t m = ~0ull;
+#pragma unroll
+            for (int k = 0; k < H; k++) m &= X[8 - j + k];
+            M[j] = m;
+        }
+    }
+}
+
+// Match masks when the 8 keys are given explicitly (one byte per bit position).
+template <int H>
+__device__ __forceinline__ void match_keys(uint2 k8, uint64_t M[8]) {
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        const uint32_t key = ((j < 4 ? k8.x : k8.y) >> (8 * (j & 3))) & 0xFFu;
+        uint64_t m = ~0ull;
+#pragma unroll
+        for (int k = 0; k < H; k++) {
+            const bool mybit = (key >> k) & 1u;
+            const uint64_t B = __ballot(mybit);
+            m &= mybit ? B : ~B;
+        }
+        M[j] = m;
+    }
+}
+
+// One round: 64 positions x 8 bit positions.  Returns the 8 probabilities.
+//   c0      : the byte being coded at this position (bit j = (c0 >> (7-j)) & 1)
+//   key[j]  : table index per bit position
+//   M[j]    : lanes with the same key_j (any group)
+//   seg     : lanes that are valid and in the same group as me
+//   gtag    : group tag (GROUPED) — entries with another tag read as Counter::new()
+template <bool GROUPED>
+__device__ __forceinline__ void rank_round(uint32_t c0, const uint32_t key[8], const uint64_t M[8], uint64_t seg, bool valid, uint32_t gtag,
+                                           uint32_t *tbl32, uint2 *tbl64, uint32_t p[8]) {
+    const uint64_t lt = lane_lt_mask(), gt = lane_gt_mask();
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        const uint64_t Mj = M[j] & seg;
+        const uint64_t ones = __ballot((c0 >> (7 - j)) & 1u) & Mj;
+        uint32_t base;
+        if constexpr (GROUPED) {
+            const uint2 e = tbl64[j * 256 + key[j]];
+            base = e.y == gtag ? e.x : 0u;
+        } else {
+            base = tbl32[j * 256 + key[j]];
+        }
+        const uint32_t b0 = base & 0xFFFFu, b1 = base >> 16;
+        const uint32_t n1l = __popcll(ones & lt), n0l = __popcll(Mj & lt) - n1l;
+        const uint32_t t1 = __popcll(ones), t0 = __popcll(Mj) - t1;
+        uint32_t s0 = b0 + n0l, s1 = b1 + n1l;
+        uint32_t fin = (b0 + t0) | ((b1 + t1) << 16);
+        // Counter::update halves both counts when one reaches 65535 (counter.rs:22-25):
+        // replay such a context serially (uniform scalar loop; rare)
+        uint64_t satm = __ballot(valid && ((b0 + t0 >= 65535u) || (b1 + t1 >= 65535u)));
+        while (satm) {
+            const int k = __ffsll((long long)satm) - 1;
+            const uint64_t Mc = readlane_u64(Mj, k);
+            const uint64_t Oc = readlane_u64(ones, k);
+            uint32_t st = readlane_u32(base, k);
+            uint64_t it = Mc;
+            while (it) {
+                const int m = __ffsll((long long)it) - 1;
+                it &= it - 1;
+                if (lane == m) { s0 = st & 0xFFFFu; s1 = st >> 16; }
+                st = counter_update_packed(st, (uint32_t)(Oc >> m) & 1u);
+            }
+            if ((Mc >> lane) & 1ull) fin = st;
+            satm &= ~Mc;
+        }
+        p[j] = counter_p(s0, s1);
+        if (valid && (Mj & gt) == 0ull) {  // last lane of this context in the round writes the state back
+            if constexpr (GROUPED) tbl64[j * 256 + key[j]] = make_uint2(fin, gtag);
+            else tbl32[j * 256 + key[j]] = fin;
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+__device__ __forceinline__ uint4 pack_p(const uint32_t p[8]) {
+    return make_uint4(p[0] | (p[1] << 16), p[2] | (p[3] << 16), p[4] | (p[5] << 16), p[6] | (p[7] << 16));
+}
+
+// OpinionMixer2 merge of a later leaf into the running stream: replace only on
+// strictly larger distance (ties keep the earlier = left leaf).
+__device__ __forceinline__ uint32_t mix_pair(uint32_t cur, uint32_t nw) {
+    const uint32_t c_lo = cur & 0xFFFFu, c_hi = cur >> 16, n_lo = nw & 0xFFFFu, n_hi = nw >> 16;
+    const uint32_t lo = opinion_dist(n_lo) > opinion_dist(c_lo) ? n_lo : c_lo;
+    const uint32_t hi = opinion_dist(n_hi) > opinion_dist(c_hi) ? n_hi : c_hi;
+    return lo | (hi << 16);
+}
+__device__ __forceinline__ uint4 mix_p(uint4 cur, uint4 nw) {
+    return make_uint4(mix_pair(cur.x, nw.x), mix_pair(cur.y, nw.y), mix_pair(cur.z, nw.z), mix_pair(cur.w, nw.w));
+}
+
+// bytes c0..c3 at position i of a block (zeros before the block start: a fresh model's history is 0)
+__device__ __forceinline__ uint32_t load_window(const uint8_t *blk, uint32_t i) {
+    uint32_t w = blk[i];
+    if (i >= 1) w |= (uint32_t)blk[i - 1] << 8;
+    if (i >= 2) w |= (uint32_t)blk[i - 2] << 16;
+    if (i >= 3) w |= (uint32_t)blk[i - 3] << 24;
+    return w;  // c0 | c1<<8 | c2<<16 | c3<<24
+}
+
+// ---------------------------------------------------------------------------
+// H <= 8, time order.  KEYS: key bytes come from args.keys (ACHistory leaves).
+// ---------------------------------------------------------------------------
+template <int H, bool KEYS>
+__global__ void __launch_bounds__(64) k_predict_small(PredictArgs a) {
+    __shared__ uint32_t tbl[8 * 256];
+    const int lane = threadIdx.x;
+    constexpr uint32_t KM = (1u << H) - 1u;
+    for (uint32_t b = blockIdx.x; b < a.nblocks; b += gridDim.x) {
+        const uint64_t off = (uint64_t)b * a.block_size;
+        const uint32_t len = (uint32_t)((a.n - off) < a.block_size ? (a.n - off) : a.block_size);
+        const uint8_t *blk = a.in + off;
+#pragma unroll
+        for (int k = 0; k < 32; k++) tbl[k * 64 + lane] = 0u;
+        __builtin_amdgcn_wave_barrier();
+        for (uint32_t base = 0; base < len; base += 64) {
+            const uint32_t i = base + lane;
+            const bool valid = i < len;
+            uint32_t c0 = 0, key[8];
+            uint64_t M[8];
+            uint4 cur = make_uint4(0, 0, 0, 0);
+            if (valid && !a.first) cur = a.P[off + i];
+            if constexpr (KEYS) {
+                uint2 k8 = make_uint2(0, 0);
+                if (valid) { k8 = a.keys[off + i]; c0 = blk[i]; }
+#pragma unroll
+                for (int j = 0; j < 8; j++) key[j] = ((j < 4 ? k8.x : k8.y) >> (8 * (j & 3))) & KM;
+                match_keys<H>(k8, M);
+            } else {
+                uint32_t w = valid ? load_window(blk, i) : 0u;
+                c0 = w & 0xFFu;
+                const uint32_t w16 = w & 0xFFFFu;
+#pragma unroll
+                for (int j = 0; j < 8; j++) key[j] = (w16 >> (8 - j)) & KM;
+                match_windows<H>(w16, M);
+            }
+            const uint64_t seg = __ballot(valid);
+            uint32_t p[8];
+            rank_round<false>(c0, key, M, seg, valid, 0u, tbl, nullptr, p);
+            if (valid) {
+                uint4 v = pack_p(p);
+                a.P[off + i] = a.first ? v : mix_p(cur, v);
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// H == 16 / 24: stable partition of the positions by c1 (and c2), then rank.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t wave_excl_scan_u32(uint32_t v, uint32_t *total) {
+    const int lane = threadIdx.x & 63;
+    uint32_t inc = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        uint32_t o = __shfl_up(inc, d, 64);
+        if (lane >= d) inc += o;
+    }
+    *total = __shfl(inc, 63, 64);
+    return inc - v;
+}
+
+// One stable counting-sort pass of the positions by the byte `back` places
+// before them.  src == nullptr means the identity order.
+__device__ __forceinline__ void partition_pass(const uint8_t *blk, uint32_t len, uint32_t back, const uint32_t *src, uint32_t *dst, uint32_t *hist) {
+    const int lane = threadIdx.x & 63;
+    const uint64_t lt = lane_lt_mask(), gt = lane_gt_mask();
+#pragma unroll
+    for (int k = 0; k < 4; k++) hist[k * 64 + lane] = 0u;
+    __builtin_amdgcn_wave_barrier();
+    for (uint32_t base = 0; base < len; base += 64) {
+        const uint32_t e = base + lane;
+        if (e < len) {
+            const uint32_t i = src ? src[e] : e;
+            const uint32_t d = i >= back ? blk[i - back] : 0u;
+            atomicAdd(&hist[d], 1u);
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    {   // exclusive scan of the 256 bins: lane owns bins 4*lane .. 4*lane+3
+        uint32_t v0 = hist[4 * lane], v1 = hist[4 * lane + 1], v2 = hist[4 * lane + 2], v3 = hist[4 * lane + 3], tot;
+        uint32_t ex = wave_excl_scan_u32(v0 + v1 + v2 + v3, &tot);
+        hist[4 * lane] = ex; hist[4 * lane + 1] = ex + v0; hist[4 * lane + 2] = ex + v0 + v1; hist[4 * lane + 3] = ex + v0 + v1 + v2;
+    }
+    __builtin_amdgcn_wave_barrier();
+    for (uint32_t base = 0; base < len; base += 64) {
+        const uint32_t e = base + lane;
+        const bool valid = e < len;
+        uint32_t i = 0, d = 0;
+        if (valid) { i = src ? src[e] : e; d = i >= back ? blk[i - back] : 0u; }
+        uint64_t m = __ballot(valid);
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const bool mybit = (d >> k) & 1u;
+            const uint64_t B = __ballot(mybit);
+            m &= mybit ? B : ~B;
+        }
+        if (valid) {
+            const uint32_t bs = hist[d];
+            dst[bs + __popcll(m & lt)] = i;
+            if ((m & gt) == 0ull) hist[d] = bs + __popcll(m);
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+template <int NBYTES>  // 1: group = c1 (Order1); 2: group = (c1,c2) (OrderN(27,3))
+__global__ void __launch_bounds__(64) k_predict_wide(PredictArgs a) {
+    __shared__ uint2 tbl[8 * 256];
+    __shared__ uint32_t hist[256];
+    const int lane = threadIdx.x;
+    uint32_t *perm_a = a.perm + (uint64_t)blockIdx.x * 2u * a.block_size;
+    uint32_t *perm_b = perm_a + a.block_size;
+    for (uint32_t b = blockIdx.x; b < a.nblocks; b += gridDim.x) {
+        const uint64_t off = (uint64_t)b * a.block_size;
+        const uint32_t len = (uint32_t)((a.n - off) < a.block_size ? (a.n - off) : a.block_size);
+        const uint8_t *blk = a.in + off;
+        const uint32_t *perm;
+        if constexpr (NBYTES == 1) {
+            partition_pass(blk, len, 1, nullptr, perm_a, hist);
+            perm = perm_a;
+        } else {
+            partition_pass(blk, len, 2, nullptr, perm_a, hist);   // LSD: minor key c2 first
+            __threadfence_block();
+            partition_pass(blk, len, 1, perm_a, perm_b, hist);
+            perm = perm_b;
+        }
+        __threadfence_block();
+#pragma unroll
+        for (int k = 0; k < 32; k++) tbl[k * 64 + lane] = make_uint2(0u, 0u);
+        __builtin_amdgcn_wave_barrier();
+        uint32_t carry_g = 0xFFFFFFFFu;  // group of the last element of the previous round
+        for (uint32_t base = 0; base < len; base += 64) {
+            const uint32_t e = base + lane;
+            const bool valid = e < len;
+            uint32_t i = 0, w = 0;
+            if (valid) { i = perm[e]; w = load_window(blk, i); }
+            uint4 cur = make_uint4(0, 0, 0, 0);
+            if (valid && !a.first) cur = a.P[off + i];
+            const uint32_t c0 = w & 0xFFu;
+            // group id and the byte that supplies the low key bits
+            const uint32_t g = NBYTES == 1 ? ((w >> 8) & 0xFFu) : ((w >> 8) & 0xFFFFu);
+            const uint32_t ck = NBYTES == 1 ? ((w >> 16) & 0xFFu) : (w >> 24);
+            const uint32_t w16 = (ck << 8) | c0;
+            // segment = lanes of my group: groups are contiguous in the sorted order
+            uint32_t gprev = __shfl_up(g, 1, 64);
+            if (lane == 0) gprev = carry_g;
+            const uint64_t vm = __ballot(valid);
+            const uint64_t heads = __ballot(valid && g != gprev) | 1ull;  // lane 0 opens a segment (same tag if the group continues)
+            const uint64_t hle = heads & (lane_lt_mask() | (1ull << lane));
+            const int start = 63 - __clzll((long long)hle);
+            const uint64_t hgt = heads & lane_gt_mask();
+            const uint64_t below_end = hgt ? ((1ull << (__ffsll((long long)hgt) - 1)) - 1ull) : ~0ull;
+            const uint64_t seg = below_end & ~((1ull << start) - 1ull) & vm;
+            carry_g = __shfl(g, 63, 64);  // only meaningful when lane 63 is valid; the last round ends the block anyway
+            uint32_t key[8], p[8];
+            uint64_t M[8];
+#pragma unroll
+            for (int j = 0; j < 8; j++) key[j] = (w16 >> (8 - j)) & 0xFFu;
+            match_windows<8>(w16, M);
+            rank_round<true>(c0, key, M, seg, valid, g + 1u, nullptr, tbl, p);
+            if (valid) {
+                uint4 v = pack_p(p);
+                a.P[off + i] = a.first ? v : mix_p(cur, v);
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// ACHistory keys: one thread per byte position computes the 8 context hashes of
+// its bit positions (history/ac_history.rs:28-46), embarrassingly parallel.
+// ---------------------------------------------------------------------------
+struct HashArgs {
+    const uint8_t *in; uint64_t n; uint32_t block_size; uint32_t max_bits; uint32_t hmask; uint16_t table[8]; uint2 *keys;
+};
+
+__global__ void __launch_bounds__(256) k_achash(HashArgs a) {
+    const uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= a.n) return;
+    const uint64_t b = g / a.block_size;
+    const uint32_t i = (uint32_t)(g - b * a.block_size);
+    const uint8_t *blk = a.in + b * a.block_size;
+    // the last 64 bits before bit 0 of byte i, newest at bit 0
+    uint64_t hist = 0;
+    for (uint32_t k = 1; k <= 8 && k <= i; k++) hist |= (uint64_t)blk[i - k] << (8 * (k - 1));
+    const uint32_t c0 = blk[i];
+    uint32_t out[2] = {0, 0};
+#pragma unroll 1
+    for (int j = 0; j < 8; j++) {
+        const uint32_t t = i * 8u + j;
+        uint32_t h = 0;
+        if (t != 0u) h = ac_history_hash(hist, t, a.max_bits, a.table) & a.hmask;  // ctx starts at 0 (ordern_entropy.rs:19)
+        out[j >> 2] |= (h & 0xFFu) << (8 * (j & 3));
+        hist = (hist << 1) | ((c0 >> (7 - j)) & 1u);
+    }
+    a.keys[g] = make_uint2(out[0], out[1]);
+}
+
+// FrozenModel as the leftmost leaf: every p is Counter::new().p() = 32768
+__global__ void __launch_bounds__(256) k_fill_half(uint4 *P, uint64_t n) {
+    const uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g < n) P[g] = make_uint4(0x80008000u, 0x80008000u, 0x80008000u, 0x80008000u);
+}
+
+}  // namespace w3

@@ -1,12 +1,152 @@
-// w3_twophase.h — placeholder until the two-phase kernels land (next commit).
+// w3_twophase.h — host orchestration of the two-phase encoder:
+//   predict (w3_predict.h): all leaves' Counter probabilities for every step, merged into P
+//   code    (w3_coder.h)  : lane-per-block arithmetic coder over P
+// Covered specs: every leaf is FrozenModel, or has alignment_bits == 3 and
+//   H = bits-3 <= 8 (any history), or H in {16, 24} with raw history.
+// Anything else runs on the generic path (w3_generic.h).
 #pragma once
 #include <hip/hip_runtime.h>
+
+#include <algorithm>
 #include <string>
+
+#include "w3_coder.h"
+#include "w3_predict.h"
 #include "w3_spec.h"
 
-struct TwoPhaseWs { void release() {} };
-static inline bool twophase_supported(const ParsedSpec &, size_t) { return false; }
-static inline int twophase_encode(TwoPhaseWs &, hipStream_t, const ParsedSpec &, const uint8_t *, size_t, size_t, uint32_t, uint8_t *,
-                                  uint32_t, uint32_t *, uint32_t *, hipEvent_t *, w3_timing *, std::string &) { return W3_E_UNSUPPORTED; }
-static inline int twophase_predict(TwoPhaseWs &, hipStream_t, const ParsedSpec &, const uint8_t *, size_t, size_t, uint32_t,
-                                   const uint16_t **, hipEvent_t *, w3_timing *, std::string &) { return W3_E_UNSUPPORTED; }
+struct TwoPhaseWs {
+    void *P = nullptr, *keys = nullptr, *perm = nullptr;
+    size_t P_cap = 0, keys_cap = 0, perm_cap = 0;
+    void release() {
+        if (P) (void)hipFree(P);
+        if (keys) (void)hipFree(keys);
+        if (perm) (void)hipFree(perm);
+        P = keys = perm = nullptr;
+        P_cap = keys_cap = perm_cap = 0;
+    }
+};
+
+static inline int tp_ensure(void *&p, size_t &cap, size_t bytes, std::string &err) {
+    if (p && bytes <= cap) return W3_OK;
+    if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
+    hipError_t e = hipMalloc(&p, std::max<size_t>(bytes, 256));
+    if (e != hipSuccess) { p = nullptr; (void)hipGetLastError(); err = "hipMalloc(" + std::to_string(bytes) + ") for the two-phase workspace failed"; return W3_E_NOMEM; }
+    cap = std::max<size_t>(bytes, 256);
+    return W3_OK;
+}
+
+enum { LEAF_FROZEN = 0, LEAF_SMALL = 1, LEAF_SMALL_AC = 2, LEAF_WIDE1 = 3, LEAF_WIDE2 = 4, LEAF_NONE = -1 };
+
+static inline int leaf_class(const w3_node &nd) {
+    if (nd.frozen) return LEAF_FROZEN;
+    if (nd.align != 3 || nd.bits < 3) return LEAF_NONE;
+    const int H = nd.bits - 3;
+    if (H <= 8) return nd.history == W3_HIST_AC ? LEAF_SMALL_AC : LEAF_SMALL;
+    if (nd.history == W3_HIST_AC) return LEAF_NONE;
+    if (H == 16) return LEAF_WIDE1;
+    if (H == 24) return LEAF_WIDE2;
+    return LEAF_NONE;
+}
+
+static inline bool twophase_supported(const ParsedSpec &ps, size_t block_size) {
+    if (block_size > (1u << 24)) return false;
+    for (int l = 0; l < ps.n_leaves; l++)
+        if (leaf_class(ps.leaf[l]) == LEAF_NONE) return false;
+    return true;
+}
+
+template <bool KEYS>
+static inline void launch_small(int H, dim3 grid, hipStream_t s, const w3::PredictArgs &pa) {
+    switch (H) {
+    case 0: hipLaunchKernelGGL((w3::k_predict_small<0, KEYS>), grid, dim3(64), 0, s, pa); break;
+    case 1: hipLaunchKernelGGL((w3::k_predict_small<1, KEYS>), grid, dim3(64), 0, s, pa); break;
+    case 2: hipLaunchKernelGGL((w3::k_predict_small<2, KEYS>), grid, dim3(64), 0, s, pa); break;
+    case 3: hipLaunchKernelGGL((w3::k_predict_small<3, KEYS>), grid, dim3(64), 0, s, pa); break;
+    case 4: hipLaunchKernelGGL((w3::k_predict_small<4, KEYS>), grid, dim3(64), 0, s, pa); break;
+    case 5: hipLaunchKernelGGL((w3::k_predict_small<5, KEYS>), grid, dim3(64), 0, s, pa); break;
+    case 6: hipLaunchKernelGGL((w3::k_predict_small<6, KEYS>), grid, dim3(64), 0, s, pa); break;
+    case 7: hipLaunchKernelGGL((w3::k_predict_small<7, KEYS>), grid, dim3(64), 0, s, pa); break;
+    default: hipLaunchKernelGGL((w3::k_predict_small<8, KEYS>), grid, dim3(64), 0, s, pa); break;
+    }
+}
+
+// Runs the predict kernels of every leaf; *d_P receives the merged stream.
+static inline int twophase_predict(TwoPhaseWs &ws, hipStream_t s, const ParsedSpec &ps, const uint8_t *d_in, size_t n, size_t block_size,
+                                   uint32_t nb, const uint16_t **d_P, hipEvent_t *ev, w3_timing *tm, std::string &err) {
+    int rc = tp_ensure(ws.P, ws.P_cap, n * 16, err);
+    if (rc) return rc;
+    const uint32_t grid_small = std::min<uint32_t>(nb, 256 * 16);
+    const uint32_t grid_wide = std::min<uint32_t>(nb, 256 * 8);
+    bool need_keys = false, need_perm = false;
+    for (int l = 0; l < ps.n_leaves; l++) {
+        int c = leaf_class(ps.leaf[l]);
+        need_keys |= c == LEAF_SMALL_AC;
+        need_perm |= c == LEAF_WIDE1 || c == LEAF_WIDE2;
+    }
+    if (need_keys && (rc = tp_ensure(ws.keys, ws.keys_cap, n * 8, err))) return rc;
+    if (need_perm && (rc = tp_ensure(ws.perm, ws.perm_cap, (size_t)grid_wide * 2 * block_size * 4, err))) return rc;
+
+    if (ev) (void)hipEventRecord(ev[0], s);
+    bool first = true;
+    uint64_t bytes = 0;
+    for (int l = 0; l < ps.n_leaves; l++) {
+        const w3_node &nd = ps.leaf[l];
+        const int c = leaf_class(nd);
+        if (c == LEAF_FROZEN) {
+            // Counter never trained: p == 32768, distance 0 -> can only matter as the leftmost leaf
+            if (first) {
+                hipLaunchKernelGGL(w3::k_fill_half, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (uint4 *)ws.P, (uint64_t)n);
+                bytes += n * 16;
+                first = false;
+            }
+            continue;
+        }
+        w3::PredictArgs pa;
+        memset(&pa, 0, sizeof pa);
+        pa.in = d_in; pa.n = n; pa.block_size = (uint32_t)block_size; pa.nblocks = nb; pa.P = (uint4 *)ws.P;
+        pa.hbits = nd.bits - 3; pa.first = first ? 1u : 0u;
+        bytes += n * (first ? 17 : 33);
+        if (c == LEAF_SMALL_AC) {
+            w3::HashArgs ha;
+            memset(&ha, 0, sizeof ha);
+            ha.in = d_in; ha.n = n; ha.block_size = (uint32_t)block_size; ha.max_bits = nd.max_bits;
+            ha.hmask = (1u << (nd.bits - 3)) - 1u; ha.keys = (uint2 *)ws.keys;
+            memcpy(ha.table, nd.table, sizeof ha.table);
+            hipLaunchKernelGGL(w3::k_achash, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, ha);
+            pa.keys = (const uint2 *)ws.keys;
+            launch_small<true>(nd.bits - 3, dim3(grid_small), s, pa);
+            bytes += n * 17;
+        } else if (c == LEAF_SMALL) {
+            launch_small<false>(nd.bits - 3, dim3(grid_small), s, pa);
+        } else {
+            pa.perm = (uint32_t *)ws.perm;
+            if (c == LEAF_WIDE1) hipLaunchKernelGGL(w3::k_predict_wide<1>, dim3(grid_wide), dim3(64), 0, s, pa);
+            else hipLaunchKernelGGL(w3::k_predict_wide<2>, dim3(grid_wide), dim3(64), 0, s, pa);
+            bytes += n * 8 * (c == LEAF_WIDE1 ? 1 : 3);  // permutation scratch write/read
+        }
+        first = false;
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) { err = std::string("predict launch: ") + hipGetErrorString(e); return W3_E_HIP; }
+    }
+    if (ev) (void)hipEventRecord(ev[1], s);
+    if (tm) tm->predict_bytes = bytes;
+    if (d_P) *d_P = (const uint16_t *)ws.P;
+    return W3_OK;
+}
+
+static inline int twophase_encode(TwoPhaseWs &ws, hipStream_t s, const ParsedSpec &ps, const uint8_t *d_in, size_t n, size_t block_size,
+                                  uint32_t nb, uint8_t *stripes, uint32_t stripe_cap, uint32_t *d_lens, uint32_t *d_flag, hipEvent_t *ev,
+                                  w3_timing *tm, std::string &err) {
+    int rc = twophase_predict(ws, s, ps, d_in, n, block_size, nb, nullptr, ev, tm, err);
+    if (rc) return rc;
+    w3::CoderArgs ca;
+    ca.in = d_in; ca.n = n; ca.block_size = (uint32_t)block_size; ca.nblocks = nb; ca.P = (const uint4 *)ws.P;
+    ca.stripes = stripes; ca.stripe_cap = stripe_cap; ca.out_len = d_lens; ca.overflow = d_flag;
+    if (ev) (void)hipEventRecord(ev[2], s);
+    hipLaunchKernelGGL(w3::k_coder, dim3((nb + 63) / 64), dim3(64), 0, s, ca);
+    if (ev) (void)hipEventRecord(ev[3], s);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { err = std::string("coder launch: ") + hipGetErrorString(e); return W3_E_HIP; }
+    if (tm) { tm->n_coder_launches = 1; tm->coder_bytes = (uint64_t)n * 17; }
+    return W3_OK;
+}

@@ -374,6 +374,7 @@ extern "C" int w3_encode_blocks_device(w3_ctx *ctx, const w3_model_spec *spec, c
     HIPCHK(ctx, hipStreamSynchronize(s));
     if (ctx->opt_timing) {
         if (!two) ctx->timing.generic_ms = elapsed(ctx, 0);
+        else { ctx->timing.predict_ms = elapsed(ctx, 0); ctx->timing.coder_ms = elapsed(ctx, 1); ctx->timing.coder_bytes += total; }
         ctx->timing.pack_ms = elapsed(ctx, 2);
         ctx->timing.total_ms = elapsed(ctx, 3);
     }
