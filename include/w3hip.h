@@ -88,7 +88,9 @@ int         w3_spec_validate(const w3_model_spec *spec);
 /* Options */
 enum {
     W3_OPT_PATH   = 1,  /* W3_PATH_*: which device implementation encode uses      */
-    W3_OPT_TIMING = 2   /* 1 = record per-kernel hipEvent timings (w3_get_timing) */
+    W3_OPT_TIMING = 2,  /* 1 = record per-kernel hipEvent timings (w3_get_timing) */
+    W3_OPT_CODER  = 3,  /* two-phase coder kernel: 0 = k_coder_fast, 2 = robust k_coder only */
+    W3_OPT_ACC_LIMIT = 4 /* test hook (19..46): accumulator fill at which the fast coder hands a block back */
 };
 enum { W3_PATH_AUTO = 0, W3_PATH_GENERIC = 1, W3_PATH_TWOPHASE = 2 };
 int         w3_ctx_set_option(w3_ctx *ctx, int opt, int64_t value);
@@ -160,6 +162,8 @@ typedef struct w3_timing {
     uint32_t n_coder_launches;
     uint64_t coder_bytes;  /* algorithmic HBM bytes of the coder launches    */
     uint64_t predict_bytes;
+    uint32_t n_recoded_blocks; /* blocks the fast coder handed to the robust coder */
+    uint32_t reserved;
 } w3_timing;
 int w3_get_timing(const w3_ctx *ctx, w3_timing *out);
 

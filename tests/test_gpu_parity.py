@@ -142,6 +142,31 @@ def test_twophase_counter_saturation(ctx, oracle):
             check_blocks(ctx, oracle, name, data, bs, "twophase")
 
 
+def test_coder_variants_and_fallback(ctx, oracle):
+    """k_coder_fast (slot/carry accumulator) the robust k_coder, and the hand-back path."""
+    data = markov_text(60000, seed=31) + bytes(5000) + np.random.default_rng(2).integers(0, 256, 20000, dtype=np.uint8).tobytes()
+    want, wlens = oracle.encode_blocks(oracle.BestOfTwoModel(oracle.Order0(), oracle.Order1()), data, 8192, nthreads=8)
+    model = w3.BestOfTwoModel(w3.Order0(), w3.Order1())
+    ctx.set_path("twophase")
+    try:
+        for mode in ("fast", "robust"):
+            ctx.set_coder(mode)
+            out, lens = ctx.encode_blocks(model, data, 8192)
+            assert lens.tolist() == wlens.tolist() and out.tobytes() == want.tobytes(), mode
+            assert ctx.timing()["n_recoded_blocks"] == 0
+        ctx.set_coder("fast")
+        for limit in (19, 24, 33):  # force the fast coder to give blocks back to k_coder
+            ctx.set_acc_limit(limit)
+            out, lens = ctx.encode_blocks(model, data, 8192)
+            assert lens.tolist() == wlens.tolist() and out.tobytes() == want.tobytes(), limit
+            if limit == 19:
+                assert ctx.timing()["n_recoded_blocks"] > 0
+    finally:
+        ctx.set_acc_limit(46)
+        ctx.set_coder("fast")
+        ctx.set_path("auto")
+
+
 def test_survey_digests_on_device(ctx, oracle):
     d = lcg_text(65536)
     for m, n, sha in [(w3.Order0(), 43693, "37791f2604aaa6d6a81de79dbeb80ef09e25581d28c95f5cd5b411848aa7c64d"),

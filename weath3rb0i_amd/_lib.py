@@ -10,7 +10,7 @@ W3_MAX_NODES = 31
 W3_NODE_ORDERN, W3_NODE_BEST_OF_TWO = 1, 2
 W3_HIST_NONE, W3_HIST_RAW, W3_HIST_AC = 0, 1, 2
 W3_OK, W3_E_INVALID, W3_E_NOSPACE, W3_E_HIP, W3_E_UNSUPPORTED, W3_E_NOMEM, W3_E_FORMAT = 0, -1, -2, -3, -4, -5, -6
-W3_OPT_PATH, W3_OPT_TIMING = 1, 2
+W3_OPT_PATH, W3_OPT_TIMING, W3_OPT_CODER, W3_OPT_ACC_LIMIT = 1, 2, 3, 4
 W3_PATH_AUTO, W3_PATH_GENERIC, W3_PATH_TWOPHASE = 0, 1, 2
 
 
@@ -26,7 +26,7 @@ class ModelSpec(C.Structure):
 class Timing(C.Structure):
     _fields_ = [("predict_ms", C.c_float), ("coder_ms", C.c_float), ("pack_ms", C.c_float), ("generic_ms", C.c_float),
                 ("total_ms", C.c_float), ("path", C.c_uint32), ("n_coder_launches", C.c_uint32),
-                ("coder_bytes", C.c_uint64), ("predict_bytes", C.c_uint64)]
+                ("coder_bytes", C.c_uint64), ("predict_bytes", C.c_uint64), ("n_recoded_blocks", C.c_uint32), ("reserved", C.c_uint32)]
 
 
 EXPORTS = [

@@ -1,8 +1,24 @@
 // w3_coder.h — CODE phase of the two-phase encoder: one wavefront lane per
 // block runs the serial arithmetic-coder recurrence (arithmetic_coder.rs:41-65)
-// over the probabilities the predict phase left in P.  The coder state
-// (x1, x2, pending-parity count, bit accumulator) lives in the lane's VGPRs;
-// nothing but P, the input byte and the output stripe touches memory.
+// over the probabilities the predict phase left in P.  The coder state lives
+// in the lane's VGPRs; only P, the input byte and the output stripe touch
+// memory.  The serial chain (block_size*8 dependent steps per lane) bounds the
+// whole encoder, so k_coder_fast is written for minimum instructions per step:
+//
+//  * both renormalisation loops (:51-62) collapse into ONE shift by
+//    s = n + m, found with two clz (n equal leading bits, then m E3 bits).
+//  * pending-parity bits (ACWriter::rev_bits, io.rs:56,66-68,84-87) are never
+//    counted.  The accumulator always ends in a "slot": a 0 that stands for the
+//    next real output bit b, followed by one 1 per pending bit.  write_bit's
+//    rule "b, then rev_bits copies of !b" is then a single add of b into the
+//    accumulator (0111..1 + 1 = 1000..0).  After the update, the top s+1 bits
+//    of x1 are exactly  b | rest(n-1) | 0 | 1^m, i.e. the bits to append plus
+//    the new slot, so emission is: acc += x1>>31; acc = acc<<s | bfe(x1,31-s,s).
+//  * bits leave the accumulator 32 at a time once per input byte, only from
+//    above the slot (so a later carry never has to reach memory).
+//  * a lane whose pending run outgrows the 64-bit accumulator (probability
+//    ~2^-39 per E3 episode; adversarial inputs can force it) gives up and its
+//    block is re-coded by k_coder (counted pending bits, any length).
 #pragma once
 #include "w3_device.h"
 
@@ -16,12 +32,19 @@ struct CoderArgs {
     uint8_t *stripes;      // block-major output stripes
     uint32_t stripe_cap;
     uint32_t *out_len;     // [nblocks]
-    uint32_t *overflow;
+    uint32_t *flags;       // [0] stripe overflow, [1] number of blocks in redo
+    uint32_t *redo;        // fast coder: blocks to re-code; safe coder: list to process (or null = all)
+    uint32_t n_redo;
+    uint32_t acc_limit;    // fast coder: max bits held before a step (46 = 64 - 18)
 };
 
+// Robust coder: counted pending bits (Encoder in w3_device.h).  Codes the
+// blocks listed in redo[0..n_redo) or, when redo == nullptr, every block.
 __global__ void __launch_bounds__(64) k_coder(CoderArgs a) {
-    const uint32_t b = blockIdx.x * 64u + threadIdx.x;
-    if (b >= a.nblocks) return;
+    const uint32_t idx = blockIdx.x * 64u + threadIdx.x;
+    uint32_t b;
+    if (a.redo) { if (idx >= a.n_redo) return; b = a.redo[idx]; }
+    else { if (idx >= a.nblocks) return; b = idx; }
     const uint64_t off = (uint64_t)b * a.block_size;
     const uint32_t len = (uint32_t)((a.n - off) < a.block_size ? (a.n - off) : a.block_size);
     const uint4 *Pb = a.P + off;
@@ -42,7 +65,120 @@ __global__ void __launch_bounds__(64) k_coder(CoderArgs a) {
     }
     const uint32_t produced = enc.flush();
     a.out_len[b] = produced;
-    if (produced > a.stripe_cap) atomicOr(a.overflow, 1u);
+    if (produced > a.stripe_cap) atomicOr(&a.flags[0], 1u);
+}
+
+// ---------------------------------------------------------------------------
+// fast coder
+// ---------------------------------------------------------------------------
+struct FastEnc {
+    uint32_t x1, x2;
+    uint64_t acc;   // low nb bits valid; ends with slot(0) + one 1 per pending bit
+    uint32_t nb;
+    uint32_t pos;   // bytes written
+};
+
+// P holds Counter::p values only: 1..65535 (models/counter.rs:13-18), never 0.
+// With range >= 2^30 before the step, the new range is >= 2^14-1, so x1 != x2
+// afterwards and s = n + m <= 18.
+// bitmask = 0xFFFFFFFF when the coded bit is 1, else 0 (prepared off the critical path).
+__device__ __forceinline__ void fast_step(FastEnc &e, uint32_t bitmask, uint32_t p32) {
+    const uint32_t range = e.x2 - e.x1;
+    const uint32_t xmid = e.x1 + __umulhi(range, p32);                                        // lerp, :112-116
+    e.x1 = (e.x1 & bitmask) | ((xmid + 1u) & ~bitmask);                                       // :45-48, branch- and VCC-free (v_bfi)
+    e.x2 = (xmid & bitmask) | (e.x2 & ~bitmask);
+    const uint32_t n = (uint32_t)__builtin_clz(e.x1 ^ e.x2);                                  // loop 1 trip count (x1 != x2)
+    const uint32_t u = ~(e.x1 & ~e.x2) & (0x7FFFFFFFu >> n);                                  // != 0 because s <= 18
+    const uint32_t c = (uint32_t)__builtin_clz(u);                                            // s + 1 = n + (loop 2 trip count) + 1
+    const uint32_t s = c - 1u;
+    e.acc += e.x1 >> 31;                                                                      // b into the slot (0 when n == 0)
+    e.acc = (e.acc << s) | __builtin_amdgcn_ubfe(e.x1, 32u - c, s);                           // rest | new slot | pending ones
+    e.nb += s;
+    e.x1 = (e.x1 << c) >> 1;                                                                  // == (x1 << s) & 0x7FFFFFFF
+    e.x2 = ~((~e.x2 << c) >> 1);                                                              // == (x2 << s) | 0x80000000 | ones(s)
+}
+
+__device__ __forceinline__ uint32_t trailing_ones64(uint64_t v) {
+    const uint64_t z = ~v;
+    return z ? (uint32_t)(__ffsll((long long)z) - 1) : 64u;
+}
+
+__global__ void __launch_bounds__(64) k_coder_fast(CoderArgs a) {
+    const uint32_t b = blockIdx.x * 64u + threadIdx.x;
+    if (b >= a.nblocks) return;
+    const uint64_t off = (uint64_t)b * a.block_size;
+    const uint32_t len = (uint32_t)((a.n - off) < a.block_size ? (a.n - off) : a.block_size);
+    const uint4 *Pb = a.P + off;
+    const uint8_t *blk = a.in + off;
+    uint8_t *out = a.stripes + (uint64_t)b * a.stripe_cap;
+    const uint32_t cap = a.stripe_cap, limit = a.acc_limit;
+    FastEnc e;
+    e.x1 = 0u; e.x2 = 0xFFFFFFFFu; e.acc = 0ull; e.nb = 1u; e.pos = 0u;   // one slot: the first output bit
+    bool failed = false;
+
+    uint4 pv = Pb[0];
+    uint32_t byte = blk[0];
+    for (uint32_t i = 0; i < len; i++) {
+        const uint4 cur = pv;
+        const uint32_t cb = byte;
+        if (i + 1 < len) { pv = Pb[i + 1]; byte = blk[i + 1]; }   // prefetch the next step's operands
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            if (__builtin_expect(e.nb > limit, 0)) {
+                // accumulator nearly full: drain finalised bytes (those above the slot) one at a time
+                const uint32_t pend = trailing_ones64(e.acc) + 1u;
+#pragma unroll 1
+                while (e.nb >= pend + 8u) {
+                    const uint8_t v = (uint8_t)(e.acc >> (e.nb - 8u));
+                    if (e.pos < cap) out[e.pos] = v;
+                    e.pos += 1u;
+                    e.nb -= 8u;
+                }
+                if (e.nb > limit) {  // pending run longer than the accumulator: hand the block to k_coder
+                    failed = true;
+                    e.acc = 0ull; e.nb = 1u;
+                }
+            }
+            const uint32_t w = j < 2 ? cur.x : j < 4 ? cur.y : j < 6 ? cur.z : cur.w;
+            const uint32_t p32 = (j & 1) ? (w & 0xFFFF0000u) : (w << 16);
+            fast_step(e, (uint32_t)__builtin_amdgcn_sbfe((int)cb, 7 - j, 1), p32);
+        }
+        // once per input byte: move 32 finalised bits out (never the slot or the pending ones)
+        const uint32_t lo = (uint32_t)e.acc;
+        const uint32_t pend = (~lo ? (uint32_t)__builtin_ctz(~lo) : 32u) + 1u;   // slot + pending ones (>= 33: nothing to move)
+        if (e.nb >= pend + 32u) {
+            const uint32_t wv = (uint32_t)(e.acc >> (e.nb - 32u));
+            if (e.pos + 4u <= cap) {
+                const uint32_t be = __builtin_bswap32(wv);
+                __builtin_memcpy(out + e.pos, &be, 4);
+            }
+            e.pos += 4u;
+            e.nb -= 32u;
+        }
+    }
+    // ArithmeticCoder::flush -> ACWriter::flush(x2) (arithmetic_coder.rs:67-71, io.rs:91-100):
+    // first bit x2>>31 (= 1) resolves the slot and the pending bits, then x2's next bits pad to a byte
+    e.acc += 1ull;
+    const uint32_t idx = e.nb & 7u;
+    if (idx) {
+        const uint32_t k = 8u - idx;
+        e.acc = (e.acc << k) | ((e.x2 << 1) >> (32u - k));
+        e.nb += k;
+    }
+#pragma unroll 1
+    while (e.nb >= 8u) {
+        const uint8_t v = (uint8_t)(e.acc >> (e.nb - 8u));
+        if (e.pos < cap) out[e.pos] = v;
+        e.pos += 1u;
+        e.nb -= 8u;
+    }
+    if (failed) {
+        const uint32_t k = atomicAdd(&a.flags[1], 1u);
+        a.redo[k] = b;
+    } else {
+        a.out_len[b] = e.pos;
+        if (e.pos > cap) atomicOr(&a.flags[0], 1u);
+    }
 }
 
 }  // namespace w3

@@ -191,23 +191,31 @@ __global__ void __launch_bounds__(64) k_predict_small(PredictArgs a) {
 #pragma unroll
         for (int k = 0; k < 32; k++) tbl[k * 64 + lane] = 0u;
         __builtin_amdgcn_wave_barrier();
+        // operands of round r+1 are loaded while round r is ranked (the loop is issue bound otherwise)
+        uint32_t nw = 0; uint2 nk = make_uint2(0, 0); uint4 ncur = make_uint4(0, 0, 0, 0);
+        if (lane < len) {
+            if constexpr (KEYS) { nk = a.keys[off + lane]; nw = blk[lane]; } else nw = load_window(blk, lane);
+            if (!a.first) ncur = a.P[off + lane];
+        }
         for (uint32_t base = 0; base < len; base += 64) {
             const uint32_t i = base + lane;
             const bool valid = i < len;
+            const uint32_t w = nw; const uint2 k8 = nk; const uint4 cur = ncur;
+            if (i + 64 < len) {
+                if constexpr (KEYS) { nk = a.keys[off + i + 64]; nw = blk[i + 64]; } else nw = load_window(blk, i + 64);
+                if (!a.first) ncur = a.P[off + i + 64];
+            }
             uint32_t c0 = 0, key[8];
             uint64_t M[8];
-            uint4 cur = make_uint4(0, 0, 0, 0);
-            if (valid && !a.first) cur = a.P[off + i];
             if constexpr (KEYS) {
-                uint2 k8 = make_uint2(0, 0);
-                if (valid) { k8 = a.keys[off + i]; c0 = blk[i]; }
+                c0 = valid ? w : 0u;
 #pragma unroll
                 for (int j = 0; j < 8; j++) key[j] = ((j < 4 ? k8.x : k8.y) >> (8 * (j & 3))) & KM;
-                match_keys<H>(k8, M);
+                match_keys<H>(valid ? k8 : make_uint2(0, 0), M);
             } else {
-                uint32_t w = valid ? load_window(blk, i) : 0u;
-                c0 = w & 0xFFu;
-                const uint32_t w16 = w & 0xFFFFu;
+                const uint32_t wv = valid ? w : 0u;
+                c0 = wv & 0xFFu;
+                const uint32_t w16 = wv & 0xFFFFu;
 #pragma unroll
                 for (int j = 0; j < 8; j++) key[j] = (w16 >> (8 - j)) & KM;
                 match_windows<H>(w16, M);
@@ -246,39 +254,46 @@ __device__ __forceinline__ void partition_pass(const uint8_t *blk, uint32_t len,
 #pragma unroll
     for (int k = 0; k < 4; k++) hist[k * 64 + lane] = 0u;
     __builtin_amdgcn_wave_barrier();
-    for (uint32_t base = 0; base < len; base += 64) {
-        const uint32_t e = base + lane;
-        if (e < len) {
-            const uint32_t i = src ? src[e] : e;
-            const uint32_t d = i >= back ? blk[i - back] : 0u;
-            atomicAdd(&hist[d], 1u);
+    {   // histogram; (i, digit) of round r+1 are fetched while round r is counted
+        uint32_t i_n = 0, d_n = 0;
+        if ((uint32_t)lane < len) { i_n = src ? src[lane] : (uint32_t)lane; d_n = i_n >= back ? blk[i_n - back] : 0u; }
+        for (uint32_t base = 0; base < len; base += 64) {
+            const uint32_t e = base + lane;
+            const uint32_t d = d_n;
+            if (e + 64u < len) { i_n = src ? src[e + 64u] : e + 64u; d_n = i_n >= back ? blk[i_n - back] : 0u; }
+            if (e < len) atomicAdd(&hist[d], 1u);
         }
     }
     __builtin_amdgcn_wave_barrier();
     {   // exclusive scan of the 256 bins: lane owns bins 4*lane .. 4*lane+3
         uint32_t v0 = hist[4 * lane], v1 = hist[4 * lane + 1], v2 = hist[4 * lane + 2], v3 = hist[4 * lane + 3], tot;
         uint32_t ex = wave_excl_scan_u32(v0 + v1 + v2 + v3, &tot);
+        __builtin_amdgcn_wave_barrier();
         hist[4 * lane] = ex; hist[4 * lane + 1] = ex + v0; hist[4 * lane + 2] = ex + v0 + v1; hist[4 * lane + 3] = ex + v0 + v1 + v2;
     }
     __builtin_amdgcn_wave_barrier();
-    for (uint32_t base = 0; base < len; base += 64) {
-        const uint32_t e = base + lane;
-        const bool valid = e < len;
-        uint32_t i = 0, d = 0;
-        if (valid) { i = src ? src[e] : e; d = i >= back ? blk[i - back] : 0u; }
-        uint64_t m = __ballot(valid);
+    {
+        uint32_t i_n = 0, d_n = 0;
+        if ((uint32_t)lane < len) { i_n = src ? src[lane] : (uint32_t)lane; d_n = i_n >= back ? blk[i_n - back] : 0u; }
+        for (uint32_t base = 0; base < len; base += 64) {
+            const uint32_t e = base + lane;
+            const bool valid = e < len;
+            const uint32_t i = i_n, d = valid ? d_n : 0u;
+            if (e + 64u < len) { i_n = src ? src[e + 64u] : e + 64u; d_n = i_n >= back ? blk[i_n - back] : 0u; }
+            uint64_t m = __ballot(valid);
 #pragma unroll
-        for (int k = 0; k < 8; k++) {
-            const bool mybit = (d >> k) & 1u;
-            const uint64_t B = __ballot(mybit);
-            m &= mybit ? B : ~B;
+            for (int k = 0; k < 8; k++) {
+                const bool mybit = (d >> k) & 1u;
+                const uint64_t B = __ballot(mybit);
+                m &= mybit ? B : ~B;
+            }
+            if (valid) {
+                const uint32_t bs = hist[d];
+                dst[bs + __popcll(m & lt)] = i;
+                if ((m & gt) == 0ull) hist[d] = bs + __popcll(m);
+            }
+            __builtin_amdgcn_wave_barrier();
         }
-        if (valid) {
-            const uint32_t bs = hist[d];
-            dst[bs + __popcll(m & lt)] = i;
-            if ((m & gt) == 0ull) hist[d] = bs + __popcll(m);
-        }
-        __builtin_amdgcn_wave_barrier();
     }
 }
 
@@ -308,13 +323,18 @@ __global__ void __launch_bounds__(64) k_predict_wide(PredictArgs a) {
         for (int k = 0; k < 32; k++) tbl[k * 64 + lane] = make_uint2(0u, 0u);
         __builtin_amdgcn_wave_barrier();
         uint32_t carry_g = 0xFFFFFFFFu;  // group of the last element of the previous round
+        // software pipeline: perm two rounds ahead, window bytes and the P word one round ahead
+        uint32_t i_n = 0, i_nn = 0, w_n = 0; uint4 cur_n = make_uint4(0, 0, 0, 0);
+        if (lane < len) { i_n = perm[lane]; }
+        if (lane + 64u < len) i_nn = perm[lane + 64u];
+        if (lane < len) { w_n = load_window(blk, i_n); if (!a.first) cur_n = a.P[off + i_n]; }
         for (uint32_t base = 0; base < len; base += 64) {
             const uint32_t e = base + lane;
             const bool valid = e < len;
-            uint32_t i = 0, w = 0;
-            if (valid) { i = perm[e]; w = load_window(blk, i); }
-            uint4 cur = make_uint4(0, 0, 0, 0);
-            if (valid && !a.first) cur = a.P[off + i];
+            const uint32_t i = i_n; const uint32_t w = valid ? w_n : 0u; const uint4 cur = cur_n;
+            i_n = i_nn;
+            if (e + 128u < len) i_nn = perm[e + 128u];
+            if (e + 64u < len) { w_n = load_window(blk, i_n); if (!a.first) cur_n = a.P[off + i_n]; }
             const uint32_t c0 = w & 0xFFu;
             // group id and the byte that supplies the low key bits
             const uint32_t g = NBYTES == 1 ? ((w >> 8) & 0xFFu) : ((w >> 8) & 0xFFFFu);

@@ -15,14 +15,17 @@
 #include "w3_spec.h"
 
 struct TwoPhaseWs {
-    void *P = nullptr, *keys = nullptr, *perm = nullptr;
-    size_t P_cap = 0, keys_cap = 0, perm_cap = 0;
+    void *P = nullptr, *keys = nullptr, *perm = nullptr, *redo = nullptr;
+    size_t P_cap = 0, keys_cap = 0, perm_cap = 0, redo_cap = 0;
+    int coder_mode = 0;        // 0 = k_coder_fast, 2 = k_coder only
+    uint32_t acc_limit = 46;   // test hook: lower values force the fast coder's fallback
     void release() {
         if (P) (void)hipFree(P);
         if (keys) (void)hipFree(keys);
         if (perm) (void)hipFree(perm);
-        P = keys = perm = nullptr;
-        P_cap = keys_cap = perm_cap = 0;
+        if (redo) (void)hipFree(redo);
+        P = keys = perm = redo = nullptr;
+        P_cap = keys_cap = perm_cap = redo_cap = 0;
     }
 };
 
@@ -139,14 +142,37 @@ static inline int twophase_encode(TwoPhaseWs &ws, hipStream_t s, const ParsedSpe
                                   w3_timing *tm, std::string &err) {
     int rc = twophase_predict(ws, s, ps, d_in, n, block_size, nb, nullptr, ev, tm, err);
     if (rc) return rc;
+    if ((rc = tp_ensure(ws.redo, ws.redo_cap, (size_t)nb * 4, err))) return rc;
     w3::CoderArgs ca;
+    memset(&ca, 0, sizeof ca);
     ca.in = d_in; ca.n = n; ca.block_size = (uint32_t)block_size; ca.nblocks = nb; ca.P = (const uint4 *)ws.P;
-    ca.stripes = stripes; ca.stripe_cap = stripe_cap; ca.out_len = d_lens; ca.overflow = d_flag;
+    ca.stripes = stripes; ca.stripe_cap = stripe_cap; ca.out_len = d_lens; ca.flags = d_flag;
+    ca.acc_limit = std::min<uint32_t>(ws.acc_limit, 46u);
     if (ev) (void)hipEventRecord(ev[2], s);
-    hipLaunchKernelGGL(w3::k_coder, dim3((nb + 63) / 64), dim3(64), 0, s, ca);
+    if (ws.coder_mode == 2) {
+        ca.redo = nullptr;
+        hipLaunchKernelGGL(w3::k_coder, dim3((nb + 63) / 64), dim3(64), 0, s, ca);
+    } else {
+        ca.redo = (uint32_t *)ws.redo;
+        hipLaunchKernelGGL(w3::k_coder_fast, dim3((nb + 63) / 64), dim3(64), 0, s, ca);
+    }
     if (ev) (void)hipEventRecord(ev[3], s);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { err = std::string("coder launch: ") + hipGetErrorString(e); return W3_E_HIP; }
     if (tm) { tm->n_coder_launches = 1; tm->coder_bytes = (uint64_t)n * 17; }
+    return W3_OK;
+}
+
+// Blocks the fast coder gave up on (pending run longer than its accumulator): re-code with k_coder.
+static inline int twophase_recode(TwoPhaseWs &ws, hipStream_t s, const uint8_t *d_in, size_t n, size_t block_size, uint32_t nb,
+                                  uint8_t *stripes, uint32_t stripe_cap, uint32_t *d_lens, uint32_t *d_flag, uint32_t n_redo, std::string &err) {
+    w3::CoderArgs ca;
+    memset(&ca, 0, sizeof ca);
+    ca.in = d_in; ca.n = n; ca.block_size = (uint32_t)block_size; ca.nblocks = nb; ca.P = (const uint4 *)ws.P;
+    ca.stripes = stripes; ca.stripe_cap = stripe_cap; ca.out_len = d_lens; ca.flags = d_flag;
+    ca.redo = (uint32_t *)ws.redo; ca.n_redo = n_redo;
+    hipLaunchKernelGGL(w3::k_coder, dim3((n_redo + 63) / 64), dim3(64), 0, s, ca);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { err = std::string("recode launch: ") + hipGetErrorString(e); return W3_E_HIP; }
     return W3_OK;
 }

@@ -120,6 +120,14 @@ extern "C" int w3_ctx_set_option(w3_ctx *ctx, int opt, int64_t value) {
         ctx->opt_path = (int)value;
         return W3_OK;
     case W3_OPT_TIMING: ctx->opt_timing = value ? 1 : 0; return W3_OK;
+    case W3_OPT_CODER:
+        if (value != 0 && value != 2) return W3_E_INVALID;
+        ctx->tp.coder_mode = (int)value;
+        return W3_OK;
+    case W3_OPT_ACC_LIMIT:
+        if (value < 19 || value > 46) return W3_E_INVALID;
+        ctx->tp.acc_limit = (uint32_t)value;
+        return W3_OK;
     default: return W3_E_INVALID;
     }
 }
@@ -356,9 +364,18 @@ extern "C" int w3_encode_blocks_device(w3_ctx *ctx, const w3_model_spec *spec, c
             ctx->timing.path = W3_PATH_GENERIC;
         }
         if (rc) return rc;
-        uint32_t ovf = 0;
-        HIPCHK(ctx, hipMemcpyAsync(&ovf, ctx->flag.p, 4, hipMemcpyDeviceToHost, s));
+        uint32_t fl[2] = {0, 0};
+        HIPCHK(ctx, hipMemcpyAsync(fl, ctx->flag.p, 8, hipMemcpyDeviceToHost, s));
         HIPCHK(ctx, hipStreamSynchronize(s));
+        if (two && fl[1]) {  // blocks the fast coder handed back (pending-bit run longer than its accumulator)
+            ctx->timing.n_recoded_blocks = fl[1];
+            rc = twophase_recode(ctx->tp, s, d_in, n, block_size, nb, (uint8_t *)ctx->stripes.p, cap, d_block_lens,
+                                 (uint32_t *)ctx->flag.p, fl[1], ctx->err);
+            if (rc) return rc;
+            HIPCHK(ctx, hipMemcpyAsync(fl, ctx->flag.p, 8, hipMemcpyDeviceToHost, s));
+            HIPCHK(ctx, hipStreamSynchronize(s));
+        }
+        const uint32_t ovf = fl[0];
         if (!ovf) break;
         if (attempt == 1) { ctx->err = "stripe overflow at the worst-case bound (internal error)"; return W3_E_HIP; }
         cap = worst_stripe_cap(block_size);  // rare: a block expanded past 2N+64
