@@ -16,7 +16,8 @@
 //           OrderNEntropy(<=11,3,h) with keys from k_achash)
 // H == 16 : positions stably partitioned by the previous byte c1, then ranked by
 // H == 24 : the remaining 8 key bits inside each (c1[,c2]) group (Order1, OrderN(27,3)).
-//           Table entries carry the group tag, so moving to the next group is free.
+//           The table describes the one group still open at a round boundary; groups that
+//           fit inside a round never touch it.
 //
 // Counter saturation (the halve-both rule at 65535) is handled exactly: the
 // table holds the true Counter state, and a context that would saturate inside
@@ -97,36 +98,42 @@ __device__ __forceinline__ void match_keys(uint2 k8, uint64_t M[8]) {
     }
 }
 
+__device__ __forceinline__ uint32_t mbcnt64(uint64_t m) {  // bits of m below my lane
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+}
+
 // One round: 64 positions x 8 bit positions.  Returns the 8 probabilities.
 //   c0      : the byte being coded at this position (bit j = (c0 >> (7-j)) & 1)
 //   key[j]  : table index per bit position
 //   M[j]    : lanes with the same key_j (any group)
-//   seg     : lanes that are valid and in the same group as me
-//   gtag    : group tag (GROUPED) — entries with another tag read as Counter::new()
+//   seg     : lanes that are valid and in the same group as me (all valid lanes when not GROUPED)
+//   rd      : GROUPED: this lane's group is the one the table currently describes (else its Counters are new)
+// The table holds the exact Counter state of every context of the current group.
+// !GROUPED: the last lane of a context writes the state back at once.
+// GROUPED : the write-back is left to the caller (it may have to clear the table first):
+//           fin[j] = state after the round, wmask bit j = this lane is the context's last lane.
 template <bool GROUPED>
-__device__ __forceinline__ void rank_round(uint32_t c0, const uint32_t key[8], const uint64_t M[8], uint64_t seg, bool valid, uint32_t gtag,
-                                           uint32_t *tbl32, uint2 *tbl64, uint32_t p[8]) {
-    const uint64_t lt = lane_lt_mask(), gt = lane_gt_mask();
+__device__ __forceinline__ void rank_round(uint32_t c0, const uint32_t key[8], const uint64_t M[8], uint64_t seg, bool valid, bool rd,
+                                           uint32_t *tbl, uint32_t p[8], uint32_t fin[8], uint32_t &wmask) {
+    const uint64_t gt = lane_gt_mask();
     const int lane = threadIdx.x & 63;
+    wmask = 0u;
 #pragma unroll
     for (int j = 0; j < 8; j++) {
         const uint64_t Mj = M[j] & seg;
-        const uint64_t ones = __ballot((c0 >> (7 - j)) & 1u) & Mj;
-        uint32_t base;
-        if constexpr (GROUPED) {
-            const uint2 e = tbl64[j * 256 + key[j]];
-            base = e.y == gtag ? e.x : 0u;
-        } else {
-            base = tbl32[j * 256 + key[j]];
-        }
+        const uint32_t bit = (c0 >> (7 - j)) & 1u;
+        const uint64_t ones = __ballot(bit) & Mj;
+        uint32_t base = tbl[j * 256 + key[j]];
+        if constexpr (GROUPED) base = rd ? base : 0u;
         const uint32_t b0 = base & 0xFFFFu, b1 = base >> 16;
-        const uint32_t n1l = __popcll(ones & lt), n0l = __popcll(Mj & lt) - n1l;
-        const uint32_t t1 = __popcll(ones), t0 = __popcll(Mj) - t1;
-        uint32_t s0 = b0 + n0l, s1 = b1 + n1l;
-        uint32_t fin = (b0 + t0) | ((b1 + t1) << 16);
+        const uint32_t n1l = mbcnt64(ones), n0l = mbcnt64(Mj) - n1l;   // same-context lanes below me, by coded bit
+        uint32_t s0 = b0 + n0l, s1 = b1 + n1l;                          // Counter state this lane predicts from
+        const bool last = valid && (Mj & gt) == 0ull;                   // last lane of its context in this round
+        uint32_t f0 = s0 + (bit ^ 1u), f1 = s1 + bit;                   // state after my own update (meaningful on `last`)
         // Counter::update halves both counts when one reaches 65535 (counter.rs:22-25):
         // replay such a context serially (uniform scalar loop; rare)
-        uint64_t satm = __ballot(valid && ((b0 + t0 >= 65535u) || (b1 + t1 >= 65535u)));
+        uint64_t satm = __ballot(last && (f0 >= 65535u || f1 >= 65535u));
+        uint32_t f = f0 | (f1 << 16);
         while (satm) {
             const int k = __ffsll((long long)satm) - 1;
             const uint64_t Mc = readlane_u64(Mj, k);
@@ -139,15 +146,17 @@ __device__ __forceinline__ void rank_round(uint32_t c0, const uint32_t key[8], c
                 if (lane == m) { s0 = st & 0xFFFFu; s1 = st >> 16; }
                 st = counter_update_packed(st, (uint32_t)(Oc >> m) & 1u);
             }
-            if ((Mc >> lane) & 1ull) fin = st;
-            satm &= ~Mc;
+            if (lane == k) f = st;
+            satm &= satm - 1;
         }
         p[j] = counter_p(s0, s1);
-        if (valid && (Mj & gt) == 0ull) {  // last lane of this context in the round writes the state back
-            if constexpr (GROUPED) tbl64[j * 256 + key[j]] = make_uint2(fin, gtag);
-            else tbl32[j * 256 + key[j]] = fin;
+        if constexpr (GROUPED) {
+            fin[j] = f;
+            wmask |= last ? (1u << j) : 0u;
+        } else {
+            if (last) tbl[j * 256 + key[j]] = f;
+            __builtin_amdgcn_wave_barrier();
         }
-        __builtin_amdgcn_wave_barrier();
     }
 }
 
@@ -221,8 +230,8 @@ __global__ void __launch_bounds__(64) k_predict_small(PredictArgs a) {
                 match_windows<H>(w16, M);
             }
             const uint64_t seg = __ballot(valid);
-            uint32_t p[8];
-            rank_round<false>(c0, key, M, seg, valid, 0u, tbl, nullptr, p);
+            uint32_t p[8], fin[8], wm;
+            rank_round<false>(c0, key, M, seg, valid, true, tbl, p, fin, wm);
             if (valid) {
                 uint4 v = pack_p(p);
                 a.P[off + i] = a.first ? v : mix_p(cur, v);
@@ -299,7 +308,7 @@ __device__ __forceinline__ void partition_pass(const uint8_t *blk, uint32_t len,
 
 template <int NBYTES>  // 1: group = c1 (Order1); 2: group = (c1,c2) (OrderN(27,3))
 __global__ void __launch_bounds__(64) k_predict_wide(PredictArgs a) {
-    __shared__ uint2 tbl[8 * 256];
+    __shared__ uint32_t tbl[8 * 256];
     __shared__ uint32_t hist[256];
     const int lane = threadIdx.x;
     uint32_t *perm_a = a.perm + (uint64_t)blockIdx.x * 2u * a.block_size;
@@ -319,10 +328,13 @@ __global__ void __launch_bounds__(64) k_predict_wide(PredictArgs a) {
             perm = perm_b;
         }
         __threadfence_block();
+        // The table describes ONE group at a time: the group that is still open at the end of a round.
+        // Groups that start and end inside a round never touch it (their Counters start new).
 #pragma unroll
-        for (int k = 0; k < 32; k++) tbl[k * 64 + lane] = make_uint2(0u, 0u);
+        for (int k = 0; k < 32; k++) tbl[k * 64 + lane] = 0u;
         __builtin_amdgcn_wave_barrier();
-        uint32_t carry_g = 0xFFFFFFFFu;  // group of the last element of the previous round
+        bool dirty = false;              // table holds states of group open_g
+        uint32_t open_g = 0xFFFFFFFFu;   // group the table describes (also: group of the previous round's last element)
         // software pipeline: perm two rounds ahead, window bytes and the P word one round ahead
         uint32_t i_n = 0, i_nn = 0, w_n = 0; uint4 cur_n = make_uint4(0, 0, 0, 0);
         if (lane < len) { i_n = perm[lane]; }
@@ -342,7 +354,7 @@ __global__ void __launch_bounds__(64) k_predict_wide(PredictArgs a) {
             const uint32_t w16 = (ck << 8) | c0;
             // segment = lanes of my group: groups are contiguous in the sorted order
             uint32_t gprev = __shfl_up(g, 1, 64);
-            if (lane == 0) gprev = carry_g;
+            if (lane == 0) gprev = open_g;
             const uint64_t vm = __ballot(valid);
             const uint64_t heads = __ballot(valid && g != gprev) | 1ull;  // lane 0 opens a segment (same tag if the group continues)
             const uint64_t hle = heads & (lane_lt_mask() | (1ull << lane));
@@ -350,13 +362,29 @@ __global__ void __launch_bounds__(64) k_predict_wide(PredictArgs a) {
             const uint64_t hgt = heads & lane_gt_mask();
             const uint64_t below_end = hgt ? ((1ull << (__ffsll((long long)hgt) - 1)) - 1ull) : ~0ull;
             const uint64_t seg = below_end & ~((1ull << start) - 1ull) & vm;
-            carry_g = __shfl(g, 63, 64);  // only meaningful when lane 63 is valid; the last round ends the block anyway
-            uint32_t key[8], p[8];
+            uint32_t key[8], p[8], fin[8], wm;
             uint64_t M[8];
 #pragma unroll
             for (int j = 0; j < 8; j++) key[j] = (w16 >> (8 - j)) & 0xFFu;
             match_windows<8>(w16, M);
-            rank_round<true>(c0, key, M, seg, valid, g + 1u, nullptr, tbl, p);
+            rank_round<true>(c0, key, M, seg, valid, g == open_g, tbl, p, fin, wm);
+            // the group of the round's last valid element stays open into the next round: its states go to the table
+            const int lastlane = 63 - __clzll((long long)vm);
+            const uint32_t g_last = readlane_u32(g, lastlane);
+            if (g_last != open_g && dirty) {
+#pragma unroll
+                for (int k = 0; k < 32; k++) tbl[k * 64 + lane] = 0u;
+                dirty = false;
+            }
+            __builtin_amdgcn_wave_barrier();
+            if (valid && g == g_last) {
+#pragma unroll
+                for (int j = 0; j < 8; j++)
+                    if ((wm >> j) & 1u) tbl[j * 256 + key[j]] = fin[j];
+            }
+            __builtin_amdgcn_wave_barrier();
+            dirty = true;
+            open_g = g_last;
             if (valid) {
                 uint4 v = pack_p(p);
                 a.P[off + i] = a.first ? v : mix_p(cur, v);

@@ -79,7 +79,7 @@ static inline int twophase_predict(TwoPhaseWs &ws, hipStream_t s, const ParsedSp
     int rc = tp_ensure(ws.P, ws.P_cap, n * 16, err);
     if (rc) return rc;
     const uint32_t grid_small = std::min<uint32_t>(nb, 256 * 16);
-    const uint32_t grid_wide = std::min<uint32_t>(nb, 256 * 8);
+    const uint32_t grid_wide = std::min<uint32_t>(nb, 256 * 16);
     bool need_keys = false, need_perm = false;
     for (int l = 0; l < ps.n_leaves; l++) {
         int c = leaf_class(ps.leaf[l]);
