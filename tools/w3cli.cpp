@@ -1,0 +1,162 @@
+// w3cli — C++ host above the C ABI (include/w3hip.h), mirroring the reference
+// binary's CLI (src/main.rs:24-87): `w3 <c|d|t> <path>`; output goes to the
+// current directory as <name>.bin (compress/test) or <name>.orig (decompress);
+// a directory is traversed shallowly (main.rs:41-50).
+//
+// Container: by default the block container of DESIGN.md §3 ("w3bk"), which is
+// what the GPU path is for.  `W3_CONTAINER=w30i` selects the reference's own
+// single-stream container (main.rs:14-15,95-96) — one GPU lane, format parity.
+// Model: init_model() of main.rs:151 — OrderNEntropy(11,3,ACHistory(8,book1)).
+#include <sys/stat.h>
+
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <dirent.h>
+#include <string>
+#include <vector>
+
+#include "../include/w3hip.h"
+
+static const uint32_t kBlock = 65536;
+
+static w3_model_spec init_model() {
+    w3_model_spec s;
+    memset(&s, 0, sizeof s);
+    s.n_nodes = 1;
+    w3_node &n = s.nodes[0];
+    n.kind = W3_NODE_ORDERN; n.bits = 11; n.align = 3; n.history = W3_HIST_AC; n.max_bits = 8;
+    const uint16_t book1[8] = {1, 50188, 62497, 15819, 22545, 31499, 22988, 29616};  // stationary.rs:41
+    memcpy(n.table, book1, sizeof book1);
+    return s;
+}
+
+static bool read_file(const std::string &p, std::vector<uint8_t> &out) {
+    FILE *f = fopen(p.c_str(), "rb");
+    if (!f) return false;
+    fseek(f, 0, SEEK_END);
+    long n = ftell(f);
+    fseek(f, 0, SEEK_SET);
+    out.resize((size_t)n);
+    bool ok = n == 0 || fread(out.data(), 1, (size_t)n, f) == (size_t)n;
+    fclose(f);
+    return ok;
+}
+static bool write_file(const std::string &p, const uint8_t *d, size_t n) {
+    FILE *f = fopen(p.c_str(), "wb");
+    if (!f) return false;
+    bool ok = n == 0 || fwrite(d, 1, n, f) == n;
+    fclose(f);
+    return ok;
+}
+static void put_be(std::vector<uint8_t> &v, uint64_t x, int bytes) { for (int i = bytes - 1; i >= 0; i--) v.push_back((uint8_t)(x >> (8 * i))); }
+static uint64_t get_be(const uint8_t *p, int bytes) { uint64_t x = 0; for (int i = 0; i < bytes; i++) x = (x << 8) | p[i]; return x; }
+
+static std::string out_path(const std::string &in, const char *ext) {  // main.rs:58-68
+    size_t slash = in.find_last_of('/');
+    std::string name = slash == std::string::npos ? in : in.substr(slash + 1);
+    size_t dot = name.find_last_of('.');
+    if (dot != std::string::npos && dot != 0) name = name.substr(0, dot);
+    return name + "." + ext;
+}
+
+static int die(w3_ctx *ctx, int rc, const char *what) {
+    fprintf(stderr, "%s: %s (%s)\n", what, w3_strerror(rc), ctx ? w3_last_error(ctx) : "");
+    return 1;
+}
+
+static int compress(w3_ctx *ctx, const std::string &in, const std::string &out) {
+    std::vector<uint8_t> data;
+    if (!read_file(in, data)) { perror(in.c_str()); return 1; }
+    w3_model_spec spec = init_model();
+    const char *cont = getenv("W3_CONTAINER");
+    if (cont && !strcmp(cont, "w30i")) {
+        std::vector<uint8_t> buf(2 * data.size() + 128);
+        size_t len = 0;
+        int rc = w3_compress_stream(ctx, &spec, data.data(), data.size(), buf.data(), buf.size(), &len);
+        if (rc) return die(ctx, rc, "w3_compress_stream");
+        return write_file(out, buf.data(), len) ? 0 : 1;
+    }
+    size_t nb = (data.size() + kBlock - 1) / kBlock;
+    std::vector<uint8_t> body(2 * data.size() + 64 * nb + 64);
+    std::vector<uint32_t> lens(nb ? nb : 1);
+    size_t blen = 0;
+    int rc = w3_encode_blocks(ctx, &spec, data.data(), data.size(), kBlock, body.data(), body.size(), &blen, lens.data());
+    if (rc == W3_E_NOSPACE) { body.resize(blen); rc = w3_encode_blocks(ctx, &spec, data.data(), data.size(), kBlock, body.data(), body.size(), &blen, lens.data()); }
+    if (rc) return die(ctx, rc, "w3_encode_blocks");
+    std::vector<uint8_t> file = {'w', '3', 'b', 'k', 1};
+    put_be(file, data.size(), 8); put_be(file, kBlock, 4); put_be(file, nb, 4);
+    for (size_t b = 0; b < nb; b++) put_be(file, lens[b], 4);
+    file.insert(file.end(), body.begin(), body.begin() + (long)blen);
+    return write_file(out, file.data(), file.size()) ? 0 : 1;
+}
+
+static int decompress(w3_ctx *ctx, const std::string &in, const std::string &out) {
+    std::vector<uint8_t> data;
+    if (!read_file(in, data)) { perror(in.c_str()); return 1; }
+    w3_model_spec spec = init_model();
+    if (data.size() >= 4 && !memcmp(data.data(), "w30i", 4)) {
+        if (data.size() < 12) return die(ctx, W3_E_FORMAT, "header");
+        std::vector<uint8_t> o((size_t)get_be(data.data() + 4, 8) + 1);
+        size_t len = 0;
+        int rc = w3_decompress_stream(ctx, &spec, data.data(), data.size(), o.data(), o.size(), &len);
+        if (rc) return die(ctx, rc, "w3_decompress_stream");
+        return write_file(out, o.data(), len) ? 0 : 1;
+    }
+    if (data.size() < 21 || memcmp(data.data(), "w3bk", 4) || data[4] != 1) {  // main.rs:123-124 asserts the magic
+        fprintf(stderr, "Magic numbers don't match up - file wasn't compressed with (this version of) w3cli!\n");
+        return 1;
+    }
+    uint64_t orig = get_be(data.data() + 5, 8);
+    uint32_t bs = (uint32_t)get_be(data.data() + 13, 4), nb = (uint32_t)get_be(data.data() + 17, 4);
+    if (data.size() < 21 + 4ull * nb) return die(ctx, W3_E_FORMAT, "length table");
+    std::vector<uint32_t> lens(nb ? nb : 1);
+    uint64_t total = 0;
+    for (uint32_t b = 0; b < nb; b++) { lens[b] = (uint32_t)get_be(data.data() + 21 + 4ull * b, 4); total += lens[b]; }
+    if (data.size() < 21 + 4ull * nb + total) return die(ctx, W3_E_FORMAT, "streams");
+    std::vector<uint8_t> o((size_t)orig + 1);
+    int rc = w3_decode_blocks(ctx, &spec, data.data() + 21 + 4ull * nb, lens.data(), nb, bs, orig, o.data());
+    if (rc) return die(ctx, rc, "w3_decode_blocks");
+    return write_file(out, o.data(), (size_t)orig) ? 0 : 1;
+}
+
+static int run(w3_ctx *ctx, const std::string &path, char action) {  // main.rs:55-87
+    auto t0 = std::chrono::steady_clock::now();
+    int rc;
+    if (action == 'c') { rc = compress(ctx, path, out_path(path, "bin")); if (!rc) printf("Compression took: %.3fs\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count()); }
+    else if (action == 'd') { rc = decompress(ctx, path, out_path(path, "orig")); if (!rc) printf("Decompression took: %.3fs\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count()); }
+    else { rc = run(ctx, path, 'c'); if (!rc) rc = run(ctx, out_path(path, "bin"), 'd'); }
+    return rc;
+}
+
+static void usage(const char *msg) {  // main.rs:154-161
+    printf("Usage: w3 <Action> <Path>\n<Action> [single file]: c (compress), d (decompress), t (test = c + d)\n"
+           "<Path> can be a single file or a directory\nNote: Directories are shallow traversed\n\n%s\n", msg);
+    exit(1);
+}
+
+int main(int argc, char **argv) {
+    if (argc != 3) usage("Invokation doesn't match usage! Provide 2 arguments.");
+    char action = argv[1][0];
+    if (strlen(argv[1]) != 1 || (action != 'c' && action != 'd' && action != 't')) usage("Unrecognized option -> <action>!");
+    struct stat st;
+    if (stat(argv[2], &st)) { fprintf(stderr, "Path must be a file or a directory!\n"); return 1; }
+    w3_ctx *ctx = nullptr;
+    int rc = w3_ctx_create(0, &ctx);
+    if (rc) return die(nullptr, rc, "w3_ctx_create (an MI355X is required; there is no CPU path)");
+    int ret = 0;
+    if (S_ISDIR(st.st_mode)) {
+        DIR *d = opendir(argv[2]);
+        while (dirent *e = d ? readdir(d) : nullptr) {
+            std::string p = std::string(argv[2]) + "/" + e->d_name;
+            struct stat s2;
+            if (!stat(p.c_str(), &s2) && S_ISREG(s2.st_mode)) ret |= run(ctx, p, action);
+        }
+        if (d) closedir(d);
+    } else {
+        ret = run(ctx, argv[2], action);
+    }
+    w3_ctx_destroy(ctx);
+    return ret;
+}

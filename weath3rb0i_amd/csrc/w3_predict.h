@@ -23,8 +23,11 @@
 // table holds the true Counter state, and a context that would saturate inside
 // a round is replayed serially with scalar code (rare).
 //
-// Probabilities of the leaves are merged on the fly into ONE u16 stream P with
-// OpinionMixer2's rule (leftmost leaf of maximal |p-1/2|; see w3_device.h).
+// Every leaf writes its own u16 stream (time-ordered kernels coalesced; the
+// partitioned kernels scatter 16 B per position, write-only: a read-modify-write
+// of a shared stream doubled the HBM traffic of those kernels).  k_mix then merges
+// the streams into ONE stream P with OpinionMixer2's rule (leftmost leaf of
+// maximal |p-1/2|; see w3_device.h), so the coder reads 16 B per input byte.
 #pragma once
 #include "w3_device.h"
 
@@ -34,11 +37,10 @@ struct PredictArgs {
     const uint8_t *in;      // original bytes (device)
     uint64_t n;
     uint32_t block_size, nblocks;
-    uint4 *P;               // [n] 8 x u16 per input byte, block-major (same index as `in`)
+    uint4 *P;               // [n] this leaf's stream: 8 x u16 per input byte, block-major (same index as `in`)
     const uint2 *keys;      // [n] 8 x u8 precomputed keys per byte (k_achash) or null
     uint32_t *perm;         // wide: per-wave scratch, 2 * block_size u32 each
     uint32_t hbits;         // H = bits_in_context - 3
-    uint32_t first;         // 1 = this leaf initialises P, 0 = merge into P
 };
 
 __device__ __forceinline__ uint64_t lane_lt_mask() { return (1ull << (threadIdx.x & 63)) - 1ull; }
@@ -201,18 +203,16 @@ __global__ void __launch_bounds__(64) k_predict_small(PredictArgs a) {
         for (int k = 0; k < 32; k++) tbl[k * 64 + lane] = 0u;
         __builtin_amdgcn_wave_barrier();
         // operands of round r+1 are loaded while round r is ranked (the loop is issue bound otherwise)
-        uint32_t nw = 0; uint2 nk = make_uint2(0, 0); uint4 ncur = make_uint4(0, 0, 0, 0);
+        uint32_t nw = 0; uint2 nk = make_uint2(0, 0);
         if (lane < len) {
             if constexpr (KEYS) { nk = a.keys[off + lane]; nw = blk[lane]; } else nw = load_window(blk, lane);
-            if (!a.first) ncur = a.P[off + lane];
         }
         for (uint32_t base = 0; base < len; base += 64) {
             const uint32_t i = base + lane;
             const bool valid = i < len;
-            const uint32_t w = nw; const uint2 k8 = nk; const uint4 cur = ncur;
+            const uint32_t w = nw; const uint2 k8 = nk;
             if (i + 64 < len) {
                 if constexpr (KEYS) { nk = a.keys[off + i + 64]; nw = blk[i + 64]; } else nw = load_window(blk, i + 64);
-                if (!a.first) ncur = a.P[off + i + 64];
             }
             uint32_t c0 = 0, key[8];
             uint64_t M[8];
@@ -232,10 +232,7 @@ __global__ void __launch_bounds__(64) k_predict_small(PredictArgs a) {
             const uint64_t seg = __ballot(valid);
             uint32_t p[8], fin[8], wm;
             rank_round<false>(c0, key, M, seg, valid, true, tbl, p, fin, wm);
-            if (valid) {
-                uint4 v = pack_p(p);
-                a.P[off + i] = a.first ? v : mix_p(cur, v);
-            }
+            if (valid) a.P[off + i] = pack_p(p);
         }
     }
 }
@@ -336,17 +333,17 @@ __global__ void __launch_bounds__(64) k_predict_wide(PredictArgs a) {
         bool dirty = false;              // table holds states of group open_g
         uint32_t open_g = 0xFFFFFFFFu;   // group the table describes (also: group of the previous round's last element)
         // software pipeline: perm two rounds ahead, window bytes and the P word one round ahead
-        uint32_t i_n = 0, i_nn = 0, w_n = 0; uint4 cur_n = make_uint4(0, 0, 0, 0);
+        uint32_t i_n = 0, i_nn = 0, w_n = 0;
         if (lane < len) { i_n = perm[lane]; }
         if (lane + 64u < len) i_nn = perm[lane + 64u];
-        if (lane < len) { w_n = load_window(blk, i_n); if (!a.first) cur_n = a.P[off + i_n]; }
+        if (lane < len) w_n = load_window(blk, i_n);
         for (uint32_t base = 0; base < len; base += 64) {
             const uint32_t e = base + lane;
             const bool valid = e < len;
-            const uint32_t i = i_n; const uint32_t w = valid ? w_n : 0u; const uint4 cur = cur_n;
+            const uint32_t i = i_n; const uint32_t w = valid ? w_n : 0u;
             i_n = i_nn;
             if (e + 128u < len) i_nn = perm[e + 128u];
-            if (e + 64u < len) { w_n = load_window(blk, i_n); if (!a.first) cur_n = a.P[off + i_n]; }
+            if (e + 64u < len) w_n = load_window(blk, i_n);
             const uint32_t c0 = w & 0xFFu;
             // group id and the byte that supplies the low key bits
             const uint32_t g = NBYTES == 1 ? ((w >> 8) & 0xFFu) : ((w >> 8) & 0xFFFFu);
@@ -385,11 +382,26 @@ __global__ void __launch_bounds__(64) k_predict_wide(PredictArgs a) {
             __builtin_amdgcn_wave_barrier();
             dirty = true;
             open_g = g_last;
-            if (valid) {
-                uint4 v = pack_p(p);
-                a.P[off + i] = a.first ? v : mix_p(cur, v);
-            }
+            if (valid) a.P[off + i] = pack_p(p);  // 16-byte scatter, write-only
         }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// k_mix: merge the leaves' streams (in leaf order) into P.  Elementwise, coalesced.
+// ---------------------------------------------------------------------------
+struct MixArgs {
+    const uint4 *src[16];
+    int n_src;
+    uint4 *P;
+    uint64_t n;
+};
+
+__global__ void __launch_bounds__(256) k_mix(MixArgs a) {
+    for (uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; g < a.n; g += (uint64_t)gridDim.x * blockDim.x) {
+        uint4 acc = a.src[0][g];
+        for (int l = 1; l < a.n_src; l++) acc = mix_p(acc, a.src[l][g]);
+        a.P[g] = acc;
     }
 }
 

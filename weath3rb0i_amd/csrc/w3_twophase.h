@@ -15,8 +15,8 @@
 #include "w3_spec.h"
 
 struct TwoPhaseWs {
-    void *P = nullptr, *keys = nullptr, *perm = nullptr, *redo = nullptr;
-    size_t P_cap = 0, keys_cap = 0, perm_cap = 0, redo_cap = 0;
+    void *P = nullptr, *keys = nullptr, *perm = nullptr, *redo = nullptr, *streams = nullptr;
+    size_t P_cap = 0, keys_cap = 0, perm_cap = 0, redo_cap = 0, streams_cap = 0;
     int coder_mode = 0;        // 0 = k_coder_fast, 2 = k_coder only
     uint32_t acc_limit = 46;   // test hook: lower values force the fast coder's fallback
     void release() {
@@ -24,8 +24,9 @@ struct TwoPhaseWs {
         if (keys) (void)hipFree(keys);
         if (perm) (void)hipFree(perm);
         if (redo) (void)hipFree(redo);
-        P = keys = perm = redo = nullptr;
-        P_cap = keys_cap = perm_cap = redo_cap = 0;
+        if (streams) (void)hipFree(streams);
+        P = keys = perm = redo = streams = nullptr;
+        P_cap = keys_cap = perm_cap = redo_cap = streams_cap = 0;
     }
 };
 
@@ -89,26 +90,31 @@ static inline int twophase_predict(TwoPhaseWs &ws, hipStream_t s, const ParsedSp
     if (need_keys && (rc = tp_ensure(ws.keys, ws.keys_cap, n * 8, err))) return rc;
     if (need_perm && (rc = tp_ensure(ws.perm, ws.perm_cap, (size_t)grid_wide * 2 * block_size * 4, err))) return rc;
 
+    // FrozenModel leaves never adapt: p == 32768, distance 0.  They can never beat a trained leaf and tie
+    // only when every leaf says 32768, so they matter only if ALL leaves are frozen.
+    int live[W3_MAX_LEAVES], n_live = 0;
+    for (int l = 0; l < ps.n_leaves; l++)
+        if (leaf_class(ps.leaf[l]) != LEAF_FROZEN) live[n_live++] = l;
+    if (n_live > 1 && (rc = tp_ensure(ws.streams, ws.streams_cap, (size_t)n_live * n * 16, err))) return rc;
+
     if (ev) (void)hipEventRecord(ev[0], s);
-    bool first = true;
     uint64_t bytes = 0;
-    for (int l = 0; l < ps.n_leaves; l++) {
-        const w3_node &nd = ps.leaf[l];
+    if (n_live == 0) {
+        hipLaunchKernelGGL(w3::k_fill_half, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (uint4 *)ws.P, (uint64_t)n);
+        bytes += n * 16;
+    }
+    w3::MixArgs ma;
+    memset(&ma, 0, sizeof ma);
+    for (int k = 0; k < n_live; k++) {
+        const w3_node &nd = ps.leaf[live[k]];
         const int c = leaf_class(nd);
-        if (c == LEAF_FROZEN) {
-            // Counter never trained: p == 32768, distance 0 -> can only matter as the leftmost leaf
-            if (first) {
-                hipLaunchKernelGGL(w3::k_fill_half, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (uint4 *)ws.P, (uint64_t)n);
-                bytes += n * 16;
-                first = false;
-            }
-            continue;
-        }
         w3::PredictArgs pa;
         memset(&pa, 0, sizeof pa);
-        pa.in = d_in; pa.n = n; pa.block_size = (uint32_t)block_size; pa.nblocks = nb; pa.P = (uint4 *)ws.P;
-        pa.hbits = nd.bits - 3; pa.first = first ? 1u : 0u;
-        bytes += n * (first ? 17 : 33);
+        pa.in = d_in; pa.n = n; pa.block_size = (uint32_t)block_size; pa.nblocks = nb;
+        pa.P = n_live == 1 ? (uint4 *)ws.P : (uint4 *)ws.streams + (size_t)k * n;   // a single leaf writes P directly
+        ma.src[k] = pa.P;
+        pa.hbits = nd.bits - 3;
+        bytes += n * 17;
         if (c == LEAF_SMALL_AC) {
             w3::HashArgs ha;
             memset(&ha, 0, sizeof ha);
@@ -127,9 +133,15 @@ static inline int twophase_predict(TwoPhaseWs &ws, hipStream_t s, const ParsedSp
             else hipLaunchKernelGGL(w3::k_predict_wide<2>, dim3(grid_wide), dim3(64), 0, s, pa);
             bytes += n * 8 * (c == LEAF_WIDE1 ? 1 : 3);  // permutation scratch write/read
         }
-        first = false;
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) { err = std::string("predict launch: ") + hipGetErrorString(e); return W3_E_HIP; }
+    }
+    if (n_live > 1) {
+        ma.n_src = n_live; ma.P = (uint4 *)ws.P; ma.n = n;
+        hipLaunchKernelGGL(w3::k_mix, dim3(256 * 8), dim3(256), 0, s, ma);
+        bytes += n * 16 * (n_live + 1);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) { err = std::string("mix launch: ") + hipGetErrorString(e); return W3_E_HIP; }
     }
     if (ev) (void)hipEventRecord(ev[1], s);
     if (tm) tm->predict_bytes = bytes;
