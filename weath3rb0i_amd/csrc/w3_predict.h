@@ -180,10 +180,16 @@ __device__ __forceinline__ uint4 mix_p(uint4 cur, uint4 nw) {
 
 // bytes c0..c3 at position i of a block (zeros before the block start: a fresh model's history is 0)
 __device__ __forceinline__ uint32_t load_window(const uint8_t *blk, uint32_t i) {
-    uint32_t w = blk[i];
-    if (i >= 1) w |= (uint32_t)blk[i - 1] << 8;
-    if (i >= 2) w |= (uint32_t)blk[i - 2] << 16;
-    if (i >= 3) w |= (uint32_t)blk[i - 3] << 24;
+    uint32_t w;
+    if (i >= 3) {  // one unaligned dword (global memory allows it): bytes i-3..i = c3 c2 c1 c0 in memory order
+        uint32_t raw;
+        __builtin_memcpy(&raw, blk + i - 3, 4);
+        w = __builtin_bswap32(raw);
+    } else {
+        w = blk[i];
+        if (i >= 1) w |= (uint32_t)blk[i - 1] << 8;
+        if (i >= 2) w |= (uint32_t)blk[i - 2] << 16;
+    }
     return w;  // c0 | c1<<8 | c2<<16 | c3<<24
 }
 
@@ -252,76 +258,105 @@ __device__ __forceinline__ uint32_t wave_excl_scan_u32(uint32_t v, uint32_t *tot
     return inc - v;
 }
 
-// One stable counting-sort pass of the positions by the byte `back` places
-// before them.  src == nullptr means the identity order.
-__device__ __forceinline__ void partition_pass(const uint8_t *blk, uint32_t len, uint32_t back, const uint32_t *src, uint32_t *dst, uint32_t *hist) {
+// Stable LSD partition of the block's positions by the previous byte(s), 4 bits per pass.
+// 16 bins keep only 16 open output lines per wave, so the scattered position writes merge
+// into full lines in L2 (256 bins x 4096 waves overflowed the L2s: every 4-byte store became
+// its own HBM transaction).  hist[pass][16] is filled in ONE time-ordered sweep up front.
+template <int NPASS, typename PT>
+__device__ __forceinline__ void partition_hist(const uint8_t *blk, uint32_t len, uint32_t *hist) {
     const int lane = threadIdx.x & 63;
-    const uint64_t lt = lane_lt_mask(), gt = lane_gt_mask();
+    const uint64_t gt = lane_gt_mask();
+    if (lane < 16 * NPASS) hist[lane] = 0u;
+    __builtin_amdgcn_wave_barrier();
+    for (uint32_t base = 0; base < len; base += 64) {
+        const uint32_t i = base + lane;
+        const bool valid = i < len;
+        // key bytes of position i: c1 (and c2); zeros before the block start
+        uint32_t kb = 0;
+        if (valid && i >= 1) kb = blk[i - 1];
+        if (NPASS == 4 && valid && i >= 2) kb |= (uint32_t)blk[i - 2] << 8;
+        const uint64_t vm = __ballot(valid);
 #pragma unroll
-    for (int k = 0; k < 4; k++) hist[k * 64 + lane] = 0u;
-    __builtin_amdgcn_wave_barrier();
-    {   // histogram; (i, digit) of round r+1 are fetched while round r is counted
-        uint32_t i_n = 0, d_n = 0;
-        if ((uint32_t)lane < len) { i_n = src ? src[lane] : (uint32_t)lane; d_n = i_n >= back ? blk[i_n - back] : 0u; }
-        for (uint32_t base = 0; base < len; base += 64) {
-            const uint32_t e = base + lane;
-            const uint32_t d = d_n;
-            if (e + 64u < len) { i_n = src ? src[e + 64u] : e + 64u; d_n = i_n >= back ? blk[i_n - back] : 0u; }
-            if (e < len) atomicAdd(&hist[d], 1u);
-        }
-    }
-    __builtin_amdgcn_wave_barrier();
-    {   // exclusive scan of the 256 bins: lane owns bins 4*lane .. 4*lane+3
-        uint32_t v0 = hist[4 * lane], v1 = hist[4 * lane + 1], v2 = hist[4 * lane + 2], v3 = hist[4 * lane + 3], tot;
-        uint32_t ex = wave_excl_scan_u32(v0 + v1 + v2 + v3, &tot);
-        __builtin_amdgcn_wave_barrier();
-        hist[4 * lane] = ex; hist[4 * lane + 1] = ex + v0; hist[4 * lane + 2] = ex + v0 + v1; hist[4 * lane + 3] = ex + v0 + v1 + v2;
-    }
-    __builtin_amdgcn_wave_barrier();
-    {
-        uint32_t i_n = 0, d_n = 0;
-        if ((uint32_t)lane < len) { i_n = src ? src[lane] : (uint32_t)lane; d_n = i_n >= back ? blk[i_n - back] : 0u; }
-        for (uint32_t base = 0; base < len; base += 64) {
-            const uint32_t e = base + lane;
-            const bool valid = e < len;
-            const uint32_t i = i_n, d = valid ? d_n : 0u;
-            if (e + 64u < len) { i_n = src ? src[e + 64u] : e + 64u; d_n = i_n >= back ? blk[i_n - back] : 0u; }
-            uint64_t m = __ballot(valid);
+        for (int ps = 0; ps < NPASS; ps++) {
+            // pass order (LSD): c2 low, c2 high, c1 low, c1 high  /  c1 low, c1 high
+            const uint32_t d = NPASS == 4 ? ((ps < 2 ? (kb >> 8) : kb) >> (4 * (ps & 1))) & 15u : (kb >> (4 * ps)) & 15u;
+            uint64_t m = vm;
 #pragma unroll
-            for (int k = 0; k < 8; k++) {
+            for (int k = 0; k < 4; k++) {
                 const bool mybit = (d >> k) & 1u;
                 const uint64_t B = __ballot(mybit);
                 m &= mybit ? B : ~B;
             }
-            if (valid) {
-                const uint32_t bs = hist[d];
-                dst[bs + __popcll(m & lt)] = i;
-                if ((m & gt) == 0ull) hist[d] = bs + __popcll(m);
-            }
+            if (valid && (m & gt) == 0ull) hist[ps * 16 + d] += (uint32_t)__popcll(m);
             __builtin_amdgcn_wave_barrier();
         }
     }
+    // exclusive scan inside each pass's 16 bins
+    uint32_t v = lane < 16 * NPASS ? hist[lane] : 0u;
+    uint32_t inc = v;
+#pragma unroll
+    for (int dd = 1; dd < 16; dd <<= 1) {
+        uint32_t o = __shfl_up(inc, dd, 64);
+        if ((lane & 15) >= dd) inc += o;
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (lane < 16 * NPASS) hist[lane] = inc - v;
+    __builtin_amdgcn_wave_barrier();
 }
 
-template <int NBYTES>  // 1: group = c1 (Order1); 2: group = (c1,c2) (OrderN(27,3))
+template <typename PT>
+__device__ __forceinline__ void partition_pass4(const uint8_t *blk, uint32_t len, uint32_t back, uint32_t shift, const PT *src, PT *dst, uint32_t *bins) {
+    const int lane = threadIdx.x & 63;
+    const uint64_t gt = lane_gt_mask();
+    uint32_t i_n = 0, d_n = 0;
+    if ((uint32_t)lane < len) { i_n = src ? (uint32_t)src[lane] : (uint32_t)lane; d_n = i_n >= back ? blk[i_n - back] : 0u; }
+    for (uint32_t base = 0; base < len; base += 64) {
+        const uint32_t e = base + lane;
+        const bool valid = e < len;
+        const uint32_t i = i_n, d = valid ? (d_n >> shift) & 15u : 0u;
+        if (e + 64u < len) { i_n = src ? (uint32_t)src[e + 64u] : e + 64u; d_n = i_n >= back ? blk[i_n - back] : 0u; }
+        uint64_t m = __ballot(valid);
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const bool mybit = (d >> k) & 1u;
+            const uint64_t B = __ballot(mybit);
+            m &= mybit ? B : ~B;
+        }
+        if (valid) {
+            const uint32_t bs = bins[d];
+            dst[bs + mbcnt64(m)] = (PT)i;
+            if ((m & gt) == 0ull) bins[d] = bs + (uint32_t)__popcll(m);
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+template <int NBYTES, typename PT>  // NBYTES 1: group = c1 (Order1); 2: group = (c1,c2) (OrderN(27,3)).  PT: u16 when block_size <= 65536
 __global__ void __launch_bounds__(64) k_predict_wide(PredictArgs a) {
     __shared__ uint32_t tbl[8 * 256];
-    __shared__ uint32_t hist[256];
+    __shared__ uint32_t hist[64];
     const int lane = threadIdx.x;
-    uint32_t *perm_a = a.perm + (uint64_t)blockIdx.x * 2u * a.block_size;
-    uint32_t *perm_b = perm_a + a.block_size;
+    PT *perm_a = reinterpret_cast<PT *>(a.perm) + (uint64_t)blockIdx.x * 2u * a.block_size;
+    PT *perm_b = perm_a + a.block_size;
     for (uint32_t b = blockIdx.x; b < a.nblocks; b += gridDim.x) {
         const uint64_t off = (uint64_t)b * a.block_size;
         const uint32_t len = (uint32_t)((a.n - off) < a.block_size ? (a.n - off) : a.block_size);
         const uint8_t *blk = a.in + off;
-        const uint32_t *perm;
+        const PT *perm;
+        partition_hist<2 * NBYTES, PT>(blk, len, hist);
         if constexpr (NBYTES == 1) {
-            partition_pass(blk, len, 1, nullptr, perm_a, hist);
-            perm = perm_a;
-        } else {
-            partition_pass(blk, len, 2, nullptr, perm_a, hist);   // LSD: minor key c2 first
+            partition_pass4<PT>(blk, len, 1, 0, nullptr, perm_a, hist);
             __threadfence_block();
-            partition_pass(blk, len, 1, perm_a, perm_b, hist);
+            partition_pass4<PT>(blk, len, 1, 4, perm_a, perm_b, hist + 16);
+            perm = perm_b;
+        } else {
+            partition_pass4<PT>(blk, len, 2, 0, nullptr, perm_a, hist);            // LSD: minor key c2 first
+            __threadfence_block();
+            partition_pass4<PT>(blk, len, 2, 4, perm_a, perm_b, hist + 16);
+            __threadfence_block();
+            partition_pass4<PT>(blk, len, 1, 0, perm_b, perm_a, hist + 32);
+            __threadfence_block();
+            partition_pass4<PT>(blk, len, 1, 4, perm_a, perm_b, hist + 48);
             perm = perm_b;
         }
         __threadfence_block();
@@ -334,15 +369,15 @@ __global__ void __launch_bounds__(64) k_predict_wide(PredictArgs a) {
         uint32_t open_g = 0xFFFFFFFFu;   // group the table describes (also: group of the previous round's last element)
         // software pipeline: perm two rounds ahead, window bytes and the P word one round ahead
         uint32_t i_n = 0, i_nn = 0, w_n = 0;
-        if (lane < len) { i_n = perm[lane]; }
-        if (lane + 64u < len) i_nn = perm[lane + 64u];
+        if (lane < len) { i_n = (uint32_t)perm[lane]; }
+        if (lane + 64u < len) i_nn = (uint32_t)perm[lane + 64u];
         if (lane < len) w_n = load_window(blk, i_n);
         for (uint32_t base = 0; base < len; base += 64) {
             const uint32_t e = base + lane;
             const bool valid = e < len;
             const uint32_t i = i_n; const uint32_t w = valid ? w_n : 0u;
             i_n = i_nn;
-            if (e + 128u < len) i_nn = perm[e + 128u];
+            if (e + 128u < len) i_nn = (uint32_t)perm[e + 128u];
             if (e + 64u < len) w_n = load_window(blk, i_n);
             const uint32_t c0 = w & 0xFFu;
             // group id and the byte that supplies the low key bits

@@ -129,8 +129,14 @@ static inline int twophase_predict(TwoPhaseWs &ws, hipStream_t s, const ParsedSp
             launch_small<false>(nd.bits - 3, dim3(grid_small), s, pa);
         } else {
             pa.perm = (uint32_t *)ws.perm;
-            if (c == LEAF_WIDE1) hipLaunchKernelGGL(w3::k_predict_wide<1>, dim3(grid_wide), dim3(64), 0, s, pa);
-            else hipLaunchKernelGGL(w3::k_predict_wide<2>, dim3(grid_wide), dim3(64), 0, s, pa);
+            const bool small_pos = block_size <= 65536;  // positions fit u16
+            if (c == LEAF_WIDE1) {
+                if (small_pos) hipLaunchKernelGGL((w3::k_predict_wide<1, uint16_t>), dim3(grid_wide), dim3(64), 0, s, pa);
+                else hipLaunchKernelGGL((w3::k_predict_wide<1, uint32_t>), dim3(grid_wide), dim3(64), 0, s, pa);
+            } else {
+                if (small_pos) hipLaunchKernelGGL((w3::k_predict_wide<2, uint16_t>), dim3(grid_wide), dim3(64), 0, s, pa);
+                else hipLaunchKernelGGL((w3::k_predict_wide<2, uint32_t>), dim3(grid_wide), dim3(64), 0, s, pa);
+            }
             bytes += n * 8 * (c == LEAF_WIDE1 ? 1 : 3);  // permutation scratch write/read
         }
         hipError_t e = hipGetLastError();
