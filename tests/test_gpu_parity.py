@@ -149,21 +149,23 @@ def test_coder_variants_and_fallback(ctx, oracle):
     model = w3.BestOfTwoModel(w3.Order0(), w3.Order1())
     ctx.set_path("twophase")
     try:
-        for mode in ("fast", "robust"):
+        for mode in ("x2", "fast", "robust"):
             ctx.set_coder(mode)
             out, lens = ctx.encode_blocks(model, data, 8192)
             assert lens.tolist() == wlens.tolist() and out.tobytes() == want.tobytes(), mode
             assert ctx.timing()["n_recoded_blocks"] == 0
-        ctx.set_coder("fast")
-        for limit in (19, 24, 33):  # force the fast coder to give blocks back to k_coder
-            ctx.set_acc_limit(limit)
-            out, lens = ctx.encode_blocks(model, data, 8192)
-            assert lens.tolist() == wlens.tolist() and out.tobytes() == want.tobytes(), limit
-            if limit == 19:
-                assert ctx.timing()["n_recoded_blocks"] > 0
+        for mode in ("x2", "fast"):
+            ctx.set_coder(mode)
+            for limit in (19, 24, 33):  # force the fast coders to give blocks back to k_coder
+                ctx.set_acc_limit(limit)
+                out, lens = ctx.encode_blocks(model, data, 8192)
+                assert lens.tolist() == wlens.tolist() and out.tobytes() == want.tobytes(), (mode, limit)
+                if limit == 19:
+                    assert ctx.timing()["n_recoded_blocks"] > 0
+            ctx.set_acc_limit(46)
     finally:
         ctx.set_acc_limit(46)
-        ctx.set_coder("fast")
+        ctx.set_coder("x2")
         ctx.set_path("auto")
 
 

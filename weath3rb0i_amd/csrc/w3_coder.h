@@ -181,4 +181,169 @@ __global__ void __launch_bounds__(64) k_coder_fast(CoderArgs a) {
     }
 }
 
+// ---------------------------------------------------------------------------
+// k_coder_x2 — the serial chain split over TWO wavefronts per 64 blocks.
+//
+// A lone wave issues a dependent VALU instruction only every ~6.6 cycles (4 if
+// independent), and at enwik9 size three quarters of the SIMDs are idle while
+// the coder runs.  So the step is cut along its dependency structure:
+//   X-wave: the (x1, x2) recurrence only — lerp, range update, the two clz, the
+//           combined shift.  It publishes one token per step, (x1 after the
+//           update, c = s + 1), into an LDS ring and never waits for memory
+//           stores or output bookkeeping.
+//   O-wave: everything derived from the tokens — slot/carry accumulator, guard,
+//           32-bit flushes to the stripe, final ACWriter::flush.  None of it
+//           feeds back into the recurrence.
+// The two waves of a workgroup sit on different SIMDs of one CU and hand
+// tokens over through a 64 KiB LDS ring (16 input bytes deep, produced and
+// consumed 8 bytes at a time).  LDS executes one wave's instructions in order,
+// so "tokens, then the counter" needs no wait on the producer side.
+// ---------------------------------------------------------------------------
+#define W3_X2_RING 16u          // ring depth in input bytes (power of two, two halves of 8)
+#define W3_X2_SPIN_LIMIT (1u << 24)
+
+__device__ __forceinline__ uint32_t lds_load_u32(const volatile uint32_t *p) {
+    return __hip_atomic_load(const_cast<const uint32_t *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ void lds_store_u32(volatile uint32_t *p, uint32_t v) {
+    __hip_atomic_store(const_cast<uint32_t *>(p), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+__global__ void __launch_bounds__(128) k_coder_x2(CoderArgs a) {
+    __shared__ uint2 tok[W3_X2_RING * 8u * 64u];   // [ring byte][bit][lane]
+    __shared__ uint32_t fin_x2[64];
+    __shared__ uint32_t sync_w[4];                  // [0] bytes produced, [1] bytes consumed, [2] abort
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    const uint32_t b = blockIdx.x * 64u + lane;
+    const bool act = b < a.nblocks;
+    const uint64_t off = (uint64_t)(act ? b : 0u) * a.block_size;
+    const uint32_t len = act ? (uint32_t)((a.n - off) < a.block_size ? (a.n - off) : a.block_size) : 0u;
+    uint32_t maxlen = len;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) maxlen = max(maxlen, (uint32_t)__shfl_xor((int)maxlen, d, 64));
+    maxlen = __builtin_amdgcn_readfirstlane(maxlen);
+    if (threadIdx.x < 4) sync_w[threadIdx.x] = 0u;
+    __syncthreads();
+    volatile uint32_t *prod = &sync_w[0], *cons = &sync_w[1], *abortf = &sync_w[2];
+
+    if (wave == 0) {
+        // ------------------------------ X-wave ------------------------------
+        const uint4 *Pb = a.P + off;
+        const uint8_t *blk = a.in + off;
+        uint32_t x1 = 0u, x2 = 0xFFFFFFFFu;
+        uint4 nx[4]; uint32_t nbytes[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) { nx[k] = make_uint4(0x80008000u, 0x80008000u, 0x80008000u, 0x80008000u); nbytes[k] = 0; }
+#pragma unroll
+        for (int k = 0; k < 4; k++) if ((uint32_t)k < len) { nx[k] = Pb[k]; nbytes[k] = blk[k]; }
+        bool dead = false;
+        for (uint32_t i = 0; i < maxlen && !dead; i += 4) {
+            if ((i & 7u) == 0u && i >= W3_X2_RING) {   // ring slots of bytes [i, i+8) must have been consumed
+                uint32_t spins = 0;
+                while (lds_load_u32(cons) + 8u < i) {
+                    __builtin_amdgcn_s_sleep(1);
+                    if (++spins > W3_X2_SPIN_LIMIT || lds_load_u32(abortf)) { lds_store_u32(abortf, 1u); dead = true; break; }
+                }
+                if (dead) break;
+            }
+            uint4 cur[4]; uint32_t cb[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) { cur[k] = nx[k]; cb[k] = nbytes[k]; }
+#pragma unroll
+            for (int k = 0; k < 4; k++) if (i + 4u + k < len) { nx[k] = Pb[i + 4u + k]; nbytes[k] = blk[i + 4u + k]; }
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                if (i + k < len) {
+                    uint2 *slot = tok + ((size_t)((i + k) & (W3_X2_RING - 1u)) * 8u) * 64u + lane;
+#pragma unroll
+                    for (int j = 0; j < 8; j++) {
+                        const uint32_t w = j < 2 ? cur[k].x : j < 4 ? cur[k].y : j < 6 ? cur[k].z : cur[k].w;
+                        const uint32_t p32 = (j & 1) ? (w & 0xFFFF0000u) : (w << 16);
+                        const uint32_t bitmask = (uint32_t)__builtin_amdgcn_sbfe((int)cb[k], 7 - j, 1);
+                        const uint32_t xmid = x1 + __umulhi(x2 - x1, p32);
+                        x1 = (x1 & bitmask) | ((xmid + 1u) & ~bitmask);
+                        x2 = (xmid & bitmask) | (x2 & ~bitmask);
+                        const uint32_t n = (uint32_t)__builtin_clz(x1 ^ x2);
+                        const uint32_t u = ~(x1 & ~x2) & (0x7FFFFFFFu >> n);
+                        const uint32_t c = (uint32_t)__builtin_clz(u);
+                        slot[j * 64] = make_uint2(x1, c);
+                        x1 = (x1 << c) >> 1;
+                        x2 = ~((~x2 << c) >> 1);
+                    }
+                    if (i + k + 1u == len) fin_x2[lane] = x2;
+                }
+            }
+            __asm__ volatile("" ::: "memory");
+            lds_store_u32(prod, min(i + 4u, maxlen));   // after the tokens: LDS runs one wave's ops in order
+        }
+        return;
+    }
+
+    // -------------------------------- O-wave --------------------------------
+    uint8_t *out = a.stripes + (uint64_t)(act ? b : 0u) * a.stripe_cap;
+    const uint32_t cap = act ? a.stripe_cap : 0u, limit = a.acc_limit;
+    uint64_t acc = 0ull; uint32_t nb = 1u, pos = 0u;
+    bool failed = false, dead = false;
+    for (uint32_t i = 0; i < maxlen && !dead; i += 8) {
+        const uint32_t need = min(i + 8u, maxlen);
+        uint32_t spins = 0;
+        while (lds_load_u32(prod) < need) {
+            __builtin_amdgcn_s_sleep(1);
+            if (++spins > W3_X2_SPIN_LIMIT || lds_load_u32(abortf)) { lds_store_u32(abortf, 1u); dead = true; break; }
+        }
+        if (dead) break;
+        __asm__ volatile("" ::: "memory");
+#pragma unroll 1
+        for (uint32_t k = 0; k < 8u; k++) {
+            if (i + k < len) {
+                const uint2 *slot = tok + ((size_t)((i + k) & (W3_X2_RING - 1u)) * 8u) * 64u + lane;
+                uint2 t[8];
+#pragma unroll
+                for (int j = 0; j < 8; j++) t[j] = slot[j * 64];
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    if (__builtin_expect(nb > limit, 0)) {
+                        const uint32_t pend = trailing_ones64(acc) + 1u;
+#pragma unroll 1
+                        while (nb >= pend + 8u) {
+                            const uint8_t v = (uint8_t)(acc >> (nb - 8u));
+                            if (pos < cap) out[pos] = v;
+                            pos += 1u; nb -= 8u;
+                        }
+                        if (nb > limit) { failed = true; acc = 0ull; nb = 1u; }
+                    }
+                    const uint32_t x1v = t[j].x, c = t[j].y, s = c - 1u;
+                    acc += x1v >> 31;
+                    acc = (acc << s) | __builtin_amdgcn_ubfe(x1v, 32u - c, s);
+                    nb += s;
+                }
+                const uint32_t lo = (uint32_t)acc;
+                const uint32_t pend = (~lo ? (uint32_t)__builtin_ctz(~lo) : 32u) + 1u;
+                if (nb >= pend + 32u) {
+                    const uint32_t wv = (uint32_t)(acc >> (nb - 32u));
+                    if (pos + 4u <= cap) { const uint32_t be = __builtin_bswap32(wv); __builtin_memcpy(out + pos, &be, 4); }
+                    pos += 4u; nb -= 32u;
+                }
+            }
+        }
+        __asm__ volatile("" ::: "memory");
+        lds_store_u32(cons, need);
+    }
+    if (dead) { if (lane == 0) atomicOr(&a.flags[0], 2u); return; }
+    if (!act) return;
+    // ACWriter::flush(x2) (io.rs:91-100)
+    const uint32_t x2f = fin_x2[lane];
+    acc += 1ull;
+    const uint32_t idx = nb & 7u;
+    if (idx) { const uint32_t k = 8u - idx; acc = (acc << k) | ((x2f << 1) >> (32u - k)); nb += k; }
+#pragma unroll 1
+    while (nb >= 8u) {
+        const uint8_t v = (uint8_t)(acc >> (nb - 8u));
+        if (pos < cap) out[pos] = v;
+        pos += 1u; nb -= 8u;
+    }
+    if (failed) { const uint32_t k = atomicAdd(&a.flags[1], 1u); a.redo[k] = b; }
+    else { a.out_len[b] = pos; if (pos > cap) atomicOr(&a.flags[0], 1u); }
+}
+
 }  // namespace w3

@@ -262,7 +262,7 @@ __device__ __forceinline__ uint32_t wave_excl_scan_u32(uint32_t v, uint32_t *tot
 // 16 bins keep only 16 open output lines per wave, so the scattered position writes merge
 // into full lines in L2 (256 bins x 4096 waves overflowed the L2s: every 4-byte store became
 // its own HBM transaction).  hist[pass][16] is filled in ONE time-ordered sweep up front.
-template <int NPASS, typename PT>
+template <int NPASS>
 __device__ __forceinline__ void partition_hist(const uint8_t *blk, uint32_t len, uint32_t *hist) {
     const int lane = threadIdx.x & 63;
     const uint64_t gt = lane_gt_mask();
@@ -304,17 +304,20 @@ __device__ __forceinline__ void partition_hist(const uint8_t *blk, uint32_t len,
     __builtin_amdgcn_wave_barrier();
 }
 
-template <typename PT>
-__device__ __forceinline__ void partition_pass4(const uint8_t *blk, uint32_t len, uint32_t back, uint32_t shift, const PT *src, PT *dst, uint32_t *bins) {
+// One stable 16-way pass.  Elements travel as RECORDS (position, window bytes c0..c3), so
+// no pass ever gathers from the input block again: with 4096 waves in flight the blocks do
+// not stay in L2 and every gathered byte cost a 64-byte fetch (212 GB of FETCH per GB input).
+__device__ __forceinline__ void partition_pass4(const uint8_t *blk, uint32_t len, uint32_t back, uint32_t shift, const uint2 *src, uint2 *dst, uint32_t *bins) {
     const int lane = threadIdx.x & 63;
     const uint64_t gt = lane_gt_mask();
-    uint32_t i_n = 0, d_n = 0;
-    if ((uint32_t)lane < len) { i_n = src ? (uint32_t)src[lane] : (uint32_t)lane; d_n = i_n >= back ? blk[i_n - back] : 0u; }
+    uint2 r_n = make_uint2(0u, 0u);
+    if ((uint32_t)lane < len) r_n = src ? src[lane] : make_uint2((uint32_t)lane, load_window(blk, (uint32_t)lane));
     for (uint32_t base = 0; base < len; base += 64) {
         const uint32_t e = base + lane;
         const bool valid = e < len;
-        const uint32_t i = i_n, d = valid ? (d_n >> shift) & 15u : 0u;
-        if (e + 64u < len) { i_n = src ? (uint32_t)src[e + 64u] : e + 64u; d_n = i_n >= back ? blk[i_n - back] : 0u; }
+        const uint2 r = r_n;
+        if (e + 64u < len) r_n = src ? src[e + 64u] : make_uint2(e + 64u, load_window(blk, e + 64u));
+        const uint32_t d = valid ? (r.y >> (8u * back + shift)) & 15u : 0u;
         uint64_t m = __ballot(valid);
 #pragma unroll
         for (int k = 0; k < 4; k++) {
@@ -324,39 +327,39 @@ __device__ __forceinline__ void partition_pass4(const uint8_t *blk, uint32_t len
         }
         if (valid) {
             const uint32_t bs = bins[d];
-            dst[bs + mbcnt64(m)] = (PT)i;
+            dst[bs + mbcnt64(m)] = r;
             if ((m & gt) == 0ull) bins[d] = bs + (uint32_t)__popcll(m);
         }
         __builtin_amdgcn_wave_barrier();
     }
 }
 
-template <int NBYTES, typename PT>  // NBYTES 1: group = c1 (Order1); 2: group = (c1,c2) (OrderN(27,3)).  PT: u16 when block_size <= 65536
+template <int NBYTES>  // 1: group = c1 (Order1); 2: group = (c1,c2) (OrderN(27,3))
 __global__ void __launch_bounds__(64) k_predict_wide(PredictArgs a) {
     __shared__ uint32_t tbl[8 * 256];
     __shared__ uint32_t hist[64];
     const int lane = threadIdx.x;
-    PT *perm_a = reinterpret_cast<PT *>(a.perm) + (uint64_t)blockIdx.x * 2u * a.block_size;
-    PT *perm_b = perm_a + a.block_size;
+    uint2 *perm_a = reinterpret_cast<uint2 *>(a.perm) + (uint64_t)blockIdx.x * 2u * a.block_size;
+    uint2 *perm_b = perm_a + a.block_size;
     for (uint32_t b = blockIdx.x; b < a.nblocks; b += gridDim.x) {
         const uint64_t off = (uint64_t)b * a.block_size;
         const uint32_t len = (uint32_t)((a.n - off) < a.block_size ? (a.n - off) : a.block_size);
         const uint8_t *blk = a.in + off;
-        const PT *perm;
-        partition_hist<2 * NBYTES, PT>(blk, len, hist);
+        const uint2 *perm;
+        partition_hist<2 * NBYTES>(blk, len, hist);
         if constexpr (NBYTES == 1) {
-            partition_pass4<PT>(blk, len, 1, 0, nullptr, perm_a, hist);
+            partition_pass4(blk, len, 1, 0, nullptr, perm_a, hist);
             __threadfence_block();
-            partition_pass4<PT>(blk, len, 1, 4, perm_a, perm_b, hist + 16);
+            partition_pass4(blk, len, 1, 4, perm_a, perm_b, hist + 16);
             perm = perm_b;
         } else {
-            partition_pass4<PT>(blk, len, 2, 0, nullptr, perm_a, hist);            // LSD: minor key c2 first
+            partition_pass4(blk, len, 2, 0, nullptr, perm_a, hist);            // LSD: minor key c2 first
             __threadfence_block();
-            partition_pass4<PT>(blk, len, 2, 4, perm_a, perm_b, hist + 16);
+            partition_pass4(blk, len, 2, 4, perm_a, perm_b, hist + 16);
             __threadfence_block();
-            partition_pass4<PT>(blk, len, 1, 0, perm_b, perm_a, hist + 32);
+            partition_pass4(blk, len, 1, 0, perm_b, perm_a, hist + 32);
             __threadfence_block();
-            partition_pass4<PT>(blk, len, 1, 4, perm_a, perm_b, hist + 48);
+            partition_pass4(blk, len, 1, 4, perm_a, perm_b, hist + 48);
             perm = perm_b;
         }
         __threadfence_block();
@@ -367,18 +370,14 @@ __global__ void __launch_bounds__(64) k_predict_wide(PredictArgs a) {
         __builtin_amdgcn_wave_barrier();
         bool dirty = false;              // table holds states of group open_g
         uint32_t open_g = 0xFFFFFFFFu;   // group the table describes (also: group of the previous round's last element)
-        // software pipeline: perm two rounds ahead, window bytes and the P word one round ahead
-        uint32_t i_n = 0, i_nn = 0, w_n = 0;
-        if (lane < len) { i_n = (uint32_t)perm[lane]; }
-        if (lane + 64u < len) i_nn = (uint32_t)perm[lane + 64u];
-        if (lane < len) w_n = load_window(blk, i_n);
+        // software pipeline: the record of round r+1 is loaded while round r is ranked
+        uint2 r_n = make_uint2(0u, 0u);
+        if ((uint32_t)lane < len) r_n = perm[lane];
         for (uint32_t base = 0; base < len; base += 64) {
             const uint32_t e = base + lane;
             const bool valid = e < len;
-            const uint32_t i = i_n; const uint32_t w = valid ? w_n : 0u;
-            i_n = i_nn;
-            if (e + 128u < len) i_nn = (uint32_t)perm[e + 128u];
-            if (e + 64u < len) w_n = load_window(blk, i_n);
+            const uint32_t i = r_n.x; const uint32_t w = valid ? r_n.y : 0u;
+            if (e + 64u < len) r_n = perm[e + 64u];
             const uint32_t c0 = w & 0xFFu;
             // group id and the byte that supplies the low key bits
             const uint32_t g = NBYTES == 1 ? ((w >> 8) & 0xFFu) : ((w >> 8) & 0xFFFFu);

@@ -17,7 +17,7 @@
 struct TwoPhaseWs {
     void *P = nullptr, *keys = nullptr, *perm = nullptr, *redo = nullptr, *streams = nullptr;
     size_t P_cap = 0, keys_cap = 0, perm_cap = 0, redo_cap = 0, streams_cap = 0;
-    int coder_mode = 0;        // 0 = k_coder_fast, 2 = k_coder only
+    int coder_mode = 0;        // 0 = k_coder_x2 (two waves per 64 blocks), 1 = k_coder_fast, 2 = k_coder only
     uint32_t acc_limit = 46;   // test hook: lower values force the fast coder's fallback
     void release() {
         if (P) (void)hipFree(P);
@@ -79,7 +79,7 @@ static inline int twophase_predict(TwoPhaseWs &ws, hipStream_t s, const ParsedSp
                                    uint32_t nb, const uint16_t **d_P, hipEvent_t *ev, w3_timing *tm, std::string &err) {
     int rc = tp_ensure(ws.P, ws.P_cap, n * 16, err);
     if (rc) return rc;
-    const uint32_t grid_small = std::min<uint32_t>(nb, 256 * 16);
+    const uint32_t grid_small = std::min<uint32_t>(nb, 256 * 20);
     const uint32_t grid_wide = std::min<uint32_t>(nb, 256 * 16);
     bool need_keys = false, need_perm = false;
     for (int l = 0; l < ps.n_leaves; l++) {
@@ -88,7 +88,7 @@ static inline int twophase_predict(TwoPhaseWs &ws, hipStream_t s, const ParsedSp
         need_perm |= c == LEAF_WIDE1 || c == LEAF_WIDE2;
     }
     if (need_keys && (rc = tp_ensure(ws.keys, ws.keys_cap, n * 8, err))) return rc;
-    if (need_perm && (rc = tp_ensure(ws.perm, ws.perm_cap, (size_t)grid_wide * 2 * block_size * 4, err))) return rc;
+    if (need_perm && (rc = tp_ensure(ws.perm, ws.perm_cap, (size_t)grid_wide * 2 * block_size * 8, err))) return rc;
 
     // FrozenModel leaves never adapt: p == 32768, distance 0.  They can never beat a trained leaf and tie
     // only when every leaf says 32768, so they matter only if ALL leaves are frozen.
@@ -129,15 +129,9 @@ static inline int twophase_predict(TwoPhaseWs &ws, hipStream_t s, const ParsedSp
             launch_small<false>(nd.bits - 3, dim3(grid_small), s, pa);
         } else {
             pa.perm = (uint32_t *)ws.perm;
-            const bool small_pos = block_size <= 65536;  // positions fit u16
-            if (c == LEAF_WIDE1) {
-                if (small_pos) hipLaunchKernelGGL((w3::k_predict_wide<1, uint16_t>), dim3(grid_wide), dim3(64), 0, s, pa);
-                else hipLaunchKernelGGL((w3::k_predict_wide<1, uint32_t>), dim3(grid_wide), dim3(64), 0, s, pa);
-            } else {
-                if (small_pos) hipLaunchKernelGGL((w3::k_predict_wide<2, uint16_t>), dim3(grid_wide), dim3(64), 0, s, pa);
-                else hipLaunchKernelGGL((w3::k_predict_wide<2, uint32_t>), dim3(grid_wide), dim3(64), 0, s, pa);
-            }
-            bytes += n * 8 * (c == LEAF_WIDE1 ? 1 : 3);  // permutation scratch write/read
+            if (c == LEAF_WIDE1) hipLaunchKernelGGL(w3::k_predict_wide<1>, dim3(grid_wide), dim3(64), 0, s, pa);
+            else hipLaunchKernelGGL(w3::k_predict_wide<2>, dim3(grid_wide), dim3(64), 0, s, pa);
+            bytes += n * 16 * (c == LEAF_WIDE1 ? 2 : 4);  // record passes: 8 B written + 8 B read each
         }
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) { err = std::string("predict launch: ") + hipGetErrorString(e); return W3_E_HIP; }
@@ -172,7 +166,8 @@ static inline int twophase_encode(TwoPhaseWs &ws, hipStream_t s, const ParsedSpe
         hipLaunchKernelGGL(w3::k_coder, dim3((nb + 63) / 64), dim3(64), 0, s, ca);
     } else {
         ca.redo = (uint32_t *)ws.redo;
-        hipLaunchKernelGGL(w3::k_coder_fast, dim3((nb + 63) / 64), dim3(64), 0, s, ca);
+        if (ws.coder_mode == 1) hipLaunchKernelGGL(w3::k_coder_fast, dim3((nb + 63) / 64), dim3(64), 0, s, ca);
+        else hipLaunchKernelGGL(w3::k_coder_x2, dim3((nb + 63) / 64), dim3(128), 0, s, ca);
     }
     if (ev) (void)hipEventRecord(ev[3], s);
     hipError_t e = hipGetLastError();

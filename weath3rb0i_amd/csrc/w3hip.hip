@@ -121,7 +121,7 @@ extern "C" int w3_ctx_set_option(w3_ctx *ctx, int opt, int64_t value) {
         return W3_OK;
     case W3_OPT_TIMING: ctx->opt_timing = value ? 1 : 0; return W3_OK;
     case W3_OPT_CODER:
-        if (value != 0 && value != 2) return W3_E_INVALID;
+        if (value < 0 || value > 2) return W3_E_INVALID;
         ctx->tp.coder_mode = (int)value;
         return W3_OK;
     case W3_OPT_ACC_LIMIT:
@@ -375,7 +375,8 @@ extern "C" int w3_encode_blocks_device(w3_ctx *ctx, const w3_model_spec *spec, c
             HIPCHK(ctx, hipMemcpyAsync(fl, ctx->flag.p, 8, hipMemcpyDeviceToHost, s));
             HIPCHK(ctx, hipStreamSynchronize(s));
         }
-        const uint32_t ovf = fl[0];
+        if (fl[0] & 2u) { ctx->err = "coder pipeline timeout (internal error)"; return W3_E_HIP; }
+        const uint32_t ovf = fl[0] & 1u;
         if (!ovf) break;
         if (attempt == 1) { ctx->err = "stripe overflow at the worst-case bound (internal error)"; return W3_E_HIP; }
         cap = worst_stripe_cap(block_size);  // rare: a block expanded past 2N+64
