@@ -77,6 +77,7 @@ def main():
     ap.add_argument("--path", default="auto", help="auto | generic | twophase")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--force-exchange", action="store_true", help="run the RCCL exchange step even with 1 rank (rehearsal)")
     args = ap.parse_args()
 
     import numpy as np
@@ -91,8 +92,10 @@ def main():
             raise SystemExit("--gpus %d needs `python -m torch.distributed.run --nproc-per-node %d bench.py ...`" % (args.gpus, args.gpus))
         raise SystemExit("WORLD_SIZE=%d does not match --gpus %d" % (world, args.gpus))
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    exchange = world > 1 or args.force_exchange
+    if exchange:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29517")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     import weath3rb0i_amd as w3
@@ -114,33 +117,19 @@ def main():
     d_total = torch.zeros(1, dtype=torch.int64, device="cuda")
     stream = torch.cuda.current_stream().cuda_stream
 
-    gather_buf = None
-    totals = torch.zeros(world, dtype=torch.int64, device="cuda")
+    from weath3rb0i_amd import shard
+    gather_buf = torch.empty(int(world * n * 0.75) + 4096, dtype=torch.uint8, device="cuda") if (exchange and rank == 0) else None
+    gathered = {}
 
     def step():
         ctx.encode_blocks_device(model, d_in, bs, d_out, d_lens, d_total, stream=stream)
-        if world > 1:
-            # exchange step: sizes all-gather, then variable-length gather of the packed streams to rank 0
-            dist.all_gather_into_tensor(totals, d_total)
-            t = totals.tolist()
-            nonlocal gather_buf
-            if rank == 0:
-                need = sum(t)
-                if gather_buf is None or gather_buf.numel() < need:
-                    gather_buf = torch.empty(int(need * 1.05) + 1024, dtype=torch.uint8, device="cuda")
-                ops, off = [], t[0]
-                gather_buf[: t[0]].copy_(d_out[: t[0]])
-                for r in range(1, world):
-                    ops.append(dist.P2POp(dist.irecv, gather_buf[off: off + t[r]], r))
-                    off += t[r]
-                for req in dist.batch_isend_irecv(ops):
-                    req.wait()
-            else:
-                for req in dist.batch_isend_irecv([dist.P2POp(dist.isend, d_out[: t[rank]], 0)]):
-                    req.wait()
+        if exchange:
+            # the one exchange step: sizes all-gather + grouped send/recv of the packed streams to rank 0 (RCCL)
+            allb, alll, totals = shard.gather_streams(d_out, int(d_total.item()), d_lens, dst=0, out=gather_buf)
+            gathered["bytes"] = sum(totals)
 
     def sync():
-        if world > 1:
+        if exchange:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -210,7 +199,7 @@ def main():
             cb["bit_exact_vs_gpu"] = bool(np.array_equal(g_lens, clens) and np.array_equal(g_out, cout))
             res["cpu_baseline"] = cb
         print(json.dumps(res), flush=True)
-    if world > 1:
+    if exchange:
         dist.barrier()
         dist.destroy_process_group()
     ctx.close()

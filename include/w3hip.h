@@ -90,7 +90,8 @@ enum {
     W3_OPT_PATH   = 1,  /* W3_PATH_*: which device implementation encode uses      */
     W3_OPT_TIMING = 2,  /* 1 = record per-kernel hipEvent timings (w3_get_timing) */
     W3_OPT_CODER  = 3,  /* two-phase coder kernel: 0 = k_coder_x2, 1 = k_coder_fast, 2 = robust k_coder only */
-    W3_OPT_ACC_LIMIT = 4 /* test hook (19..46): accumulator fill at which the fast coder hands a block back */
+    W3_OPT_ACC_LIMIT = 4, /* test hook (19..46): accumulator fill at which the fast coder hands a block back */
+    W3_OPT_DEBUG_STAMPS = 5 /* diagnostic: 1 = the partitioned predict kernel sums s_memtime per phase */
 };
 enum { W3_PATH_AUTO = 0, W3_PATH_GENERIC = 1, W3_PATH_TWOPHASE = 2 };
 int         w3_ctx_set_option(w3_ctx *ctx, int opt, int64_t value);
@@ -150,6 +151,10 @@ int w3_stationary_table(const uint8_t *buf, size_t n, uint16_t table[8]);
  * Exhaustively compares the kernels' division-free Counter::p with the literal
  * u64 formula (models/counter.rs:13-18) for all 2^32 (c0,c1) states, on the GPU. */
 int w3_selftest_counter_p(w3_ctx *ctx, uint64_t *mismatches);
+
+/* Diagnostic: per-phase s_memtime sums of the last partitioned predict kernel (W3_OPT_DEBUG_STAMPS=1):
+ * [0] digit histograms, [1] first partition pass, [2] remaining passes, [3] rank loop, [7] blocks.       */
+int w3_debug_get_stamps(w3_ctx *ctx, uint64_t out[8]);
 
 /* ---- timing of the last encode call (W3_OPT_TIMING=1) ----------------------- */
 typedef struct w3_timing {

@@ -116,12 +116,18 @@ __global__ void __launch_bounds__(64) k_coder_fast(CoderArgs a) {
     e.x1 = 0u; e.x2 = 0xFFFFFFFFu; e.acc = 0ull; e.nb = 1u; e.pos = 0u;   // one slot: the first output bit
     bool failed = false;
 
-    uint4 pv = Pb[0];
-    uint32_t byte = blk[0];
+    // operands are fetched 4 bytes ahead with UNCONDITIONAL loads (index clamped): hipcc waits vmcnt(0)
+    // right after a load it has to branch around, which would expose one HBM latency per input byte
+    const uint32_t last = len - 1u;
+    uint4 pq[4]; uint32_t bq[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) { const uint32_t ic = min((uint32_t)k, last); pq[k] = Pb[ic]; bq[k] = blk[ic]; }
     for (uint32_t i = 0; i < len; i++) {
-        const uint4 cur = pv;
-        const uint32_t cb = byte;
-        if (i + 1 < len) { pv = Pb[i + 1]; byte = blk[i + 1]; }   // prefetch the next step's operands
+        const uint4 cur = pq[0];
+        const uint32_t cb = bq[0];
+#pragma unroll
+        for (int k = 0; k < 3; k++) { pq[k] = pq[k + 1]; bq[k] = bq[k + 1]; }
+        { const uint32_t ic = min(i + 4u, last); pq[3] = Pb[ic]; bq[3] = blk[ic]; }
 #pragma unroll
         for (int j = 0; j < 8; j++) {
             if (__builtin_expect(e.nb > limit, 0)) {
@@ -231,11 +237,11 @@ __global__ void __launch_bounds__(128) k_coder_x2(CoderArgs a) {
         const uint4 *Pb = a.P + off;
         const uint8_t *blk = a.in + off;
         uint32_t x1 = 0u, x2 = 0xFFFFFFFFu;
+        // operands one 4-byte group ahead, with UNCONDITIONAL loads (index clamped): see k_coder_fast
+        const uint32_t last = (act && len) ? len - 1u : 0u;
         uint4 nx[4]; uint32_t nbytes[4];
 #pragma unroll
-        for (int k = 0; k < 4; k++) { nx[k] = make_uint4(0x80008000u, 0x80008000u, 0x80008000u, 0x80008000u); nbytes[k] = 0; }
-#pragma unroll
-        for (int k = 0; k < 4; k++) if ((uint32_t)k < len) { nx[k] = Pb[k]; nbytes[k] = blk[k]; }
+        for (int k = 0; k < 4; k++) { const uint32_t ic = min((uint32_t)k, last); nx[k] = Pb[ic]; nbytes[k] = blk[ic]; }
         bool dead = false;
         for (uint32_t i = 0; i < maxlen && !dead; i += 4) {
             if ((i & 7u) == 0u && i >= W3_X2_RING) {   // ring slots of bytes [i, i+8) must have been consumed
@@ -250,7 +256,7 @@ __global__ void __launch_bounds__(128) k_coder_x2(CoderArgs a) {
 #pragma unroll
             for (int k = 0; k < 4; k++) { cur[k] = nx[k]; cb[k] = nbytes[k]; }
 #pragma unroll
-            for (int k = 0; k < 4; k++) if (i + 4u + k < len) { nx[k] = Pb[i + 4u + k]; nbytes[k] = blk[i + 4u + k]; }
+            for (int k = 0; k < 4; k++) { const uint32_t ic = min(i + 4u + k, last); nx[k] = Pb[ic]; nbytes[k] = blk[ic]; }
 #pragma unroll
             for (int k = 0; k < 4; k++) {
                 if (i + k < len) {

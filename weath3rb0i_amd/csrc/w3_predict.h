@@ -41,7 +41,17 @@ struct PredictArgs {
     const uint2 *keys;      // [n] 8 x u8 precomputed keys per byte (k_achash) or null
     uint32_t *perm;         // wide: per-wave scratch, 2 * block_size u32 each
     uint32_t hbits;         // H = bits_in_context - 3
+    unsigned long long *dbg; // optional: per-phase s_memtime sums (diagnostic builds/runs only; never read by kernels)
 };
+
+#define W3_STAMP(slot)                                                                         \
+    do {                                                                                       \
+        if (a.dbg) {                                                                           \
+            const unsigned long long t_ = __builtin_amdgcn_s_memtime();                        \
+            if ((threadIdx.x & 63) == 0) atomicAdd(&a.dbg[slot], t_ - t_prev);                 \
+            t_prev = t_;                                                                       \
+        }                                                                                      \
+    } while (0)
 
 __device__ __forceinline__ uint64_t lane_lt_mask() { return (1ull << (threadIdx.x & 63)) - 1ull; }
 __device__ __forceinline__ uint64_t lane_gt_mask() { return ~((2ull << (threadIdx.x & 63)) - 1ull); }
@@ -178,19 +188,19 @@ __device__ __forceinline__ uint4 mix_p(uint4 cur, uint4 nw) {
     return make_uint4(mix_pair(cur.x, nw.x), mix_pair(cur.y, nw.y), mix_pair(cur.z, nw.z), mix_pair(cur.w, nw.w));
 }
 
-// bytes c0..c3 at position i of a block (zeros before the block start: a fresh model's history is 0)
-__device__ __forceinline__ uint32_t load_window(const uint8_t *blk, uint32_t i) {
-    uint32_t w;
-    if (i >= 3) {  // one unaligned dword (global memory allows it): bytes i-3..i = c3 c2 c1 c0 in memory order
-        uint32_t raw;
-        __builtin_memcpy(&raw, blk + i - 3, 4);
-        w = __builtin_bswap32(raw);
-    } else {
-        w = blk[i];
-        if (i >= 1) w |= (uint32_t)blk[i - 1] << 8;
-        if (i >= 2) w |= (uint32_t)blk[i - 2] << 16;
-    }
-    return w;  // c0 | c1<<8 | c2<<16 | c3<<24
+// bytes c0..c3 at position i of a block (zeros before the block start: a fresh model's history is 0).
+// ONE unconditional unaligned dword load, so that batches of these loads stay in flight together
+// (hipcc waits vmcnt(0) right after any load it has to branch around).  `first` = the block starts the
+// input buffer: positions 0..2 then read bytes 0..3 and shift; otherwise they read into the previous
+// block (valid memory) and mask.  Needs n >= 4 (the host sends smaller inputs to the generic kernel).
+__device__ __forceinline__ uint32_t load_window(const uint8_t *blk, uint32_t i, bool first) {
+    const uint32_t j = first ? max(i, 3u) : i;
+    uint32_t raw;
+    __builtin_memcpy(&raw, blk + (int64_t)j - 3, 4);
+    uint32_t w = __builtin_bswap32(raw);   // memory order c3 c2 c1 c0 -> c0 | c1<<8 | c2<<16 | c3<<24
+    const uint32_t sh = 8u * (3u - min(i, 3u));
+    w = first ? (w >> sh) : (w & (0xFFFFFFFFu >> sh));
+    return w;
 }
 
 // ---------------------------------------------------------------------------
@@ -208,17 +218,21 @@ __global__ void __launch_bounds__(64) k_predict_small(PredictArgs a) {
 #pragma unroll
         for (int k = 0; k < 32; k++) tbl[k * 64 + lane] = 0u;
         __builtin_amdgcn_wave_barrier();
-        // operands of round r+1 are loaded while round r is ranked (the loop is issue bound otherwise)
-        uint32_t nw = 0; uint2 nk = make_uint2(0, 0);
-        if (lane < len) {
-            if constexpr (KEYS) { nk = a.keys[off + lane]; nw = blk[lane]; } else nw = load_window(blk, lane);
+        // operands of round r+1 are loaded while round r is ranked; every load is unconditional (index clamped)
+        const bool first = off == 0;
+        const uint32_t last = len - 1u;
+        uint32_t nw; uint2 nk = make_uint2(0, 0);
+        {
+            const uint32_t ic = min((uint32_t)lane, last);
+            if constexpr (KEYS) { nk = a.keys[off + ic]; nw = blk[ic]; } else nw = load_window(blk, ic, first);
         }
         for (uint32_t base = 0; base < len; base += 64) {
             const uint32_t i = base + lane;
             const bool valid = i < len;
             const uint32_t w = nw; const uint2 k8 = nk;
-            if (i + 64 < len) {
-                if constexpr (KEYS) { nk = a.keys[off + i + 64]; nw = blk[i + 64]; } else nw = load_window(blk, i + 64);
+            {
+                const uint32_t ic = min(i + 64u, last);
+                if constexpr (KEYS) { nk = a.keys[off + ic]; nw = blk[ic]; } else nw = load_window(blk, ic, first);
             }
             uint32_t c0 = 0, key[8];
             uint64_t M[8];
@@ -262,33 +276,47 @@ __device__ __forceinline__ uint32_t wave_excl_scan_u32(uint32_t v, uint32_t *tot
 // 16 bins keep only 16 open output lines per wave, so the scattered position writes merge
 // into full lines in L2 (256 bins x 4096 waves overflowed the L2s: every 4-byte store became
 // its own HBM transaction).  hist[pass][16] is filled in ONE time-ordered sweep up front.
+#define W3_PF 8   // rounds whose loads are in flight together in the short-round loops
+
 template <int NPASS>
-__device__ __forceinline__ void partition_hist(const uint8_t *blk, uint32_t len, uint32_t *hist) {
+__device__ __forceinline__ void partition_hist(const uint8_t *blk, uint32_t len, bool first, uint32_t *hist) {
     const int lane = threadIdx.x & 63;
     const uint64_t gt = lane_gt_mask();
     if (lane < 16 * NPASS) hist[lane] = 0u;
     __builtin_amdgcn_wave_barrier();
-    for (uint32_t base = 0; base < len; base += 64) {
-        const uint32_t i = base + lane;
-        const bool valid = i < len;
-        // key bytes of position i: c1 (and c2); zeros before the block start
-        uint32_t kb = 0;
-        if (valid && i >= 1) kb = blk[i - 1];
-        if (NPASS == 4 && valid && i >= 2) kb |= (uint32_t)blk[i - 2] << 8;
-        const uint64_t vm = __ballot(valid);
+    // Rounds are short, so a round-at-a-time loop would sit out one memory latency (~4-6k cycles under
+    // load) per round: the loads of W3_PF rounds are issued together, one batch ahead.
+    uint32_t wn[W3_PF];
+    const uint32_t last = len - 1u;
 #pragma unroll
-        for (int ps = 0; ps < NPASS; ps++) {
-            // pass order (LSD): c2 low, c2 high, c1 low, c1 high  /  c1 low, c1 high
-            const uint32_t d = NPASS == 4 ? ((ps < 2 ? (kb >> 8) : kb) >> (4 * (ps & 1))) & 15u : (kb >> (4 * ps)) & 15u;
-            uint64_t m = vm;
+    for (int r = 0; r < W3_PF; r++) wn[r] = load_window(blk, min(r * 64u + lane, last), first);
+    for (uint32_t base = 0; base < len; base += 64u * W3_PF) {
+        uint32_t wc[W3_PF];
 #pragma unroll
-            for (int k = 0; k < 4; k++) {
-                const bool mybit = (d >> k) & 1u;
-                const uint64_t B = __ballot(mybit);
-                m &= mybit ? B : ~B;
+        for (int r = 0; r < W3_PF; r++) wc[r] = wn[r];
+#pragma unroll
+        for (int r = 0; r < W3_PF; r++) wn[r] = load_window(blk, min(base + (W3_PF + r) * 64u + lane, last), first);
+#pragma unroll
+        for (int r = 0; r < W3_PF; r++) {
+            const uint32_t i = base + r * 64u + lane;
+            if (base + r * 64u >= len) break;
+            const bool valid = i < len;
+            const uint32_t kb = valid ? (wc[r] >> 8) & 0xFFFFu : 0u;   // c1 | c2 << 8 (zeros before the block start)
+            const uint64_t vm = __ballot(valid);
+#pragma unroll
+            for (int ps = 0; ps < NPASS; ps++) {
+                // pass order (LSD): c2 low, c2 high, c1 low, c1 high  /  c1 low, c1 high
+                const uint32_t d = NPASS == 4 ? ((ps < 2 ? (kb >> 8) : kb) >> (4 * (ps & 1))) & 15u : (kb >> (4 * ps)) & 15u;
+                uint64_t m = vm;
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const bool mybit = (d >> k) & 1u;
+                    const uint64_t B = __ballot(mybit);
+                    m &= mybit ? B : ~B;
+                }
+                if (valid && (m & gt) == 0ull) hist[ps * 16 + d] += (uint32_t)__popcll(m);
+                __builtin_amdgcn_wave_barrier();
             }
-            if (valid && (m & gt) == 0ull) hist[ps * 16 + d] += (uint32_t)__popcll(m);
-            __builtin_amdgcn_wave_barrier();
         }
     }
     // exclusive scan inside each pass's 16 bins
@@ -307,30 +335,47 @@ __device__ __forceinline__ void partition_hist(const uint8_t *blk, uint32_t len,
 // One stable 16-way pass.  Elements travel as RECORDS (position, window bytes c0..c3), so
 // no pass ever gathers from the input block again: with 4096 waves in flight the blocks do
 // not stay in L2 and every gathered byte cost a 64-byte fetch (212 GB of FETCH per GB input).
-__device__ __forceinline__ void partition_pass4(const uint8_t *blk, uint32_t len, uint32_t back, uint32_t shift, const uint2 *src, uint2 *dst, uint32_t *bins) {
+template <bool FROM_INPUT>
+__device__ __forceinline__ void partition_pass4(const uint8_t *blk, uint32_t len, bool first, uint32_t back, uint32_t shift, const uint2 *src, uint2 *dst, uint32_t *bins) {
     const int lane = threadIdx.x & 63;
     const uint64_t gt = lane_gt_mask();
-    uint2 r_n = make_uint2(0u, 0u);
-    if ((uint32_t)lane < len) r_n = src ? src[lane] : make_uint2((uint32_t)lane, load_window(blk, (uint32_t)lane));
-    for (uint32_t base = 0; base < len; base += 64) {
-        const uint32_t e = base + lane;
-        const bool valid = e < len;
-        const uint2 r = r_n;
-        if (e + 64u < len) r_n = src ? src[e + 64u] : make_uint2(e + 64u, load_window(blk, e + 64u));
-        const uint32_t d = valid ? (r.y >> (8u * back + shift)) & 15u : 0u;
-        uint64_t m = __ballot(valid);
+    const uint32_t last = len - 1u;
+    uint2 rn[W3_PF];
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const bool mybit = (d >> k) & 1u;
-            const uint64_t B = __ballot(mybit);
-            m &= mybit ? B : ~B;
+    for (int r = 0; r < W3_PF; r++) {
+        const uint32_t e = min(r * 64u + lane, last);
+        if constexpr (FROM_INPUT) rn[r] = make_uint2(e, load_window(blk, e, first)); else rn[r] = src[e];
+    }
+    for (uint32_t base = 0; base < len; base += 64u * W3_PF) {
+        uint2 rc[W3_PF];
+#pragma unroll
+        for (int r = 0; r < W3_PF; r++) rc[r] = rn[r];
+#pragma unroll
+        for (int r = 0; r < W3_PF; r++) {
+            const uint32_t e = min(base + (W3_PF + r) * 64u + lane, last);
+            if constexpr (FROM_INPUT) rn[r] = make_uint2(e, load_window(blk, e, first)); else rn[r] = src[e];
         }
-        if (valid) {
-            const uint32_t bs = bins[d];
-            dst[bs + mbcnt64(m)] = r;
-            if ((m & gt) == 0ull) bins[d] = bs + (uint32_t)__popcll(m);
+#pragma unroll
+        for (int r = 0; r < W3_PF; r++) {
+            const uint32_t e = base + r * 64u + lane;
+            if (base + r * 64u >= len) break;
+            const bool valid = e < len;
+            const uint2 rec = rc[r];
+            const uint32_t d = valid ? (rec.y >> (8u * back + shift)) & 15u : 0u;
+            uint64_t m = __ballot(valid);
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const bool mybit = (d >> k) & 1u;
+                const uint64_t B = __ballot(mybit);
+                m &= mybit ? B : ~B;
+            }
+            if (valid) {
+                const uint32_t bs = bins[d];
+                dst[bs + mbcnt64(m)] = rec;
+                if ((m & gt) == 0ull) bins[d] = bs + (uint32_t)__popcll(m);
+            }
+            __builtin_amdgcn_wave_barrier();
         }
-        __builtin_amdgcn_wave_barrier();
     }
 }
 
@@ -346,23 +391,29 @@ __global__ void __launch_bounds__(64) k_predict_wide(PredictArgs a) {
         const uint32_t len = (uint32_t)((a.n - off) < a.block_size ? (a.n - off) : a.block_size);
         const uint8_t *blk = a.in + off;
         const uint2 *perm;
-        partition_hist<2 * NBYTES>(blk, len, hist);
+        unsigned long long t_prev = a.dbg ? __builtin_amdgcn_s_memtime() : 0ull;
+        const bool first = off == 0;
+        partition_hist<2 * NBYTES>(blk, len, first, hist);
+        W3_STAMP(0);
         if constexpr (NBYTES == 1) {
-            partition_pass4(blk, len, 1, 0, nullptr, perm_a, hist);
+            partition_pass4<true>(blk, len, first, 1, 0, nullptr, perm_a, hist);
             __threadfence_block();
-            partition_pass4(blk, len, 1, 4, perm_a, perm_b, hist + 16);
+            W3_STAMP(1);
+            partition_pass4<false>(blk, len, first, 1, 4, perm_a, perm_b, hist + 16);
             perm = perm_b;
         } else {
-            partition_pass4(blk, len, 2, 0, nullptr, perm_a, hist);            // LSD: minor key c2 first
+            partition_pass4<true>(blk, len, first, 2, 0, nullptr, perm_a, hist);            // LSD: minor key c2 first
             __threadfence_block();
-            partition_pass4(blk, len, 2, 4, perm_a, perm_b, hist + 16);
+            W3_STAMP(1);
+            partition_pass4<false>(blk, len, first, 2, 4, perm_a, perm_b, hist + 16);
             __threadfence_block();
-            partition_pass4(blk, len, 1, 0, perm_b, perm_a, hist + 32);
+            partition_pass4<false>(blk, len, first, 1, 0, perm_b, perm_a, hist + 32);
             __threadfence_block();
-            partition_pass4(blk, len, 1, 4, perm_a, perm_b, hist + 48);
+            partition_pass4<false>(blk, len, first, 1, 4, perm_a, perm_b, hist + 48);
             perm = perm_b;
         }
         __threadfence_block();
+        W3_STAMP(2);
         // The table describes ONE group at a time: the group that is still open at the end of a round.
         // Groups that start and end inside a round never touch it (their Counters start new).
 #pragma unroll
@@ -371,13 +422,14 @@ __global__ void __launch_bounds__(64) k_predict_wide(PredictArgs a) {
         bool dirty = false;              // table holds states of group open_g
         uint32_t open_g = 0xFFFFFFFFu;   // group the table describes (also: group of the previous round's last element)
         // software pipeline: the record of round r+1 is loaded while round r is ranked
-        uint2 r_n = make_uint2(0u, 0u);
-        if ((uint32_t)lane < len) r_n = perm[lane];
+        const uint32_t last = len - 1u;
+        uint2 r_n = perm[min((uint32_t)lane, last)], r_nn = perm[min((uint32_t)lane + 64u, last)];
         for (uint32_t base = 0; base < len; base += 64) {
             const uint32_t e = base + lane;
             const bool valid = e < len;
             const uint32_t i = r_n.x; const uint32_t w = valid ? r_n.y : 0u;
-            if (e + 64u < len) r_n = perm[e + 64u];
+            r_n = r_nn;
+            r_nn = perm[min(e + 128u, last)];
             const uint32_t c0 = w & 0xFFu;
             // group id and the byte that supplies the low key bits
             const uint32_t g = NBYTES == 1 ? ((w >> 8) & 0xFFu) : ((w >> 8) & 0xFFFFu);
@@ -418,6 +470,8 @@ __global__ void __launch_bounds__(64) k_predict_wide(PredictArgs a) {
             open_g = g_last;
             if (valid) a.P[off + i] = pack_p(p);  // 16-byte scatter, write-only
         }
+        W3_STAMP(3);
+        if (a.dbg && lane == 0) atomicAdd(&a.dbg[7], 1ull);
     }
 }
 

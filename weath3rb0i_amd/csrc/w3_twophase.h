@@ -17,6 +17,8 @@
 struct TwoPhaseWs {
     void *P = nullptr, *keys = nullptr, *perm = nullptr, *redo = nullptr, *streams = nullptr;
     size_t P_cap = 0, keys_cap = 0, perm_cap = 0, redo_cap = 0, streams_cap = 0;
+    void *dbg = nullptr;       // 8 x u64 phase stamps of the last wide predict kernel (W3_OPT_DEBUG_STAMPS)
+    int debug_stamps = 0;
     int coder_mode = 0;        // 0 = k_coder_x2 (two waves per 64 blocks), 1 = k_coder_fast, 2 = k_coder only
     uint32_t acc_limit = 46;   // test hook: lower values force the fast coder's fallback
     void release() {
@@ -25,6 +27,8 @@ struct TwoPhaseWs {
         if (perm) (void)hipFree(perm);
         if (redo) (void)hipFree(redo);
         if (streams) (void)hipFree(streams);
+        if (dbg) (void)hipFree(dbg);
+        dbg = nullptr;
         P = keys = perm = redo = streams = nullptr;
         P_cap = keys_cap = perm_cap = redo_cap = streams_cap = 0;
     }
@@ -52,8 +56,8 @@ static inline int leaf_class(const w3_node &nd) {
     return LEAF_NONE;
 }
 
-static inline bool twophase_supported(const ParsedSpec &ps, size_t block_size) {
-    if (block_size > (1u << 24)) return false;
+static inline bool twophase_supported(const ParsedSpec &ps, size_t block_size, size_t n) {
+    if (block_size > (1u << 24) || n < 4) return false;   // the window loads read 4 bytes at once
     for (int l = 0; l < ps.n_leaves; l++)
         if (leaf_class(ps.leaf[l]) == LEAF_NONE) return false;
     return true;
@@ -129,6 +133,10 @@ static inline int twophase_predict(TwoPhaseWs &ws, hipStream_t s, const ParsedSp
             launch_small<false>(nd.bits - 3, dim3(grid_small), s, pa);
         } else {
             pa.perm = (uint32_t *)ws.perm;
+            if (ws.debug_stamps) {
+                if (!ws.dbg && hipMalloc(&ws.dbg, 64) != hipSuccess) ws.dbg = nullptr;
+                if (ws.dbg) { (void)hipMemsetAsync(ws.dbg, 0, 64, s); pa.dbg = (unsigned long long *)ws.dbg; }
+            }
             if (c == LEAF_WIDE1) hipLaunchKernelGGL(w3::k_predict_wide<1>, dim3(grid_wide), dim3(64), 0, s, pa);
             else hipLaunchKernelGGL(w3::k_predict_wide<2>, dim3(grid_wide), dim3(64), 0, s, pa);
             bytes += n * 16 * (c == LEAF_WIDE1 ? 2 : 4);  // record passes: 8 B written + 8 B read each

@@ -124,6 +124,7 @@ extern "C" int w3_ctx_set_option(w3_ctx *ctx, int opt, int64_t value) {
         if (value < 0 || value > 2) return W3_E_INVALID;
         ctx->tp.coder_mode = (int)value;
         return W3_OK;
+    case W3_OPT_DEBUG_STAMPS: ctx->tp.debug_stamps = value ? 1 : 0; return W3_OK;
     case W3_OPT_ACC_LIMIT:
         if (value < 19 || value > 46) return W3_E_INVALID;
         ctx->tp.acc_limit = (uint32_t)value;
@@ -343,7 +344,7 @@ extern "C" int w3_encode_blocks_device(w3_ctx *ctx, const w3_model_spec *spec, c
     if (!d_in || !d_out || !d_block_lens) return W3_E_INVALID;
     ENSURE(ctx, ctx->flag, 16);
 
-    bool two = twophase_supported(ps, block_size);
+    bool two = twophase_supported(ps, block_size, n);
     if (ctx->opt_path == W3_PATH_GENERIC) two = false;
     if (ctx->opt_path == W3_PATH_TWOPHASE && !two) { ctx->err = "spec/block size not covered by the two-phase path"; return W3_E_UNSUPPORTED; }
 
@@ -552,7 +553,7 @@ extern "C" int w3_predict_blocks(w3_ctx *ctx, const w3_model_spec *spec, const u
     if ((rc = parse_spec(spec, ps))) return rc;
     if (n == 0) return W3_OK;
     if (!in || !p_out) return W3_E_INVALID;
-    if (!twophase_supported(ps, block_size)) { ctx->err = "spec not covered by the two-phase predict kernels"; return W3_E_UNSUPPORTED; }
+    if (!twophase_supported(ps, block_size, n)) { ctx->err = "spec not covered by the two-phase predict kernels"; return W3_E_UNSUPPORTED; }
     HIPCHK(ctx, hipSetDevice(ctx->device));
     hipStream_t s = ctx->stream;
     const uint32_t nb = (uint32_t)((n + block_size - 1) / block_size);
@@ -580,5 +581,15 @@ extern "C" int w3_selftest_counter_p(w3_ctx *ctx, uint64_t *mismatches) {
     }
     HIPCHK(ctx, hipMemcpyAsync(mismatches, ctx->total.p, 8, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return W3_OK;
+}
+
+extern "C" int w3_debug_get_stamps(w3_ctx *ctx, uint64_t out[8]) {
+    if (!ctx || !out) return W3_E_INVALID;
+    memset(out, 0, 64);
+    if (!ctx->tp.dbg) return W3_OK;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, hipDeviceSynchronize());
+    HIPCHK(ctx, hipMemcpy(out, ctx->tp.dbg, 64, hipMemcpyDeviceToHost));
     return W3_OK;
 }
