@@ -195,6 +195,12 @@ def test_edge_blocks(ctx, oracle, path):
     assert ctx.encode_blocks(w3.Order0(), b"\xff" * bs, bs)[0].tobytes() == b"\x00" * 16 + b"\x01"
     for cname, data in cases.items():
         b = bs if cname in ("zeros", "ones") else 4096
+        if path == "twophase" and len(data) < 4:
+            # the predict kernels read 4-byte windows: inputs under 4 bytes always take the generic kernel
+            with pytest.raises(w3.W3Error):
+                check_blocks(ctx, oracle, "order0", data, b, path)
+            check_blocks(ctx, oracle, "order0", data, b, "auto")
+            continue
         for name in ("order0", "best012"):
             out, lens = check_blocks(ctx, oracle, name, data, b, path)
             dev, _ = pair(oracle, name)
