@@ -89,7 +89,7 @@ int         w3_spec_validate(const w3_model_spec *spec);
 enum {
     W3_OPT_PATH   = 1,  /* W3_PATH_*: which device implementation encode uses      */
     W3_OPT_TIMING = 2,  /* 1 = record per-kernel hipEvent timings (w3_get_timing) */
-    W3_OPT_CODER  = 3,  /* two-phase coder kernel: 0 = k_coder_x2, 1 = k_coder_fast, 2 = robust k_coder only */
+    W3_OPT_CODER  = 3,  /* two-phase coder kernel: 0 = k_coder_x3 (default), 1 = k_coder_fast, 2 = robust k_coder only, 3 = k_coder_x2 */
     W3_OPT_ACC_LIMIT = 4, /* test hook (19..46): accumulator fill at which the fast coder hands a block back */
     W3_OPT_DEBUG_STAMPS = 5 /* diagnostic: 1 = the partitioned predict kernel sums s_memtime per phase */
 };

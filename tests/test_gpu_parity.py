@@ -149,12 +149,12 @@ def test_coder_variants_and_fallback(ctx, oracle):
     model = w3.BestOfTwoModel(w3.Order0(), w3.Order1())
     ctx.set_path("twophase")
     try:
-        for mode in ("x2", "fast", "robust"):
+        for mode in ("x3", "x2", "fast", "robust"):
             ctx.set_coder(mode)
             out, lens = ctx.encode_blocks(model, data, 8192)
             assert lens.tolist() == wlens.tolist() and out.tobytes() == want.tobytes(), mode
             assert ctx.timing()["n_recoded_blocks"] == 0
-        for mode in ("x2", "fast"):
+        for mode in ("x3", "x2", "fast"):
             ctx.set_coder(mode)
             for limit in (19, 24, 33):  # force the fast coders to give blocks back to k_coder
                 ctx.set_acc_limit(limit)
@@ -165,7 +165,7 @@ def test_coder_variants_and_fallback(ctx, oracle):
             ctx.set_acc_limit(46)
     finally:
         ctx.set_acc_limit(46)
-        ctx.set_coder("x2")
+        ctx.set_coder("x3")
         ctx.set_path("auto")
 
 

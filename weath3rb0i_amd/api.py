@@ -44,7 +44,7 @@ class Context:
         self._chk(self.lib.w3_ctx_set_option(self.h, L.W3_OPT_PATH, {"auto": 0, "generic": 1, "twophase": 2}[path]))
 
     def set_coder(self, mode):
-        self._chk(self.lib.w3_ctx_set_option(self.h, L.W3_OPT_CODER, {"x2": 0, "fast": 1, "robust": 2}[mode]))
+        self._chk(self.lib.w3_ctx_set_option(self.h, L.W3_OPT_CODER, {"x3": 0, "fast": 1, "robust": 2, "x2": 3}[mode]))
 
     def set_acc_limit(self, bits):
         self._chk(self.lib.w3_ctx_set_option(self.h, L.W3_OPT_ACC_LIMIT, bits))

@@ -353,3 +353,226 @@ __global__ void __launch_bounds__(128) k_coder_x2(CoderArgs a) {
 }
 
 }  // namespace w3
+
+namespace w3 {
+
+// ---------------------------------------------------------------------------
+// k_coder_x3<L> — three wavefronts per 64 blocks: MIX -> RECURRENCE -> OUTPUT.
+//
+//   M-wave: streams the L leaves' probability streams and the input bytes from
+//           HBM (the only wave that touches global loads), applies OpinionMixer2
+//           (leftmost leaf of maximal |p-1/2|) and hands the X-wave, per step,
+//           the two operands it needs: p32 = p<<16 and the bit as a 0/~0 mask.
+//           This replaces the separate k_mix pass (48+16 GB of traffic per GB
+//           of input at L = 3) and keeps memory latency out of the recurrence.
+//   X-wave: (x1, x2) recurrence only, LDS in, LDS out (see k_coder_x2).
+//   O-wave: accumulator, flushes, final ACWriter::flush (see k_coder_x2).
+// Two LDS rings of 16 input bytes each (M->X operands, X->O tokens): 128 KiB.
+// ---------------------------------------------------------------------------
+struct Coder3Args {
+    const uint8_t *in;
+    uint64_t n;
+    uint32_t block_size, nblocks;
+    const uint4 *src[4];   // leaf streams in leaf order (L of them)
+    uint8_t *stripes;
+    uint32_t stripe_cap;
+    uint32_t *out_len;
+    uint32_t *flags;       // [0] bit0 stripe overflow, bit1 pipeline timeout; [1] blocks in redo
+    uint32_t *redo;
+    uint32_t acc_limit;
+};
+
+__device__ __forceinline__ uint32_t spin_until_ge(const volatile uint32_t *ctr, uint32_t need, volatile uint32_t *abortf, bool &dead) {
+    uint32_t v = lds_load_u32(ctr), spins = 0;
+    while (v < need) {
+        __builtin_amdgcn_s_sleep(1);
+        if (++spins > W3_X2_SPIN_LIMIT || lds_load_u32(abortf)) { lds_store_u32(abortf, 1u); dead = true; break; }
+        v = lds_load_u32(ctr);
+    }
+    return v;
+}
+
+template <int L>
+__global__ void __launch_bounds__(192) k_coder_x3(Coder3Args a) {
+    __shared__ uint2 opq[W3_X2_RING * 8u * 64u];   // M -> X: (p32, bitmask) per step   [ring byte][bit][lane]
+    __shared__ uint2 tok[W3_X2_RING * 8u * 64u];   // X -> O: (x1 after update, c)      [ring byte][bit][lane]
+    __shared__ uint32_t fin_x2[64];
+    __shared__ uint32_t sync_w[8];                 // [0] M produced, [1] X consumed, [2] X produced, [3] O consumed, [4] abort
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    const uint32_t b = blockIdx.x * 64u + lane;
+    const bool act = b < a.nblocks;
+    const uint64_t off = (uint64_t)(act ? b : 0u) * a.block_size;
+    const uint32_t len = act ? (uint32_t)((a.n - off) < a.block_size ? (a.n - off) : a.block_size) : 0u;
+    uint32_t maxlen = len;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) maxlen = max(maxlen, (uint32_t)__shfl_xor((int)maxlen, d, 64));
+    maxlen = __builtin_amdgcn_readfirstlane(maxlen);
+    if (threadIdx.x < 8) sync_w[threadIdx.x] = 0u;
+    __syncthreads();
+    volatile uint32_t *m_prod = &sync_w[0], *x_cons = &sync_w[1], *x_prod = &sync_w[2], *o_cons = &sync_w[3], *abortf = &sync_w[4];
+    bool dead = false;
+
+    if (wave == 0) {
+        // ------------------------------ M-wave ------------------------------
+        const uint32_t last = (act && len) ? len - 1u : 0u;
+        const uint8_t *blk = a.in + off;
+        uint4 nx[L][4]; uint32_t nbyte[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const uint32_t ic = min((uint32_t)k, last);
+            nbyte[k] = blk[ic];
+#pragma unroll
+            for (int l = 0; l < L; l++) nx[l][k] = a.src[l][off + ic];
+        }
+        uint32_t seen = 0;   // last value read from x_cons
+        for (uint32_t i = 0; i < maxlen && !dead; i += 4) {
+            if ((i & 7u) == 0u && i + 8u > seen + W3_X2_RING) {   // ring slots of bytes [i, i+8) must have been consumed
+                seen = spin_until_ge(x_cons, i + 8u - W3_X2_RING, abortf, dead);
+                if (dead) break;
+            }
+            uint4 cur[L][4]; uint32_t cb[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                cb[k] = nbyte[k];
+#pragma unroll
+                for (int l = 0; l < L; l++) cur[l][k] = nx[l][k];
+            }
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const uint32_t ic = min(i + 4u + k, last);
+                nbyte[k] = blk[ic];
+#pragma unroll
+                for (int l = 0; l < L; l++) nx[l][k] = a.src[l][off + ic];
+            }
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                if (i + k < len) {
+                    uint2 *slot = opq + ((size_t)((i + k) & (W3_X2_RING - 1u)) * 8u) * 64u + lane;
+#pragma unroll
+                    for (int q = 0; q < 4; q++) {   // one dword = two steps
+                        uint32_t w0 = q == 0 ? cur[0][k].x : q == 1 ? cur[0][k].y : q == 2 ? cur[0][k].z : cur[0][k].w;
+                        uint32_t plo = w0 & 0xFFFFu, phi = w0 >> 16;
+                        if constexpr (L > 1) {
+                            uint32_t dlo = opinion_dist(plo), dhi = opinion_dist(phi);
+#pragma unroll
+                            for (int l = 1; l < L; l++) {
+                                const uint32_t w = q == 0 ? cur[l][k].x : q == 1 ? cur[l][k].y : q == 2 ? cur[l][k].z : cur[l][k].w;
+                                const uint32_t qlo = w & 0xFFFFu, qhi = w >> 16;
+                                const uint32_t elo = opinion_dist(qlo), ehi = opinion_dist(qhi);
+                                if (elo > dlo) { plo = qlo; dlo = elo; }   // ties keep the left leaf
+                                if (ehi > dhi) { phi = qhi; dhi = ehi; }
+                            }
+                        }
+                        slot[(2 * q) * 64] = make_uint2(plo << 16, (uint32_t)__builtin_amdgcn_sbfe((int)cb[k], 7 - 2 * q, 1));
+                        slot[(2 * q + 1) * 64] = make_uint2(phi << 16, (uint32_t)__builtin_amdgcn_sbfe((int)cb[k], 6 - 2 * q, 1));
+                    }
+                }
+            }
+            __asm__ volatile("" ::: "memory");
+            lds_store_u32(m_prod, min(i + 4u, maxlen));
+        }
+        return;
+    }
+
+    if (wave == 1) {
+        // ------------------------------ X-wave ------------------------------
+        uint32_t x1 = 0u, x2 = 0xFFFFFFFFu;
+        uint32_t seen_m = 0, seen_o = 0;
+        for (uint32_t i = 0; i < maxlen && !dead; i += 8) {
+            const uint32_t need = min(i + 8u, maxlen);
+            if (seen_m < need) { seen_m = spin_until_ge(m_prod, need, abortf, dead); if (dead) break; }
+            if (i + 8u > seen_o + W3_X2_RING) { seen_o = spin_until_ge(o_cons, i + 8u - W3_X2_RING, abortf, dead); if (dead) break; }
+            __asm__ volatile("" ::: "memory");
+#pragma unroll 1
+            for (uint32_t k = 0; k < 8u; k++) {
+                if (i + k < len) {
+                    const size_t ring = ((size_t)((i + k) & (W3_X2_RING - 1u)) * 8u) * 64u + lane;
+                    uint2 op[8];
+#pragma unroll
+                    for (int j = 0; j < 8; j++) op[j] = opq[ring + j * 64];
+#pragma unroll
+                    for (int j = 0; j < 8; j++) {
+                        const uint32_t p32 = op[j].x, bitmask = op[j].y;
+                        const uint32_t xmid = x1 + __umulhi(x2 - x1, p32);
+                        x1 = (x1 & bitmask) | ((xmid + 1u) & ~bitmask);
+                        x2 = (xmid & bitmask) | (x2 & ~bitmask);
+                        const uint32_t n = (uint32_t)__builtin_clz(x1 ^ x2);
+                        const uint32_t u = ~(x1 & ~x2) & (0x7FFFFFFFu >> n);
+                        const uint32_t c = (uint32_t)__builtin_clz(u);
+                        tok[ring + j * 64] = make_uint2(x1, c);
+                        x1 = (x1 << c) >> 1;
+                        x2 = ~((~x2 << c) >> 1);
+                    }
+                    if (i + k + 1u == len) fin_x2[lane] = x2;
+                }
+            }
+            __asm__ volatile("" ::: "memory");
+            lds_store_u32(x_cons, need);
+            lds_store_u32(x_prod, need);
+        }
+        return;
+    }
+
+    // -------------------------------- O-wave --------------------------------
+    uint8_t *out = a.stripes + (uint64_t)(act ? b : 0u) * a.stripe_cap;
+    const uint32_t cap = act ? a.stripe_cap : 0u, limit = a.acc_limit;
+    uint64_t acc = 0ull; uint32_t nb = 1u, pos = 0u;
+    bool failed = false;
+    uint32_t seen_x = 0;
+    for (uint32_t i = 0; i < maxlen && !dead; i += 8) {
+        const uint32_t need = min(i + 8u, maxlen);
+        if (seen_x < need) { seen_x = spin_until_ge(x_prod, need, abortf, dead); if (dead) break; }
+        __asm__ volatile("" ::: "memory");
+#pragma unroll 1
+        for (uint32_t k = 0; k < 8u; k++) {
+            if (i + k < len) {
+                const uint2 *slot = tok + ((size_t)((i + k) & (W3_X2_RING - 1u)) * 8u) * 64u + lane;
+                uint2 t[8];
+#pragma unroll
+                for (int j = 0; j < 8; j++) t[j] = slot[j * 64];
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    if (__builtin_expect(nb > limit, 0)) {
+                        const uint32_t pend = trailing_ones64(acc) + 1u;
+#pragma unroll 1
+                        while (nb >= pend + 8u) {
+                            const uint8_t v = (uint8_t)(acc >> (nb - 8u));
+                            if (pos < cap) out[pos] = v;
+                            pos += 1u; nb -= 8u;
+                        }
+                        if (nb > limit) { failed = true; acc = 0ull; nb = 1u; }
+                    }
+                    const uint32_t x1v = t[j].x, c = t[j].y, s = c - 1u;
+                    acc += x1v >> 31;
+                    acc = (acc << s) | __builtin_amdgcn_ubfe(x1v, 32u - c, s);
+                    nb += s;
+                }
+                const uint32_t lo = (uint32_t)acc;
+                const uint32_t pend = (~lo ? (uint32_t)__builtin_ctz(~lo) : 32u) + 1u;
+                if (nb >= pend + 32u) {
+                    const uint32_t wv = (uint32_t)(acc >> (nb - 32u));
+                    if (pos + 4u <= cap) { const uint32_t be = __builtin_bswap32(wv); __builtin_memcpy(out + pos, &be, 4); }
+                    pos += 4u; nb -= 32u;
+                }
+            }
+        }
+        __asm__ volatile("" ::: "memory");
+        lds_store_u32(o_cons, need);
+    }
+    if (dead) { if (lane == 0) atomicOr(&a.flags[0], 2u); return; }
+    if (!act) return;
+    const uint32_t x2f = fin_x2[lane];
+    acc += 1ull;
+    const uint32_t idx = nb & 7u;
+    if (idx) { const uint32_t k = 8u - idx; acc = (acc << k) | ((x2f << 1) >> (32u - k)); nb += k; }
+#pragma unroll 1
+    while (nb >= 8u) {
+        const uint8_t v = (uint8_t)(acc >> (nb - 8u));
+        if (pos < cap) out[pos] = v;
+        pos += 1u; nb -= 8u;
+    }
+    if (failed) { const uint32_t k = atomicAdd(&a.flags[1], 1u); a.redo[k] = b; }
+    else { a.out_len[b] = pos; if (pos > cap) atomicOr(&a.flags[0], 1u); }
+}
+
+}  // namespace w3

@@ -17,9 +17,11 @@
 struct TwoPhaseWs {
     void *P = nullptr, *keys = nullptr, *perm = nullptr, *redo = nullptr, *streams = nullptr;
     size_t P_cap = 0, keys_cap = 0, perm_cap = 0, redo_cap = 0, streams_cap = 0;
+    w3::MixArgs mix{};         // leaf streams of the last predict (sources of k_mix / k_coder_x3)
+    bool P_valid = false;      // ws.P holds the merged stream of the last predict
     void *dbg = nullptr;       // 8 x u64 phase stamps of the last wide predict kernel (W3_OPT_DEBUG_STAMPS)
     int debug_stamps = 0;
-    int coder_mode = 0;        // 0 = k_coder_x2 (two waves per 64 blocks), 1 = k_coder_fast, 2 = k_coder only
+    int coder_mode = 0;        // 0 = k_coder_x3 (mix+recurrence+output waves), 1 = k_coder_fast, 2 = k_coder only, 3 = k_coder_x2
     uint32_t acc_limit = 46;   // test hook: lower values force the fast coder's fallback
     void release() {
         if (P) (void)hipFree(P);
@@ -79,10 +81,24 @@ static inline void launch_small(int H, dim3 grid, hipStream_t s, const w3::Predi
 }
 
 // Runs the predict kernels of every leaf; *d_P receives the merged stream.
-static inline int twophase_predict(TwoPhaseWs &ws, hipStream_t s, const ParsedSpec &ps, const uint8_t *d_in, size_t n, size_t block_size,
-                                   uint32_t nb, const uint16_t **d_P, hipEvent_t *ev, w3_timing *tm, std::string &err) {
+static inline int twophase_mix(TwoPhaseWs &ws, hipStream_t s, size_t n, std::string &err) {
+    if (ws.P_valid) return W3_OK;
     int rc = tp_ensure(ws.P, ws.P_cap, n * 16, err);
     if (rc) return rc;
+    ws.mix.P = (uint4 *)ws.P; ws.mix.n = n;
+    hipLaunchKernelGGL(w3::k_mix, dim3(256 * 8), dim3(256), 0, s, ws.mix);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { err = std::string("mix launch: ") + hipGetErrorString(e); return W3_E_HIP; }
+    ws.P_valid = true;
+    return W3_OK;
+}
+
+// need_P: also merge the leaves' streams into ws.P (k_mix).  The default coder (k_coder_x3) mixes on the fly
+// and needs no P for up to 4 live leaves.
+static inline int twophase_predict(TwoPhaseWs &ws, hipStream_t s, const ParsedSpec &ps, const uint8_t *d_in, size_t n, size_t block_size,
+                                   uint32_t nb, bool need_P, const uint16_t **d_P, hipEvent_t *ev, w3_timing *tm, std::string &err) {
+    int rc = W3_OK;
+    ws.P_valid = false;
     const uint32_t grid_small = std::min<uint32_t>(nb, 256 * 20);
     const uint32_t grid_wide = std::min<uint32_t>(nb, 256 * 16);
     bool need_keys = false, need_perm = false;
@@ -100,15 +116,18 @@ static inline int twophase_predict(TwoPhaseWs &ws, hipStream_t s, const ParsedSp
     for (int l = 0; l < ps.n_leaves; l++)
         if (leaf_class(ps.leaf[l]) != LEAF_FROZEN) live[n_live++] = l;
     if (n_live > 1 && (rc = tp_ensure(ws.streams, ws.streams_cap, (size_t)n_live * n * 16, err))) return rc;
+    if (n_live <= 1 && (rc = tp_ensure(ws.P, ws.P_cap, n * 16, err))) return rc;
 
     if (ev) (void)hipEventRecord(ev[0], s);
     uint64_t bytes = 0;
+    w3::MixArgs &ma = ws.mix;
+    memset(&ma, 0, sizeof ma);
     if (n_live == 0) {
         hipLaunchKernelGGL(w3::k_fill_half, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (uint4 *)ws.P, (uint64_t)n);
         bytes += n * 16;
+        ma.src[0] = (const uint4 *)ws.P; ma.n_src = 1;
+        ws.P_valid = true;
     }
-    w3::MixArgs ma;
-    memset(&ma, 0, sizeof ma);
     for (int k = 0; k < n_live; k++) {
         const w3_node &nd = ps.leaf[live[k]];
         const int c = leaf_class(nd);
@@ -144,12 +163,11 @@ static inline int twophase_predict(TwoPhaseWs &ws, hipStream_t s, const ParsedSp
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) { err = std::string("predict launch: ") + hipGetErrorString(e); return W3_E_HIP; }
     }
-    if (n_live > 1) {
-        ma.n_src = n_live; ma.P = (uint4 *)ws.P; ma.n = n;
-        hipLaunchKernelGGL(w3::k_mix, dim3(256 * 8), dim3(256), 0, s, ma);
+    if (n_live >= 1) ma.n_src = n_live;
+    if (n_live == 1) ws.P_valid = true;   // the single leaf wrote ws.P itself
+    if (need_P && !ws.P_valid) {
+        if ((rc = twophase_mix(ws, s, n, err))) return rc;
         bytes += n * 16 * (n_live + 1);
-        hipError_t e = hipGetLastError();
-        if (e != hipSuccess) { err = std::string("mix launch: ") + hipGetErrorString(e); return W3_E_HIP; }
     }
     if (ev) (void)hipEventRecord(ev[1], s);
     if (tm) tm->predict_bytes = bytes;
@@ -160,33 +178,57 @@ static inline int twophase_predict(TwoPhaseWs &ws, hipStream_t s, const ParsedSp
 static inline int twophase_encode(TwoPhaseWs &ws, hipStream_t s, const ParsedSpec &ps, const uint8_t *d_in, size_t n, size_t block_size,
                                   uint32_t nb, uint8_t *stripes, uint32_t stripe_cap, uint32_t *d_lens, uint32_t *d_flag, hipEvent_t *ev,
                                   w3_timing *tm, std::string &err) {
-    int rc = twophase_predict(ws, s, ps, d_in, n, block_size, nb, nullptr, ev, tm, err);
+    int n_live = 0;
+    for (int l = 0; l < ps.n_leaves; l++) n_live += leaf_class(ps.leaf[l]) != LEAF_FROZEN;
+    const bool x3 = ws.coder_mode == 0 && n_live <= 4;   // more leaves: merge with k_mix first, then k_coder_x2
+    int rc = twophase_predict(ws, s, ps, d_in, n, block_size, nb, !x3, nullptr, ev, tm, err);
     if (rc) return rc;
     if ((rc = tp_ensure(ws.redo, ws.redo_cap, (size_t)nb * 4, err))) return rc;
-    w3::CoderArgs ca;
-    memset(&ca, 0, sizeof ca);
-    ca.in = d_in; ca.n = n; ca.block_size = (uint32_t)block_size; ca.nblocks = nb; ca.P = (const uint4 *)ws.P;
-    ca.stripes = stripes; ca.stripe_cap = stripe_cap; ca.out_len = d_lens; ca.flags = d_flag;
-    ca.acc_limit = std::min<uint32_t>(ws.acc_limit, 46u);
+    const uint32_t limit = std::min<uint32_t>(ws.acc_limit, 46u);
     if (ev) (void)hipEventRecord(ev[2], s);
-    if (ws.coder_mode == 2) {
-        ca.redo = nullptr;
-        hipLaunchKernelGGL(w3::k_coder, dim3((nb + 63) / 64), dim3(64), 0, s, ca);
+    if (x3) {
+        w3::Coder3Args c3;
+        memset(&c3, 0, sizeof c3);
+        c3.in = d_in; c3.n = n; c3.block_size = (uint32_t)block_size; c3.nblocks = nb;
+        for (int l = 0; l < ws.mix.n_src; l++) c3.src[l] = ws.mix.src[l];
+        c3.stripes = stripes; c3.stripe_cap = stripe_cap; c3.out_len = d_lens; c3.flags = d_flag; c3.redo = (uint32_t *)ws.redo;
+        c3.acc_limit = limit;
+        const dim3 grid((nb + 63) / 64), blk(192);
+        switch (ws.mix.n_src) {
+        case 1: hipLaunchKernelGGL(w3::k_coder_x3<1>, grid, blk, 0, s, c3); break;
+        case 2: hipLaunchKernelGGL(w3::k_coder_x3<2>, grid, blk, 0, s, c3); break;
+        case 3: hipLaunchKernelGGL(w3::k_coder_x3<3>, grid, blk, 0, s, c3); break;
+        default: hipLaunchKernelGGL(w3::k_coder_x3<4>, grid, blk, 0, s, c3); break;
+        }
+        if (tm) tm->coder_bytes = (uint64_t)n * (16 * ws.mix.n_src + 1);
     } else {
-        ca.redo = (uint32_t *)ws.redo;
-        if (ws.coder_mode == 1) hipLaunchKernelGGL(w3::k_coder_fast, dim3((nb + 63) / 64), dim3(64), 0, s, ca);
-        else hipLaunchKernelGGL(w3::k_coder_x2, dim3((nb + 63) / 64), dim3(128), 0, s, ca);
+        w3::CoderArgs ca;
+        memset(&ca, 0, sizeof ca);
+        ca.in = d_in; ca.n = n; ca.block_size = (uint32_t)block_size; ca.nblocks = nb; ca.P = (const uint4 *)ws.P;
+        ca.stripes = stripes; ca.stripe_cap = stripe_cap; ca.out_len = d_lens; ca.flags = d_flag;
+        ca.acc_limit = limit;
+        if (ws.coder_mode == 2) {
+            ca.redo = nullptr;
+            hipLaunchKernelGGL(w3::k_coder, dim3((nb + 63) / 64), dim3(64), 0, s, ca);
+        } else {
+            ca.redo = (uint32_t *)ws.redo;
+            if (ws.coder_mode == 1) hipLaunchKernelGGL(w3::k_coder_fast, dim3((nb + 63) / 64), dim3(64), 0, s, ca);
+            else hipLaunchKernelGGL(w3::k_coder_x2, dim3((nb + 63) / 64), dim3(128), 0, s, ca);
+        }
+        if (tm) tm->coder_bytes = (uint64_t)n * 17;
     }
     if (ev) (void)hipEventRecord(ev[3], s);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { err = std::string("coder launch: ") + hipGetErrorString(e); return W3_E_HIP; }
-    if (tm) { tm->n_coder_launches = 1; tm->coder_bytes = (uint64_t)n * 17; }
+    if (tm) tm->n_coder_launches = 1;
     return W3_OK;
 }
 
 // Blocks the fast coder gave up on (pending run longer than its accumulator): re-code with k_coder.
 static inline int twophase_recode(TwoPhaseWs &ws, hipStream_t s, const uint8_t *d_in, size_t n, size_t block_size, uint32_t nb,
                                   uint8_t *stripes, uint32_t stripe_cap, uint32_t *d_lens, uint32_t *d_flag, uint32_t n_redo, std::string &err) {
+    int rc = twophase_mix(ws, s, n, err);   // k_coder_x3 mixes on the fly; the robust coder wants the merged stream
+    if (rc) return rc;
     w3::CoderArgs ca;
     memset(&ca, 0, sizeof ca);
     ca.in = d_in; ca.n = n; ca.block_size = (uint32_t)block_size; ca.nblocks = nb; ca.P = (const uint4 *)ws.P;

@@ -121,7 +121,7 @@ extern "C" int w3_ctx_set_option(w3_ctx *ctx, int opt, int64_t value) {
         return W3_OK;
     case W3_OPT_TIMING: ctx->opt_timing = value ? 1 : 0; return W3_OK;
     case W3_OPT_CODER:
-        if (value < 0 || value > 2) return W3_E_INVALID;
+        if (value < 0 || value > 3) return W3_E_INVALID;
         ctx->tp.coder_mode = (int)value;
         return W3_OK;
     case W3_OPT_DEBUG_STAMPS: ctx->tp.debug_stamps = value ? 1 : 0; return W3_OK;
@@ -560,7 +560,7 @@ extern "C" int w3_predict_blocks(w3_ctx *ctx, const w3_model_spec *spec, const u
     ENSURE(ctx, ctx->io_in, n);
     HIPCHK(ctx, hipMemcpyAsync(ctx->io_in.p, in, n, hipMemcpyHostToDevice, s));
     const uint16_t *d_p = nullptr;
-    rc = twophase_predict(ctx->tp, s, ps, (const uint8_t *)ctx->io_in.p, n, block_size, nb, &d_p, nullptr, &ctx->timing, ctx->err);
+    rc = twophase_predict(ctx->tp, s, ps, (const uint8_t *)ctx->io_in.p, n, block_size, nb, true, &d_p, nullptr, &ctx->timing, ctx->err);
     if (rc) return rc;
     HIPCHK(ctx, hipStreamSynchronize(s));
     HIPCHK(ctx, hipMemcpy(p_out, d_p, n * 16, hipMemcpyDeviceToHost));
