@@ -39,7 +39,9 @@ struct PredictArgs {
     uint32_t block_size, nblocks;
     uint4 *P;               // [n] this leaf's stream: 8 x u16 per input byte, block-major (same index as `in`)
     const uint2 *keys;      // [n] 8 x u8 precomputed keys per byte (k_achash) or null
-    uint32_t *perm;         // wide: per-wave scratch, 2 * block_size u32 each
+    uint32_t *perm;         // partition: per-wave scratch, 2 * block_size records
+    uint2 *rec;             // [n] sorted records (position, window bytes) of every block
+    uint32_t *splits;       // [nblocks][W3_SLICES + 1] slice boundaries inside each block's sorted range
     uint32_t hbits;         // H = bits_in_context - 3
     unsigned long long *dbg; // optional: per-phase s_memtime sums (diagnostic builds/runs only; never read by kernels)
 };
@@ -379,9 +381,13 @@ __device__ __forceinline__ void partition_pass4(const uint8_t *blk, uint32_t len
     }
 }
 
-template <int NBYTES>  // 1: group = c1 (Order1); 2: group = (c1,c2) (OrderN(27,3))
-__global__ void __launch_bounds__(64) k_predict_wide(PredictArgs a) {
-    __shared__ uint32_t tbl[8 * 256];
+#define W3_SLICES 16u   // rank jobs per block (sorted range cut at group boundaries)
+
+// k_partition<NBYTES>: one wavefront per block sorts the block's records stably by the group key
+// (NBYTES 1: c1 — Order1; 2: (c1,c2) — OrderN(27,3)) into a.rec, and cuts the sorted range into
+// W3_SLICES slices at group boundaries (a.splits) for k_rank_sorted.
+template <int NBYTES>
+__global__ void __launch_bounds__(64) k_partition(PredictArgs a) {
     __shared__ uint32_t hist[64];
     const int lane = threadIdx.x;
     uint2 *perm_a = reinterpret_cast<uint2 *>(a.perm) + (uint64_t)blockIdx.x * 2u * a.block_size;
@@ -390,7 +396,7 @@ __global__ void __launch_bounds__(64) k_predict_wide(PredictArgs a) {
         const uint64_t off = (uint64_t)b * a.block_size;
         const uint32_t len = (uint32_t)((a.n - off) < a.block_size ? (a.n - off) : a.block_size);
         const uint8_t *blk = a.in + off;
-        const uint2 *perm;
+        uint2 *out = a.rec + off;
         unsigned long long t_prev = a.dbg ? __builtin_amdgcn_s_memtime() : 0ull;
         const bool first = off == 0;
         partition_hist<2 * NBYTES>(blk, len, first, hist);
@@ -399,8 +405,7 @@ __global__ void __launch_bounds__(64) k_predict_wide(PredictArgs a) {
             partition_pass4<true>(blk, len, first, 1, 0, nullptr, perm_a, hist);
             __threadfence_block();
             W3_STAMP(1);
-            partition_pass4<false>(blk, len, first, 1, 4, perm_a, perm_b, hist + 16);
-            perm = perm_b;
+            partition_pass4<false>(blk, len, first, 1, 4, perm_a, out, hist + 16);
         } else {
             partition_pass4<true>(blk, len, first, 2, 0, nullptr, perm_a, hist);            // LSD: minor key c2 first
             __threadfence_block();
@@ -409,11 +414,53 @@ __global__ void __launch_bounds__(64) k_predict_wide(PredictArgs a) {
             __threadfence_block();
             partition_pass4<false>(blk, len, first, 1, 0, perm_b, perm_a, hist + 32);
             __threadfence_block();
-            partition_pass4<false>(blk, len, first, 1, 4, perm_a, perm_b, hist + 48);
-            perm = perm_b;
+            partition_pass4<false>(blk, len, first, 1, 4, perm_a, out, hist + 48);
         }
         __threadfence_block();
         W3_STAMP(2);
+        // slice boundaries: the first group start at or after s*len/W3_SLICES
+        uint32_t *sp = a.splits + (uint64_t)b * (W3_SLICES + 1u);
+        uint32_t prev = 0u;
+        if (lane == 0) { sp[0] = 0u; sp[W3_SLICES] = len; }
+        for (uint32_t sl = 1; sl < W3_SLICES; sl++) {
+            uint32_t start = max((uint32_t)((uint64_t)sl * len / W3_SLICES), prev), found = len;
+            for (uint32_t base = start; base < len; base += 64) {
+                const uint32_t e = base + lane;
+                bool head = false;
+                if (e < len) {
+                    const uint32_t g = NBYTES == 1 ? ((out[e].y >> 8) & 0xFFu) : ((out[e].y >> 8) & 0xFFFFu);
+                    const uint32_t gp = e ? (NBYTES == 1 ? ((out[e - 1].y >> 8) & 0xFFu) : ((out[e - 1].y >> 8) & 0xFFFFu)) : 0xFFFFFFFFu;
+                    head = g != gp;
+                }
+                const uint64_t hm = __ballot(head);
+                if (hm) { found = base + (uint32_t)(__ffsll((long long)hm) - 1); break; }
+            }
+            if (lane == 0) sp[sl] = found;
+            prev = found;
+        }
+        W3_STAMP(4);
+    }
+}
+
+// k_rank_sorted<NBYTES>: job = (block, slice).  A persistent grid of 2048 wavefronts walks the jobs in
+// block-major order, so only ~2048/W3_SLICES = 128 blocks are being scattered into at any time: their
+// P regions (1 MiB each) then stay in the 256 MiB Infinity Cache, where the eight partial 16-byte
+// writes every 128-byte line receives merge (3.2x cheaper than with 4096 blocks live; see
+// profiles/r1_ubench_partial_line_merge_vs_footprint.txt).
+template <int NBYTES>
+__global__ void __launch_bounds__(64) k_rank_sorted(PredictArgs a) {
+    __shared__ uint32_t tbl[8 * 256];
+    const int lane = threadIdx.x;
+    const uint32_t njobs = a.nblocks * W3_SLICES;
+    for (uint32_t job = blockIdx.x; job < njobs; job += gridDim.x) {
+        const uint32_t b = job / W3_SLICES, sl = job % W3_SLICES;
+        const uint64_t off = (uint64_t)b * a.block_size;
+        const uint32_t *sp = a.splits + (uint64_t)b * (W3_SLICES + 1u);
+        const uint32_t lo = sp[sl], hi = sp[sl + 1];
+        if (lo >= hi) continue;
+        const uint32_t len = hi - lo;
+        const uint2 *perm = a.rec + off + lo;
+        unsigned long long t_prev = a.dbg ? __builtin_amdgcn_s_memtime() : 0ull;
         // The table describes ONE group at a time: the group that is still open at the end of a round.
         // Groups that start and end inside a round never touch it (their Counters start new).
 #pragma unroll
@@ -471,7 +518,7 @@ __global__ void __launch_bounds__(64) k_predict_wide(PredictArgs a) {
             if (valid) a.P[off + i] = pack_p(p);  // 16-byte scatter, write-only
         }
         W3_STAMP(3);
-        if (a.dbg && lane == 0) atomicAdd(&a.dbg[7], 1ull);
+        if (a.dbg && lane == 0 && sl == 0) atomicAdd(&a.dbg[7], 1ull);
     }
 }
 

@@ -15,8 +15,8 @@
 #include "w3_spec.h"
 
 struct TwoPhaseWs {
-    void *P = nullptr, *keys = nullptr, *perm = nullptr, *redo = nullptr, *streams = nullptr;
-    size_t P_cap = 0, keys_cap = 0, perm_cap = 0, redo_cap = 0, streams_cap = 0;
+    void *P = nullptr, *keys = nullptr, *perm = nullptr, *redo = nullptr, *streams = nullptr, *rec = nullptr, *splits = nullptr;
+    size_t P_cap = 0, keys_cap = 0, perm_cap = 0, redo_cap = 0, streams_cap = 0, rec_cap = 0, splits_cap = 0;
     w3::MixArgs mix{};         // leaf streams of the last predict (sources of k_mix / k_coder_x3)
     bool P_valid = false;      // ws.P holds the merged stream of the last predict
     void *dbg = nullptr;       // 8 x u64 phase stamps of the last wide predict kernel (W3_OPT_DEBUG_STAMPS)
@@ -29,6 +29,9 @@ struct TwoPhaseWs {
         if (perm) (void)hipFree(perm);
         if (redo) (void)hipFree(redo);
         if (streams) (void)hipFree(streams);
+        if (rec) (void)hipFree(rec);
+        if (splits) (void)hipFree(splits);
+        rec = splits = nullptr; rec_cap = splits_cap = 0;
         if (dbg) (void)hipFree(dbg);
         dbg = nullptr;
         P = keys = perm = redo = streams = nullptr;
@@ -109,6 +112,8 @@ static inline int twophase_predict(TwoPhaseWs &ws, hipStream_t s, const ParsedSp
     }
     if (need_keys && (rc = tp_ensure(ws.keys, ws.keys_cap, n * 8, err))) return rc;
     if (need_perm && (rc = tp_ensure(ws.perm, ws.perm_cap, (size_t)grid_wide * 2 * block_size * 8, err))) return rc;
+    if (need_perm && (rc = tp_ensure(ws.rec, ws.rec_cap, n * 8, err))) return rc;
+    if (need_perm && (rc = tp_ensure(ws.splits, ws.splits_cap, (size_t)nb * (W3_SLICES + 1) * 4, err))) return rc;
 
     // FrozenModel leaves never adapt: p == 32768, distance 0.  They can never beat a trained leaf and tie
     // only when every leaf says 32768, so they matter only if ALL leaves are frozen.
@@ -156,8 +161,15 @@ static inline int twophase_predict(TwoPhaseWs &ws, hipStream_t s, const ParsedSp
                 if (!ws.dbg && hipMalloc(&ws.dbg, 64) != hipSuccess) ws.dbg = nullptr;
                 if (ws.dbg) { (void)hipMemsetAsync(ws.dbg, 0, 64, s); pa.dbg = (unsigned long long *)ws.dbg; }
             }
-            if (c == LEAF_WIDE1) hipLaunchKernelGGL(w3::k_predict_wide<1>, dim3(grid_wide), dim3(64), 0, s, pa);
-            else hipLaunchKernelGGL(w3::k_predict_wide<2>, dim3(grid_wide), dim3(64), 0, s, pa);
+            pa.rec = (uint2 *)ws.rec; pa.splits = (uint32_t *)ws.splits;
+            const uint32_t grid_rank = std::min<uint32_t>(nb * W3_SLICES, 2048u);   // ~128 blocks live: P regions stay in the Infinity Cache
+            if (c == LEAF_WIDE1) {
+                hipLaunchKernelGGL(w3::k_partition<1>, dim3(grid_wide), dim3(64), 0, s, pa);
+                hipLaunchKernelGGL(w3::k_rank_sorted<1>, dim3(grid_rank), dim3(64), 0, s, pa);
+            } else {
+                hipLaunchKernelGGL(w3::k_partition<2>, dim3(grid_wide), dim3(64), 0, s, pa);
+                hipLaunchKernelGGL(w3::k_rank_sorted<2>, dim3(grid_rank), dim3(64), 0, s, pa);
+            }
             bytes += n * 16 * (c == LEAF_WIDE1 ? 2 : 4);  // record passes: 8 B written + 8 B read each
         }
         hipError_t e = hipGetLastError();
