@@ -42,7 +42,9 @@ struct PredictArgs {
     uint32_t *perm;         // partition: per-wave scratch, 2 * block_size records
     uint2 *rec;             // [n] sorted records (position, window bytes) of every block
     uint32_t *splits;       // [nblocks][W3_SLICES + 1] slice boundaries inside each block's sorted range
+    uint32_t *job_counter;  // k_rank_sorted: next job (zeroed before the launch)
     uint32_t hbits;         // H = bits_in_context - 3
+    uint32_t dbg_flags;      // diagnostic: bit0 = skip the stream stores (timing experiments only)
     unsigned long long *dbg; // optional: per-phase s_memtime sums (diagnostic builds/runs only; never read by kernels)
 };
 
@@ -452,7 +454,13 @@ __global__ void __launch_bounds__(64) k_rank_sorted(PredictArgs a) {
     __shared__ uint32_t tbl[8 * 256];
     const int lane = threadIdx.x;
     const uint32_t njobs = a.nblocks * W3_SLICES;
-    for (uint32_t job = blockIdx.x; job < njobs; job += gridDim.x) {
+    // jobs are handed out in block-major order from one counter: slices are very uneven (a block's biggest
+    // group is one slice), and in-order hand-out keeps the set of blocks being scattered into small
+    for (;;) {
+        uint32_t job = 0;
+        if (lane == 0) job = atomicAdd(a.job_counter, 1u);
+        job = __builtin_amdgcn_readfirstlane(job);
+        if (job >= njobs) break;
         const uint32_t b = job / W3_SLICES, sl = job % W3_SLICES;
         const uint64_t off = (uint64_t)b * a.block_size;
         const uint32_t *sp = a.splits + (uint64_t)b * (W3_SLICES + 1u);
@@ -515,7 +523,7 @@ __global__ void __launch_bounds__(64) k_rank_sorted(PredictArgs a) {
             __builtin_amdgcn_wave_barrier();
             dirty = true;
             open_g = g_last;
-            if (valid) a.P[off + i] = pack_p(p);  // 16-byte scatter, write-only
+            if (valid && !(a.dbg_flags & 1u)) a.P[off + i] = pack_p(p);  // 16-byte scatter, write-only
         }
         W3_STAMP(3);
         if (a.dbg && lane == 0 && sl == 0) atomicAdd(&a.dbg[7], 1ull);

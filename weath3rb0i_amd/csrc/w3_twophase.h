@@ -8,6 +8,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstdlib>
 #include <string>
 
 #include "w3_coder.h"
@@ -113,7 +114,7 @@ static inline int twophase_predict(TwoPhaseWs &ws, hipStream_t s, const ParsedSp
     if (need_keys && (rc = tp_ensure(ws.keys, ws.keys_cap, n * 8, err))) return rc;
     if (need_perm && (rc = tp_ensure(ws.perm, ws.perm_cap, (size_t)grid_wide * 2 * block_size * 8, err))) return rc;
     if (need_perm && (rc = tp_ensure(ws.rec, ws.rec_cap, n * 8, err))) return rc;
-    if (need_perm && (rc = tp_ensure(ws.splits, ws.splits_cap, (size_t)nb * (W3_SLICES + 1) * 4, err))) return rc;
+    if (need_perm && (rc = tp_ensure(ws.splits, ws.splits_cap, (size_t)nb * (W3_SLICES + 1) * 4 + 64, err))) return rc;
 
     // FrozenModel leaves never adapt: p == 32768, distance 0.  They can never beat a trained leaf and tie
     // only when every leaf says 32768, so they matter only if ALL leaves are frozen.
@@ -162,7 +163,12 @@ static inline int twophase_predict(TwoPhaseWs &ws, hipStream_t s, const ParsedSp
                 if (ws.dbg) { (void)hipMemsetAsync(ws.dbg, 0, 64, s); pa.dbg = (unsigned long long *)ws.dbg; }
             }
             pa.rec = (uint2 *)ws.rec; pa.splits = (uint32_t *)ws.splits;
-            const uint32_t grid_rank = std::min<uint32_t>(nb * W3_SLICES, 2048u);   // ~128 blocks live: P regions stay in the Infinity Cache
+            pa.job_counter = (uint32_t *)ws.splits + (size_t)nb * (W3_SLICES + 1);   // lives behind the split table
+            (void)hipMemsetAsync(pa.job_counter, 0, 4, s);
+            if (getenv("W3_DEBUG_NOSTORE")) pa.dbg_flags = 1u;   // timing experiment: results are wrong
+            uint32_t rank_waves = 2048u;   // ~128 blocks live: P regions stay in the Infinity Cache
+            if (const char *ev_ = getenv("W3_RANK_GRID")) rank_waves = (uint32_t)std::max(64, atoi(ev_));   // tuning hook
+            const uint32_t grid_rank = std::min<uint32_t>(nb * W3_SLICES, rank_waves);
             if (c == LEAF_WIDE1) {
                 hipLaunchKernelGGL(w3::k_partition<1>, dim3(grid_wide), dim3(64), 0, s, pa);
                 hipLaunchKernelGGL(w3::k_rank_sorted<1>, dim3(grid_rank), dim3(64), 0, s, pa);
@@ -195,6 +201,7 @@ static inline int twophase_encode(TwoPhaseWs &ws, hipStream_t s, const ParsedSpe
     const bool x3 = ws.coder_mode == 0 && n_live <= 4;   // more leaves: merge with k_mix first, then k_coder_x2
     int rc = twophase_predict(ws, s, ps, d_in, n, block_size, nb, !x3, nullptr, ev, tm, err);
     if (rc) return rc;
+    if (getenv("W3_DEBUG_NOSTORE")) { err = "W3_DEBUG_NOSTORE: predict-only timing experiment"; return W3_E_UNSUPPORTED; }
     if ((rc = tp_ensure(ws.redo, ws.redo_cap, (size_t)nb * 4, err))) return rc;
     const uint32_t limit = std::min<uint32_t>(ws.acc_limit, 46u);
     if (ev) (void)hipEventRecord(ev[2], s);
