@@ -164,10 +164,17 @@ def main():
         ms_per_step = dt / args.steps * 1e3
         value = world * n * args.steps / dt / 2**20
         # dominant kernel: the lane-per-block coder (two-phase) or the fused generic kernel
+        traffic = None
         if path == 2:
             dom_ms = kern_ms["coder_ms"] / launches
             dom_bytes = coder_bytes / launches
-            dom_name = "k_coder"
+            dom_name = "k_coder_x3 (mix + recurrence + output wavefronts)"
+            try:  # PMC-measured HBM bytes of this kernel for this exact config (profiles/, separate rocprofv3 --pmc passes)
+                tj = json.load(open(os.path.join(ROOT, "profiles", "r1_traffic.json")))
+                if tj["config"] == {"model": args.model, "bytes_per_gpu": n, "block_size": bs}:
+                    traffic = tj["traffic_bytes_per_launch"]
+            except (OSError, KeyError, ValueError):
+                pass
         else:
             dom_ms = kern_ms["generic_ms"] / args.steps
             # A = 1 + c (stream write) + 64 B of Counter RMW per table model and input byte
@@ -186,7 +193,7 @@ def main():
                        "model": model_name, "path": {1: "generic", 2: "twophase"}.get(path, str(path)), "compressed_ratio": round(ratio, 4),
                        "exchange": "all_gather sizes + grouped send/recv to rank 0 (RCCL)" if world > 1 else "none (1 GPU)"},
             "roofline": {"bound": "hbm", "kernel": dom_name, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic,
                          "avg_launch_ms": round(dom_ms, 4), "algorithmic_bytes_per_launch": int(dom_bytes)},
             "kernel_ms_per_step": {k: round(v / args.steps, 3) for k, v in kern_ms.items()},
         }
