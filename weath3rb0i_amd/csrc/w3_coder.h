@@ -494,8 +494,10 @@ __global__ void __launch_bounds__(192) k_coder_x3(Coder3Args a) {
                     for (int j = 0; j < 8; j++) {
                         const uint32_t p32 = op[j].x, bitmask = op[j].y;
                         const uint32_t xmid = x1 + __umulhi(x2 - x1, p32);
-                        x1 = (x1 & bitmask) | ((xmid + 1u) & ~bitmask);
-                        x2 = (xmid & bitmask) | (x2 & ~bitmask);
+                        const uint32_t xmid1 = xmid + 1u;
+                        // v_bfi_b32: (mask & a) | (~mask & b).  hipcc turns the C form into v_cmp + 2 v_cndmask + s_nop.
+                        asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(x1) : "v"(bitmask), "v"(x1), "v"(xmid1));
+                        asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(x2) : "v"(bitmask), "v"(xmid), "v"(x2));
                         const uint32_t n = (uint32_t)__builtin_clz(x1 ^ x2);
                         const uint32_t u = ~(x1 & ~x2) & (0x7FFFFFFFu >> n);
                         const uint32_t c = (uint32_t)__builtin_clz(u);

@@ -134,12 +134,16 @@ __device__ __forceinline__ void rank_round(uint32_t c0, const uint32_t key[8], c
     const uint64_t gt = lane_gt_mask();
     const int lane = threadIdx.x & 63;
     wmask = 0u;
+    // the eight table reads are independent (one table per bit position): issue them together
+    uint32_t basev[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) basev[j] = tbl[j * 256 + key[j]];
 #pragma unroll
     for (int j = 0; j < 8; j++) {
         const uint64_t Mj = M[j] & seg;
         const uint32_t bit = (c0 >> (7 - j)) & 1u;
         const uint64_t ones = __ballot(bit) & Mj;
-        uint32_t base = tbl[j * 256 + key[j]];
+        uint32_t base = basev[j];
         if constexpr (GROUPED) base = rd ? base : 0u;
         const uint32_t b0 = base & 0xFFFFu, b1 = base >> 16;
         const uint32_t n1l = mbcnt64(ones), n0l = mbcnt64(Mj) - n1l;   // same-context lanes below me, by coded bit
@@ -166,13 +170,13 @@ __device__ __forceinline__ void rank_round(uint32_t c0, const uint32_t key[8], c
             satm &= satm - 1;
         }
         p[j] = counter_p(s0, s1);
-        if constexpr (GROUPED) {
-            fin[j] = f;
-            wmask |= last ? (1u << j) : 0u;
-        } else {
-            if (last) tbl[j * 256 + key[j]] = f;
-            __builtin_amdgcn_wave_barrier();
-        }
+        fin[j] = f;
+        wmask |= last ? (1u << j) : 0u;
+    }
+    if constexpr (!GROUPED) {
+#pragma unroll
+        for (int j = 0; j < 8; j++)
+            if ((wmask >> j) & 1u) tbl[j * 256 + key[j]] = fin[j];
     }
 }
 
