@@ -130,7 +130,10 @@ __device__ __forceinline__ uint32_t mbcnt64(uint64_t m) {  // bits of m below my
 //           fin[j] = state after the round, wmask bit j = this lane is the context's last lane.
 template <bool GROUPED>
 __device__ __forceinline__ void rank_round(uint32_t c0, const uint32_t key[8], const uint64_t M[8], uint64_t seg, bool valid, bool rd,
-                                           uint32_t *tbl, uint32_t p[8], uint32_t fin[8], uint32_t &wmask) {
+                                           volatile uint32_t *tbl, uint32_t p[8], uint32_t fin[8], uint32_t &wmask) {
+    // `tbl` is volatile: lanes communicate through it (one lane writes a context's state, others read it a
+    // round later).  To the compiler that is a data race, and with constant indices (H == 0) it forwarded each
+    // lane's own stale value instead of re-reading LDS.
     const uint64_t gt = lane_gt_mask();
     const int lane = threadIdx.x & 63;
     wmask = 0u;
@@ -287,7 +290,7 @@ __device__ __forceinline__ uint32_t wave_excl_scan_u32(uint32_t v, uint32_t *tot
 #define W3_PF 8   // rounds whose loads are in flight together in the short-round loops
 
 template <int NPASS>
-__device__ __forceinline__ void partition_hist(const uint8_t *blk, uint32_t len, bool first, uint32_t *hist) {
+__device__ __forceinline__ void partition_hist(const uint8_t *blk, uint32_t len, bool first, volatile uint32_t *hist) {
     const int lane = threadIdx.x & 63;
     const uint64_t gt = lane_gt_mask();
     if (lane < 16 * NPASS) hist[lane] = 0u;
@@ -344,7 +347,7 @@ __device__ __forceinline__ void partition_hist(const uint8_t *blk, uint32_t len,
 // no pass ever gathers from the input block again: with 4096 waves in flight the blocks do
 // not stay in L2 and every gathered byte cost a 64-byte fetch (212 GB of FETCH per GB input).
 template <bool FROM_INPUT>
-__device__ __forceinline__ void partition_pass4(const uint8_t *blk, uint32_t len, bool first, uint32_t back, uint32_t shift, const uint2 *src, uint2 *dst, uint32_t *bins) {
+__device__ __forceinline__ void partition_pass4(const uint8_t *blk, uint32_t len, bool first, uint32_t back, uint32_t shift, const uint2 *src, uint2 *dst, volatile uint32_t *bins) {
     const int lane = threadIdx.x & 63;
     const uint64_t gt = lane_gt_mask();
     const uint32_t last = len - 1u;
@@ -509,20 +512,21 @@ __global__ void __launch_bounds__(64) k_rank_sorted(PredictArgs a) {
 #pragma unroll
             for (int j = 0; j < 8; j++) key[j] = (w16 >> (8 - j)) & 0xFFu;
             match_windows<8>(w16, M);
-            rank_round<true>(c0, key, M, seg, valid, g == open_g, tbl, p, fin, wm);
+            volatile uint32_t *vt = tbl;
+            rank_round<true>(c0, key, M, seg, valid, g == open_g, vt, p, fin, wm);
             // the group of the round's last valid element stays open into the next round: its states go to the table
             const int lastlane = 63 - __clzll((long long)vm);
             const uint32_t g_last = readlane_u32(g, lastlane);
             if (g_last != open_g && dirty) {
 #pragma unroll
-                for (int k = 0; k < 32; k++) tbl[k * 64 + lane] = 0u;
+                for (int k = 0; k < 32; k++) vt[k * 64 + lane] = 0u;
                 dirty = false;
             }
             __builtin_amdgcn_wave_barrier();
             if (valid && g == g_last) {
 #pragma unroll
                 for (int j = 0; j < 8; j++)
-                    if ((wm >> j) & 1u) tbl[j * 256 + key[j]] = fin[j];
+                    if ((wm >> j) & 1u) vt[j * 256 + key[j]] = fin[j];
             }
             __builtin_amdgcn_wave_barrier();
             dirty = true;
