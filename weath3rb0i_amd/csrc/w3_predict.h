@@ -130,10 +130,12 @@ __device__ __forceinline__ uint32_t mbcnt64(uint64_t m) {  // bits of m below my
 //           fin[j] = state after the round, wmask bit j = this lane is the context's last lane.
 template <bool GROUPED>
 __device__ __forceinline__ void rank_round(uint32_t c0, const uint32_t key[8], const uint64_t M[8], uint64_t seg, bool valid, bool rd,
-                                           volatile uint32_t *tbl, uint32_t p[8], uint32_t fin[8], uint32_t &wmask) {
-    // `tbl` is volatile: lanes communicate through it (one lane writes a context's state, others read it a
-    // round later).  To the compiler that is a data race, and with constant indices (H == 0) it forwarded each
-    // lane's own stale value instead of re-reading LDS.
+                                           uint32_t *tbl, uint32_t p[8], uint32_t fin[8], uint32_t &wmask) {
+    // Lanes communicate through `tbl` (one lane writes a context's state, others read it a round later).  To the
+    // compiler that is a data race: with constant indices (H == 0) it forwarded each lane's own stale value
+    // instead of re-reading LDS.  A compiler-level memory barrier per round makes it re-load (volatile accesses
+    // also work but serialise the eight reads: +25 % kernel time).
+    __asm__ volatile("" ::: "memory");
     const uint64_t gt = lane_gt_mask();
     const int lane = threadIdx.x & 63;
     wmask = 0u;
@@ -180,6 +182,7 @@ __device__ __forceinline__ void rank_round(uint32_t c0, const uint32_t key[8], c
 #pragma unroll
         for (int j = 0; j < 8; j++)
             if ((wmask >> j) & 1u) tbl[j * 256 + key[j]] = fin[j];
+        __asm__ volatile("" ::: "memory");
     }
 }
 
@@ -290,7 +293,7 @@ __device__ __forceinline__ uint32_t wave_excl_scan_u32(uint32_t v, uint32_t *tot
 #define W3_PF 8   // rounds whose loads are in flight together in the short-round loops
 
 template <int NPASS>
-__device__ __forceinline__ void partition_hist(const uint8_t *blk, uint32_t len, bool first, volatile uint32_t *hist) {
+__device__ __forceinline__ void partition_hist(const uint8_t *blk, uint32_t len, bool first, uint32_t *hist) {
     const int lane = threadIdx.x & 63;
     const uint64_t gt = lane_gt_mask();
     if (lane < 16 * NPASS) hist[lane] = 0u;
@@ -326,7 +329,7 @@ __device__ __forceinline__ void partition_hist(const uint8_t *blk, uint32_t len,
                     m &= mybit ? B : ~B;
                 }
                 if (valid && (m & gt) == 0ull) hist[ps * 16 + d] += (uint32_t)__popcll(m);
-                __builtin_amdgcn_wave_barrier();
+                __asm__ volatile("" ::: "memory");
             }
         }
     }
@@ -347,7 +350,7 @@ __device__ __forceinline__ void partition_hist(const uint8_t *blk, uint32_t len,
 // no pass ever gathers from the input block again: with 4096 waves in flight the blocks do
 // not stay in L2 and every gathered byte cost a 64-byte fetch (212 GB of FETCH per GB input).
 template <bool FROM_INPUT>
-__device__ __forceinline__ void partition_pass4(const uint8_t *blk, uint32_t len, bool first, uint32_t back, uint32_t shift, const uint2 *src, uint2 *dst, volatile uint32_t *bins) {
+__device__ __forceinline__ void partition_pass4(const uint8_t *blk, uint32_t len, bool first, uint32_t back, uint32_t shift, const uint2 *src, uint2 *dst, uint32_t *bins) {
     const int lane = threadIdx.x & 63;
     const uint64_t gt = lane_gt_mask();
     const uint32_t last = len - 1u;
@@ -385,7 +388,7 @@ __device__ __forceinline__ void partition_pass4(const uint8_t *blk, uint32_t len
                 dst[bs + mbcnt64(m)] = rec;
                 if ((m & gt) == 0ull) bins[d] = bs + (uint32_t)__popcll(m);
             }
-            __builtin_amdgcn_wave_barrier();
+            __asm__ volatile("" ::: "memory");
         }
     }
 }
@@ -512,7 +515,7 @@ __global__ void __launch_bounds__(64) k_rank_sorted(PredictArgs a) {
 #pragma unroll
             for (int j = 0; j < 8; j++) key[j] = (w16 >> (8 - j)) & 0xFFu;
             match_windows<8>(w16, M);
-            volatile uint32_t *vt = tbl;
+            uint32_t *vt = tbl;
             rank_round<true>(c0, key, M, seg, valid, g == open_g, vt, p, fin, wm);
             // the group of the round's last valid element stays open into the next round: its states go to the table
             const int lastlane = 63 - __clzll((long long)vm);
@@ -528,6 +531,7 @@ __global__ void __launch_bounds__(64) k_rank_sorted(PredictArgs a) {
                 for (int j = 0; j < 8; j++)
                     if ((wm >> j) & 1u) vt[j * 256 + key[j]] = fin[j];
             }
+            __asm__ volatile("" ::: "memory");
             __builtin_amdgcn_wave_barrier();
             dirty = true;
             open_g = g_last;
