@@ -33,6 +33,10 @@ def make_model(w3, name):
                 "BestOfTwo(BestOfTwo(Order0,Order1),OrderN(27,3))")
     if name == "default":
         return w3.init_model(), "OrderNEntropy(11,3,ACHistory(8,book1))"
+    if name == "order012apm":  # BASELINE configs[1] with its "single APM mixer" (build-defined APM)
+        return w3.APM(make_model(w3, "order012")[0]), "APM(" + make_model(w3, "order012")[1] + ",order0 ctx,rate 7)"
+    if name == "fullcm":       # BASELINE configs[2]: Counter orders 0/1/2 + slot-state orders 1-4 + two APM stages
+        return w3.full_cm(), "APM(APM(BestOfTwo^6(Order0,Order1,OrderN(27,3),Slot1..4(2^14 cells)),o0,7),o1,6)"
     raise SystemExit("unknown --model " + name)
 
 
@@ -43,7 +47,19 @@ def make_oracle_model(orc, name):
         return orc.BestOfTwoModel(orc.Order0(), orc.Order1())
     if name == "order012":
         return orc.BestOfTwoModel(orc.BestOfTwoModel(orc.Order0(), orc.Order1()), orc.OrderN(27, 3))
+    if name == "order012apm":
+        return orc.APM(make_oracle_model(orc, "order012"))
+    if name == "fullcm":
+        m = make_oracle_model(orc, "order012")
+        for order in (1, 2, 3, 4):
+            m = orc.BestOfTwoModel(m, orc.SlotModel(order, 14))
+        return orc.APM(orc.APM(m, orc.APM_ORDER0, 7), orc.APM_ORDER1, 6)
     return orc.OrderNEntropy(11, 3, orc.ACHistory(8, orc.StationaryModel.for_book1()))
+
+
+# per input byte, (Counter leaves, slot-state leaves, APM stages) of each bench model
+MODEL_SHAPE = {"order0": (1, 0, 0), "order01": (2, 0, 0), "order012": (3, 0, 0), "default": (1, 0, 0), "order012apm": (3, 0, 1),
+               "fullcm": (3, 4, 2)}
 
 
 def cpu_baseline(name, sample, block_size, budget_s=15.0):
@@ -73,7 +89,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--model", default="order012", help="order0 | order01 | order012 | default")
+    ap.add_argument("--model", default="order012", help="order0 | order01 | order012 | default | order012apm | fullcm")
     ap.add_argument("--size", type=int, default=1_000_000_000, help="input bytes PER GPU (enwik9-class = 1e9)")
     ap.add_argument("--block-size", type=int, default=65536)
     ap.add_argument("--path", default="auto", help="auto | generic | twophase")
@@ -181,9 +197,10 @@ def main():
             dom_ms = kern_ms["generic_ms"] / args.steps
             # A = 1 + c (stream write) + 64 B of Counter RMW per table model and input byte
             from weath3rb0i_amd import _lib as L  # noqa: F401
-            nleaves = {"order0": 1, "order01": 2, "order012": 3, "default": 1}[args.model]
-            dom_bytes = n * (1 + ratio + 64 * nleaves)
-            dom_name = "k_generic"
+            # + 384 B per slot-state leaf (2 nibbles x 96-B cell read + write) + 48 B per APM stage (8 x (4 B read + 2 B write))
+            ncnt, nslot, napm = MODEL_SHAPE[args.model]
+            dom_bytes = n * (1 + ratio + 64 * ncnt + 384 * nslot + 48 * napm)
+            dom_name = "k_cm" if (nslot or napm) else "k_generic"
         achieved = dom_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
         res = {
             "metric": "encode MiB/s, 64 KiB blocks, bit-exact vs CPU ref",

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define W3_ABI_VERSION 1
+#define W3_ABI_VERSION 2
 
 /* ---- error codes --------------------------------------------------------- */
 enum {
@@ -50,11 +50,27 @@ enum {
  *                          (bijective re-indexing, bin/cmp/main.rs:14-24)
  *   node  W3_NODE_BEST_OF_TWO : BestOfTwoModel::new(a, b)        models/mod.rs:42-75
  *                          pops the two preceding subtrees (a pushed first).
+ *
+ * BUILD-DEFINED nodes (SURVEY §8 A19 ii-v: the reference ships the primitives but no model
+ * that uses them; README.md:6-10 lists "12-bit state table" and "APM mixers" as goals):
+ *   leaf  W3_NODE_SLOT_STATE : state-table CM leaf per docs/hashslots.md — context = the
+ *                          previous `bits` (= order, 0..7) bytes, hashed once per nibble into a
+ *                          HashMap of 2^log_cells Cells (hashmap.rs:1-71); each Slot holds the 15
+ *                          12-bit NaiveStateTable states of one nibble (hashmap.rs:73-129,
+ *                          state_table/naive.rs); P(1) = StateTable::p(state), update =
+ *                          StateTable::next.  Tag miss = the reference's TODO (hashmap.rs:64-68):
+ *                          least-observed slot is overwritten.
+ *   node  W3_NODE_APM       : adaptive probability map over stretch(p) ("APM mixers"): pops one
+ *                          subtree.  align = context kind (W3_APM_ORDER0: partial byte, 256 rows;
+ *                          W3_APM_ORDER1: partial byte | previous byte << 8, 65536 rows),
+ *                          max_bits = adaptation rate (1..15).  Only as a chain at the root.
  */
-enum { W3_NODE_ORDERN = 1, W3_NODE_BEST_OF_TWO = 2 };
+enum { W3_NODE_ORDERN = 1, W3_NODE_BEST_OF_TWO = 2, W3_NODE_SLOT_STATE = 3, W3_NODE_APM = 4 };
 enum { W3_HIST_NONE = 0, W3_HIST_RAW = 1, W3_HIST_AC = 2 };
+enum { W3_APM_ORDER0 = 0, W3_APM_ORDER1 = 1 };
 #define W3_MAX_NODES  31
 #define W3_MAX_LEAVES 16
+#define W3_MAX_APM    4
 
 typedef struct w3_node {
     uint8_t  kind;      /* W3_NODE_*                                  */
@@ -63,7 +79,8 @@ typedef struct w3_node {
     uint8_t  history;   /* W3_HIST_*                                  */
     uint8_t  max_bits;  /* ACHistory max_bits (0..32)                 */
     uint8_t  frozen;    /* 1 = FrozenModel wrapper                    */
-    uint8_t  reserved[2];
+    uint8_t  log_cells; /* SLOT_STATE: HashMap log_cell_count (1..24) */
+    uint8_t  reserved;
     uint16_t table[8];  /* StationaryModel table, index 0 = MSB       */
 } w3_node;
 
@@ -146,6 +163,15 @@ int w3_predict_blocks(w3_ctx *ctx, const w3_model_spec *spec,
  * Host-side table preparation for ACHistory: 8 Counters by bit position walked
  * over `buf`, table[i] = p().  Model construction, not the hot path.          */
 int w3_stationary_table(const uint8_t *buf, size_t n, uint16_t table[8]);
+
+/* ---- read-only tables of the CM kernels (host-side; for known-answer tests) -----------
+ * w3_state_table: NaiveStateTable (state_table/naive.rs:7-115) as 3963 rows of
+ * {prob, next[0], next[1]} — the rows of docs/state_table/state_table.csv.
+ * w3_stretch_squash: the build-defined logistic pair, stretch[4096] (index p>>4) and
+ * squash[4095] (index d+2047).                                                          */
+#define W3_STATE_TABLE_SIZE 3963
+int w3_state_table(uint16_t *out /* [3963*3] */);
+int w3_stretch_squash(int16_t *stretch /* [4096] */, uint16_t *squash /* [4095] */);
 
 /* ---- device self-test ---------------------------------------------------------
  * Exhaustively compares the kernels' division-free Counter::p with the literal

@@ -72,6 +72,18 @@ def _load():
     lib.w3o_slot_set_state.argtypes = [vp, C.c_uint8, C.c_uint8, C.c_uint8, C.c_uint16]
     lib.w3o_slot_get_nib.argtypes = [vp, C.c_uint8, C.c_uint8, vp]
     lib.w3o_slot_set_nib.argtypes = [vp, C.c_uint8, C.c_uint8, vp]
+    lib.w3o_slot_model.restype = vp
+    lib.w3o_slot_model.argtypes = [C.c_uint8, C.c_uint8]
+    lib.w3o_apm.restype = vp
+    lib.w3o_apm.argtypes = [vp, C.c_uint8, C.c_uint8]
+    lib.w3o_squash.restype = C.c_uint16
+    lib.w3o_squash.argtypes = [C.c_int]
+    lib.w3o_stretch.restype = C.c_int
+    lib.w3o_stretch.argtypes = [C.c_uint16]
+    lib.w3o_slot_hash.restype = C.c_uint64
+    lib.w3o_slot_hash.argtypes = [C.c_uint8, C.c_uint64, C.c_int, C.c_uint32]
+    lib.w3o_st_conf.restype = C.c_uint8
+    lib.w3o_st_conf.argtypes = [C.c_uint16]
     lib.free = C.CDLL(None).free
     lib.free.argtypes = [vp]
     return lib
@@ -300,6 +312,36 @@ def FrozenModel(model):
 
 def BestOfTwoModel(m1, m2):
     return Model(lib.w3o_best_of_two(m1._take(), m2._take()))
+
+
+# ---- build-defined models (SURVEY §8 A19 ii-v) -----------------
+APM_ORDER0, APM_ORDER1 = 0, 1
+
+
+def SlotModel(order, log_cells):
+    assert 0 <= order <= 7 and 1 <= log_cells <= 24
+    return Model(lib.w3o_slot_model(order, log_cells))
+
+
+def APM(model, ctx=APM_ORDER0, rate=7):
+    assert ctx in (0, 1) and 1 <= rate <= 15
+    return Model(lib.w3o_apm(model._take(), ctx, rate))
+
+
+def squash(d):
+    return lib.w3o_squash(d)
+
+
+def stretch(p):
+    return lib.w3o_stretch(p)
+
+
+def slot_hash(order, hist_bytes, second, hi_nib):
+    return lib.w3o_slot_hash(order, hist_bytes, int(second), hi_nib)
+
+
+def st_conf(state):
+    return lib.w3o_st_conf(state)
 
 
 def opinion_mix(p1, p2):

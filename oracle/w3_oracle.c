@@ -286,7 +286,7 @@ uint32_t w3o_history_hash(w3o_history *h) {
 /* Models                                                              */
 /* ================================================================== */
 
-enum { M_ORDER0, M_ORDER1, M_ORDERN, M_ORDERN_ENTROPY, M_FROZEN, M_BEST2 };
+enum { M_ORDER0, M_ORDER1, M_ORDERN, M_ORDERN_ENTROPY, M_FROZEN, M_BEST2, M_SLOT, M_APM };
 
 struct w3o_model {
     int kind;
@@ -299,6 +299,12 @@ struct w3o_model {
     uint32_t *dirty; size_t ndirty, dirty_cap;
     /* composites */
     w3o_model *a, *b;
+    /* M_SLOT (build-defined): byte history, current cell/slot, position inside the nibble */
+    uint8_t order, log_cells, slot_id, bit_id, nib_ctx;
+    uint64_t hist_bytes; uint32_t c0;
+    w3o_cell *cells, *cur;
+    /* M_APM (build-defined) */
+    uint16_t *apm_t; uint32_t apm_rows; uint8_t apm_ctx, apm_rate; uint32_t apm_c0, apm_c1;
 };
 
 #define DIRTY_THRESHOLD ((size_t)1 << 16)
@@ -332,17 +338,27 @@ w3o_model *w3o_best_of_two(w3o_model *m1, w3o_model *m2) { /* mod.rs:57-60 */
     m->kind = M_BEST2; m->a = m1; m->b = m2;
     return m;
 }
+static void slot_reset(w3o_model *m);
+static void slot_update(w3o_model *m, uint8_t bit);
+static void apm_reset(w3o_model *m);
+static void apm_update(w3o_model *m, uint8_t bit);
+static uint16_t apm_pp(const w3o_model *m, uint16_t p, uint32_t *idx);
+
 w3o_model *w3o_model_clone_fresh(const w3o_model *m) {
     switch (m->kind) {
     case M_FROZEN: return w3o_frozen(w3o_model_clone_fresh(m->a));
     case M_BEST2:  return w3o_best_of_two(w3o_model_clone_fresh(m->a), w3o_model_clone_fresh(m->b));
     case M_ORDERN_ENTROPY: return w3o_ordern_entropy(m->bits, m->align_bits, &m->hist0);
+    case M_SLOT: return w3o_slot_model(m->order, m->log_cells);
+    case M_APM:  return w3o_apm(w3o_model_clone_fresh(m->a), m->apm_ctx, m->apm_rate);
     default: return leaf_new(m->kind, m->bits, m->align_bits);
     }
 }
 void w3o_model_reset(w3o_model *m) {
     if (m->kind == M_FROZEN) { w3o_model_reset(m->a); return; }
     if (m->kind == M_BEST2) { w3o_model_reset(m->a); w3o_model_reset(m->b); return; }
+    if (m->kind == M_SLOT) { slot_reset(m); return; }
+    if (m->kind == M_APM) { w3o_model_reset(m->a); apm_reset(m); return; }
     if (m->dirty) {
         for (size_t i = 0; i < m->ndirty; i++) { m->stats[m->dirty[i]].data[0] = 0; m->stats[m->dirty[i]].data[1] = 0; }
         m->ndirty = 0;
@@ -355,7 +371,7 @@ void w3o_model_reset(w3o_model *m) {
 void w3o_model_free(w3o_model *m) {
     if (!m) return;
     w3o_model_free(m->a); w3o_model_free(m->b);
-    free(m->stats); free(m->dirty); free(m);
+    free(m->stats); free(m->dirty); free(m->cells); free(m->apm_t); free(m);
 }
 
 uint16_t w3o_opinion_mix(uint16_t p1, uint16_t p2) { /* opinion_mixer2.rs:5-10 */
@@ -369,6 +385,8 @@ uint16_t w3o_model_predict(const w3o_model *m) {
     switch (m->kind) {
     case M_FROZEN: return w3o_model_predict(m->a);                          /* frozen.rs:14-16 */
     case M_BEST2:  return w3o_opinion_mix(w3o_model_predict(m->a), w3o_model_predict(m->b)); /* mod.rs:67-69 */
+    case M_SLOT:   return w3o_st_p(w3o_slot_get_state(m->cur, m->slot_id, m->bit_id, m->nib_ctx));
+    case M_APM:    { uint32_t idx; return apm_pp(m, w3o_model_predict(m->a), &idx); }
     default:       return w3o_counter_p(&m->stats[m->ctx]);                 /* order0.rs:22-24 etc. */
     }
 }
@@ -427,6 +445,8 @@ void w3o_model_update(w3o_model *m, uint8_t bit) {
     switch (m->kind) {
     case M_FROZEN: leaf_advance(m->a, bit); break;                               /* frozen.rs:18-20 */
     case M_BEST2:  w3o_model_update(m->a, bit); w3o_model_update(m->b, bit); break; /* mod.rs:71-74 */
+    case M_SLOT:   slot_update(m, bit); break;
+    case M_APM:    apm_update(m, bit); break;
     default:       leaf_adapt(m, bit); leaf_advance(m, bit); break;              /* mod.rs:28-31 */
     }
 }
@@ -713,4 +733,167 @@ void w3o_slot_get_nib(const w3o_cell *c, uint8_t id, uint8_t nib, uint16_t out[4
     out[1] = w3o_slot_get_state(c, id, 1, nib >> 3);
     out[2] = w3o_slot_get_state(c, id, 2, nib >> 2);
     out[3] = w3o_slot_get_state(c, id, 3, nib >> 1);
+}
+
+/* ================================================================== */
+/* BUILD-DEFINED models (SURVEY §8 A19 ii-v).  The reference has the    */
+/* primitives (state table, Cell/Slot) but no model that uses them, no  */
+/* replacement policy, no APM; these definitions are this build's own,  */
+/* integer-only, and "parity unpinned" (DESIGN.md §2.4).                */
+/* ================================================================== */
+
+/* observation-count proxy of a state: 0 for the root, 1 for states 1/2, level+1 inside a lattice copy
+ * (naive.rs:19-27,52-77: level L holds the nodes reached after L-1 lattice steps) */
+static uint8_t g_conf[W3O_ST_SIZE];
+static pthread_once_t g_conf_once = PTHREAD_ONCE_INIT;
+static void conf_build(void) {
+    g_conf[0] = 0; g_conf[1] = 1; g_conf[2] = 1;
+    size_t filled = 0;
+    for (size_t level = 1; level <= MAX_LEVEL; level++) {
+        for (size_t node = 0; node < level; node++)
+            for (int copy = 0; copy < 4; copy++) g_conf[3 + copy * W3O_ST_AUX + filled + node] = (uint8_t)(level + 1);
+        filled += level;
+    }
+}
+uint8_t w3o_st_conf(uint16_t state) { pthread_once(&g_conf_once, conf_build); return g_conf[state]; }
+
+/* splitmix64 finaliser over (order, previous `order` bytes, nibble marker) */
+uint64_t w3o_slot_hash(uint8_t order, uint64_t hist_bytes, int second, uint32_t hi_nib) {
+    uint64_t k = order ? (hist_bytes & ((1ull << (8 * order)) - 1ull)) : 0;   /* order <= 7 */
+    k = (k << 8) | (second ? (0x10u | hi_nib) : 0u);
+    k += (uint64_t)(order + 1) * 0x9E3779B97F4A7C15ull;
+    k ^= k >> 30; k *= 0xBF58476D1CE4E5B9ull;
+    k ^= k >> 27; k *= 0x94D049BB133111EBull;
+    k ^= k >> 31;
+    return k;
+}
+
+static uint32_t cell_tag(const w3o_cell *c, int id) { /* hashmap.rs:43-63: id 3 = lowest 12 bits of the BE concat */
+    uint64_t hc = 0;
+    for (int i = 0; i < 6; i++) hc = (hc << 8) | c->hashes[i];
+    return (uint32_t)((hc >> (12 * (3 - id))) & 0xFFF);
+}
+static void cell_set_tag(w3o_cell *c, int id, uint32_t tag) {
+    uint64_t hc = 0;
+    for (int i = 0; i < 6; i++) hc = (hc << 8) | c->hashes[i];
+    int sh = 12 * (3 - id);
+    hc = (hc & ~(0xFFFull << sh)) | ((uint64_t)tag << sh);
+    for (int i = 5; i >= 0; i--) { c->hashes[i] = (uint8_t)hc; hc >>= 8; }
+}
+
+/* Locate the slot of a nibble context.  Hit: Cell::get_slot (hashmap.rs:42-63).  Miss: the policy the
+ * reference leaves as "TODO: Select min and set new hash" (hashmap.rs:64-68) — the victim is the slot whose
+ * first-bit state has the fewest observations (candidates in the order 1,0,2,3, so an empty cell gives the
+ * PoC's slot 1, hashslots.md:24), its tag is set and its 15 states are cleared. */
+static void slot_select(w3o_model *m, int second, uint32_t hi_nib) {
+    uint64_t h = w3o_slot_hash(m->order, m->hist_bytes, second, hi_nib);
+    w3o_cell *c = &m->cells[w3o_hashmap_cell_index(h, m->log_cells)];
+    uint32_t tag = (uint32_t)(h & 0xFFF);
+    int id = -1;
+    for (int k = 3; k >= 0; k--) if (cell_tag(c, k) == tag) { id = k; break; }
+    if (id < 0) {
+        static const int cand[4] = {1, 0, 2, 3};
+        int best = 256;
+        for (int k = 0; k < 4; k++) {
+            int conf = w3o_st_conf(w3o_slot_get_state(c, (uint8_t)cand[k], 0, 0));
+            if (conf < best) { best = conf; id = cand[k]; }
+        }
+        cell_set_tag(c, id, tag);
+        for (int bit_id = 0; bit_id < 4; bit_id++)
+            for (int ctx = 0; ctx < (1 << bit_id); ctx++) w3o_slot_set_state(c, (uint8_t)id, (uint8_t)bit_id, (uint8_t)ctx, 0);
+    }
+    m->cur = c; m->slot_id = (uint8_t)id; m->bit_id = 0; m->nib_ctx = 0;
+}
+
+static void slot_reset(w3o_model *m) {
+    memset(m->cells, 0, sizeof(w3o_cell) << m->log_cells);
+    m->hist_bytes = 0; m->c0 = 1;
+    slot_select(m, 0, 0);
+}
+
+w3o_model *w3o_slot_model(uint8_t order, uint8_t log_cells) {
+    w3o_model *m = (w3o_model *)calloc(1, sizeof *m);
+    m->kind = M_SLOT; m->order = order; m->log_cells = log_cells;
+    m->cells = (w3o_cell *)malloc(sizeof(w3o_cell) << log_cells);
+    slot_reset(m);
+    return m;
+}
+
+static void slot_update(w3o_model *m, uint8_t bit) {
+    uint16_t st = w3o_slot_get_state(m->cur, m->slot_id, m->bit_id, m->nib_ctx);
+    w3o_slot_set_state(m->cur, m->slot_id, m->bit_id, m->nib_ctx, w3o_st_next(st, bit));   /* adapt */
+    m->c0 = (m->c0 << 1) | bit;                                                             /* advance */
+    m->nib_ctx = (uint8_t)((m->nib_ctx << 1) | bit);
+    m->bit_id++;
+    if (m->bit_id == 4) {
+        if (m->c0 >= 256) { m->hist_bytes = (m->hist_bytes << 8) | (m->c0 & 0xFF); m->c0 = 1; slot_select(m, 0, 0); }
+        else slot_select(m, 1, m->c0 & 15);
+    }
+}
+
+/* ---- stretch / squash: integer-only logistic in units of 1/256 nat ------------------------------- */
+static uint16_t g_squash[4095];   /* index d + 2047 */
+static int16_t  g_stretch[4096];  /* index p >> 4    */
+static pthread_once_t g_ss_once = PTHREAD_ONCE_INIT;
+static void ss_build(void) {
+    const uint64_t K = 0xFF007FD5ull;            /* round(2^32 * e^(-1/256)) */
+    uint64_t e = 1ull << 32;                     /* e^(-d/256) in Q32 */
+    for (int d = 0; d <= 2047; d++) {
+        uint64_t den = (1ull << 32) + e;
+        uint64_t q = ((1ull << 48) + den / 2) / den;
+        if (q > 65535) q = 65535;
+        g_squash[2047 + d] = (uint16_t)q;
+        uint64_t lo = 65536 - q;
+        g_squash[2047 - d] = (uint16_t)(lo < 1 ? 1 : lo);
+        e = (e * K) >> 32;
+    }
+    g_squash[2047] = 32768;
+    int d = -2047;
+    for (int q = 0; q < 4096; q++) {             /* smallest d with squash(d) >= 16 q + 8 */
+        uint32_t want = (uint32_t)q * 16 + 8;
+        while (d < 2047 && g_squash[d + 2047] < want) d++;
+        g_stretch[q] = (int16_t)d;
+    }
+}
+uint16_t w3o_squash(int d) {
+    pthread_once(&g_ss_once, ss_build);
+    if (d < -2047) d = -2047;
+    if (d > 2047) d = 2047;
+    return g_squash[d + 2047];
+}
+int w3o_stretch(uint16_t p) { pthread_once(&g_ss_once, ss_build); return g_stretch[p >> 4]; }
+
+/* ---- APM ------------------------------------------------------------------------------------------ */
+static void apm_reset(w3o_model *m) {
+    for (uint32_t r = 0; r < m->apm_rows; r++)
+        for (int j = 0; j < 33; j++) m->apm_t[r * 33 + j] = w3o_squash((j - 16) * 128);
+    m->apm_c0 = 1; m->apm_c1 = 0;
+}
+w3o_model *w3o_apm(w3o_model *input, uint8_t ctx_kind, uint8_t rate) {
+    w3o_model *m = (w3o_model *)calloc(1, sizeof *m);
+    m->kind = M_APM; m->a = input; m->apm_ctx = ctx_kind; m->apm_rate = rate;
+    m->apm_rows = ctx_kind == W3O_APM_ORDER1 ? 65536u : 256u;
+    m->apm_t = (uint16_t *)malloc((size_t)m->apm_rows * 33 * sizeof(uint16_t));
+    apm_reset(m);
+    return m;
+}
+static uint16_t apm_pp(const w3o_model *m, uint16_t p, uint32_t *idx) {
+    uint32_t row = m->apm_ctx == W3O_APM_ORDER1 ? (m->apm_c0 | (m->apm_c1 << 8)) : m->apm_c0;
+    uint32_t pos = (uint32_t)(w3o_stretch(p) + 2048) * 32u;
+    uint32_t j = pos >> 12, w = pos & 4095u;
+    const uint16_t *t = m->apm_t + row * 33u;
+    uint32_t pa = ((uint32_t)t[j] * (4096u - w) + (uint32_t)t[j + 1] * w) >> 12;
+    *idx = row * 33u + j + (w >> 11);
+    uint32_t out = ((uint32_t)p + 3u * pa + 2u) >> 2;
+    return (uint16_t)(out < 1 ? 1 : out > 65535 ? 65535 : out);
+}
+static void apm_update(w3o_model *m, uint8_t bit) {
+    uint32_t idx;
+    (void)apm_pp(m, w3o_model_predict(m->a), &idx);     /* the input's prediction for THIS step (before its update) */
+    int32_t t = m->apm_t[idx], target = bit ? 65535 : 0, delta = target - t;
+    int32_t step = delta >= 0 ? (delta >> m->apm_rate) : -((-delta + (1 << m->apm_rate) - 1) >> m->apm_rate);  /* floor */
+    m->apm_t[idx] = (uint16_t)(t + step);
+    w3o_model_update(m->a, bit);
+    m->apm_c0 = (m->apm_c0 << 1) | bit;
+    if (m->apm_c0 >= 256) { m->apm_c1 = m->apm_c0 & 0xFF; m->apm_c0 = 1; }
 }

@@ -103,6 +103,18 @@ w3o_model *w3o_ordern(uint8_t bits, uint8_t align);            /* models/ordern.
 w3o_model *w3o_ordern_entropy(uint8_t bits, uint8_t align, const w3o_history *h); /* models/ordern_entropy.rs */
 w3o_model *w3o_frozen(w3o_model *adaptive);                    /* models/frozen.rs  (takes ownership) */
 w3o_model *w3o_best_of_two(w3o_model *m1, w3o_model *m2);      /* models/mod.rs:42-75 (takes ownership) */
+/* ---- BUILD-DEFINED models (SURVEY §8 A19 ii-v; no reference counterpart, "parity unpinned") ----
+ * w3o_slot_model: the state-table CM leaf hashslots.md describes, wiring NaiveStateTable (A15)
+ *   to the Cell/Slot hashmap (A16): one cell touch per nibble, 15 12-bit states per slot.
+ * w3o_apm: adaptive probability map over stretch(p) with 33 interpolated buckets per row
+ *   ("APM mixers", README.md:10).  See DESIGN.md §2.4 for the integer definitions. */
+w3o_model *w3o_slot_model(uint8_t order, uint8_t log_cells);
+enum { W3O_APM_ORDER0 = 0, W3O_APM_ORDER1 = 1 };
+w3o_model *w3o_apm(w3o_model *input, uint8_t ctx_kind, uint8_t rate);   /* takes ownership */
+uint16_t   w3o_squash(int d);            /* d in [-2047,2047] -> P(1)*2^16 in [1,65535] */
+int        w3o_stretch(uint16_t p);      /* inverse on p>>4, in [-2047,2047]            */
+uint64_t   w3o_slot_hash(uint8_t order, uint64_t hist_bytes, int second, uint32_t hi_nib);
+uint8_t    w3o_st_conf(uint16_t state);  /* observation count proxy used by the slot replacement policy */
 w3o_model *w3o_model_clone_fresh(const w3o_model *m);          /* same structure, initial state */
 void       w3o_model_reset(w3o_model *m);
 void       w3o_model_free(w3o_model *m);

@@ -1,0 +1,126 @@
+"""GPU parity of the CM path (slot-state leaves, APM chain; k_cm and its encoder fast paths) against the CPU
+oracle, byte for byte, through the C ABI.  The models are BUILD-DEFINED: the oracle here is
+this build's own restatement, pinned by the committed digests in tests/golden/cm_streams.json."""
+import hashlib
+import json
+
+import numpy as np
+import pytest
+
+import weath3rb0i_amd as w3
+from tests.synth import lcg_text, markov_text, mixed_bytes
+from tests.test_cm_cpu import GOLDEN, golden_inputs
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = w3.Context(0)
+    yield c
+    c.close()
+
+
+def o012(m):
+    return m.BestOfTwoModel(m.BestOfTwoModel(m.Order0(), m.Order1()), m.OrderN(27, 3))
+
+
+def full(m, slot, log_cells=14):
+    t = o012(m)
+    for order in (1, 2, 3, 4):
+        t = m.BestOfTwoModel(t, slot(order, log_cells))
+    return m.APM(m.APM(t, 0, 7), 1, 6)
+
+
+def pair(oracle, name):
+    o = oracle
+    table = {
+        "slot0": (lambda: w3.SlotModel(0, 4), lambda: o.SlotModel(0, 4)),
+        "slot1": (lambda: w3.SlotModel(1, 10), lambda: o.SlotModel(1, 10)),
+        "slot2": (lambda: w3.SlotModel(2, 12), lambda: o.SlotModel(2, 12)),
+        "slot3_tiny_table": (lambda: w3.SlotModel(3, 1), lambda: o.SlotModel(3, 1)),     # constant eviction
+        "slot7": (lambda: w3.SlotModel(7, 14), lambda: o.SlotModel(7, 14)),
+        "slot2_hashmap_sized": (lambda: w3.SlotModel(2, w3.HashMap.new(1 << 20)), lambda: o.SlotModel(2, 13)),
+        "apm0_order0": (lambda: w3.APM(w3.Order0()), lambda: o.APM(o.Order0())),
+        "apm1_order0_r3": (lambda: w3.APM(w3.Order0(), w3.APM.ORDER1, 3), lambda: o.APM(o.Order0(), o.APM_ORDER1, 3)),
+        "apm_rate15": (lambda: w3.APM(w3.Order1(), 0, 15), lambda: o.APM(o.Order1(), 0, 15)),
+        "apm_rate1": (lambda: w3.APM(w3.Order1(), 0, 1), lambda: o.APM(o.Order1(), 0, 1)),
+        "o012_apm": (lambda: w3.APM(o012(w3)), lambda: o.APM(o012(o))),
+        "apm_chain4": (lambda: w3.APM(w3.APM(w3.APM(w3.APM(w3.Order0(), 0, 7), 1, 6), 0, 5), 1, 4),
+                       lambda: o.APM(o.APM(o.APM(o.APM(o.Order0(), 0, 7), 1, 6), 0, 5), 1, 4)),
+        "slot_mix": (lambda: w3.BestOfTwoModel(w3.SlotModel(2, 12), w3.BestOfTwoModel(w3.Order0(), w3.SlotModel(1, 12))),
+                     lambda: o.BestOfTwoModel(o.SlotModel(2, 12), o.BestOfTwoModel(o.Order0(), o.SlotModel(1, 12)))),
+        "apm_frozen": (lambda: w3.APM(w3.FrozenModel(w3.Order0())), lambda: o.APM(o.FrozenModel(o.Order0()))),
+        "apm_main_default": (lambda: w3.APM(w3.init_model()),
+                             lambda: o.APM(o.OrderNEntropy(11, 3, o.ACHistory(8, o.StationaryModel.for_book1())))),
+        "full_cm": (lambda: w3.full_cm(), lambda: full(o, o.SlotModel)),
+        "full_cm_small_tables": (lambda: full(w3, w3.SlotModel, 8), lambda: full(o, o.SlotModel, 8)),
+    }
+    return table[name]
+
+
+NAMES = ["slot0", "slot1", "slot2", "slot3_tiny_table", "slot7", "slot2_hashmap_sized", "apm0_order0", "apm1_order0_r3", "apm_rate15",
+         "apm_rate1", "o012_apm", "apm_chain4", "slot_mix", "apm_frozen", "apm_main_default", "full_cm", "full_cm_small_tables"]
+
+
+def check(ctx, oracle, name, data, bs, decode=True):
+    dev, orc = pair(oracle, name)
+    out, lens = ctx.encode_blocks(dev(), data, bs)
+    want, wlens = oracle.encode_blocks(orc(), data, bs, nthreads=8)
+    assert lens.tolist() == wlens.tolist(), name
+    assert out.tobytes() == want.tobytes(), name
+    if decode:
+        assert ctx.decode_blocks(dev(), out, lens, bs, len(data)).tobytes() == bytes(data), name
+    return out, lens
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_cm_models_encode_decode(ctx, oracle, name):
+    data = markov_text(30000, seed=41) + lcg_text(6000, seed=4) + bytes(700) + mixed_bytes(5000, seed=6)
+    check(ctx, oracle, name, data, 8192)
+
+
+def test_cm_golden_digests_on_device(ctx):
+    """The committed digests (tests/golden/cm_streams.json) straight from the device: no oracle in the loop."""
+    want = json.load(open(GOLDEN))
+    models = {"slot2": lambda: w3.SlotModel(2, 12), "apm0_order0": lambda: w3.APM(w3.Order0()), "o012_apm": lambda: w3.APM(o012(w3)),
+              "full_cm": lambda: w3.full_cm()}
+    for iname, data in golden_inputs().items():
+        for mname, mk in models.items():
+            out, lens = ctx.encode_blocks(mk(), data, len(data))
+            assert [len(out), hashlib.sha256(out.tobytes()).hexdigest()] == want[iname][mname], (iname, mname)
+
+
+def test_cm_edge_blocks(ctx, oracle):
+    cases = {
+        "zeros64k": (bytes(65536), 65536), "ones64k": (b"\xff" * 65536, 65536), "alt55": (b"\x55" * 5000, 4096), "single": (b"A", 4096),
+        "two": (b"AB", 1), "bs_plus_1": (lcg_text(4097, seed=5), 4096), "bs_minus_1": (lcg_text(4095, seed=6), 4096),
+        "ragged": (lcg_text(3 * 4096 + 17, seed=7), 4096),
+        "random": (np.random.default_rng(1).integers(0, 256, 20000, dtype=np.uint8).tobytes(), 4096),
+        "lanes_65": (markov_text(65 * 512, seed=8), 512),           # more than one wavefront, last one ragged
+    }
+    for cname, (data, bs) in cases.items():
+        for name in ("slot2", "o012_apm", "full_cm_small_tables"):
+            check(ctx, oracle, name, data, bs)
+    out, lens = ctx.encode_blocks(w3.full_cm(), b"", 4096)
+    assert len(out) == 0 and len(lens) == 0
+
+
+def test_cm_256k_blocks_mixed(ctx, oracle):
+    """BASELINE configs[4] shape: mixed text/binary, 256 KiB blocks (hash-map stress: 2^19 nibble contexts per leaf)."""
+    data = mixed_bytes(600000, seed=5)
+    check(ctx, oracle, "full_cm", data, 262144)
+
+
+def test_cm_full_block_64k(ctx, oracle):
+    data = markov_text(3 * 65536 + 1000, seed=77)
+    check(ctx, oracle, "full_cm", data, 65536)
+    check(ctx, oracle, "o012_apm", data, 65536)
+
+
+def test_cm_reference_container(ctx, oracle):
+    """w30i + length + ONE stream (main.rs:89-144) with a CM model."""
+    d = markov_text(20000, seed=3)
+    got = ctx.compress(d, w3.full_cm())
+    assert got == oracle.compress(full(oracle, oracle.SlotModel), d)
+    assert ctx.decompress(got, w3.full_cm()) == d

@@ -7,7 +7,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 SO = os.path.join(HERE, "libw3hip.so")
 
 W3_MAX_NODES = 31
-W3_NODE_ORDERN, W3_NODE_BEST_OF_TWO = 1, 2
+W3_NODE_ORDERN, W3_NODE_BEST_OF_TWO, W3_NODE_SLOT_STATE, W3_NODE_APM = 1, 2, 3, 4
+W3_APM_ORDER0, W3_APM_ORDER1 = 0, 1
+W3_MAX_APM = 4
 W3_HIST_NONE, W3_HIST_RAW, W3_HIST_AC = 0, 1, 2
 W3_OK, W3_E_INVALID, W3_E_NOSPACE, W3_E_HIP, W3_E_UNSUPPORTED, W3_E_NOMEM, W3_E_FORMAT = 0, -1, -2, -3, -4, -5, -6
 W3_OPT_PATH, W3_OPT_TIMING, W3_OPT_CODER, W3_OPT_ACC_LIMIT, W3_OPT_DEBUG_STAMPS = 1, 2, 3, 4, 5
@@ -16,7 +18,7 @@ W3_PATH_AUTO, W3_PATH_GENERIC, W3_PATH_TWOPHASE = 0, 1, 2
 
 class Node(C.Structure):
     _fields_ = [("kind", C.c_uint8), ("bits", C.c_uint8), ("align", C.c_uint8), ("history", C.c_uint8),
-                ("max_bits", C.c_uint8), ("frozen", C.c_uint8), ("reserved", C.c_uint8 * 2), ("table", C.c_uint16 * 8)]
+                ("max_bits", C.c_uint8), ("frozen", C.c_uint8), ("log_cells", C.c_uint8), ("reserved", C.c_uint8), ("table", C.c_uint16 * 8)]
 
 
 class ModelSpec(C.Structure):
@@ -33,7 +35,7 @@ EXPORTS = [
     "w3_abi_version", "w3_strerror", "w3_last_error", "w3_ctx_create", "w3_ctx_destroy", "w3_spec_validate",
     "w3_ctx_set_option", "w3_max_compressed_size", "w3_encode_blocks", "w3_decode_blocks", "w3_encode_blocks_device",
     "w3_decode_blocks_device", "w3_compress_stream", "w3_decompress_stream", "w3_predict_blocks", "w3_stationary_table",
-    "w3_get_timing", "w3_selftest_counter_p", "w3_debug_get_stamps",
+    "w3_get_timing", "w3_selftest_counter_p", "w3_debug_get_stamps", "w3_state_table", "w3_stretch_squash",
 ]
 
 _lib = None
@@ -79,5 +81,7 @@ def load():
     lib.w3_selftest_counter_p.argtypes = [vp, C.POINTER(C.c_uint64)]
     lib.w3_debug_get_stamps.argtypes = [vp, C.POINTER(C.c_uint64 * 8)]
     lib.w3_get_timing.argtypes = [vp, C.POINTER(Timing)]
+    lib.w3_state_table.argtypes = [vp]
+    lib.w3_stretch_squash.argtypes = [vp, vp]
     _lib = lib
     return lib

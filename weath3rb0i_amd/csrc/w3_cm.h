@@ -1,0 +1,215 @@
+// w3_cm.h — lane-per-block CONTEXT-MIXING kernel: the literal north-star design.  One wavefront lane
+// owns one block's arithmetic coder and model state; the 12-bit state table (NaiveStateTable,
+// state_table/naive.rs) and the APM stretch LUT are staged in LDS; slot-model contexts are resolved
+// against a per-lane Cell/Slot hash map in HBM (hashmap.rs); Counter tables as in w3_generic.h.
+//
+// Runs every spec that contains a SLOT_STATE leaf or an APM stage, and every decode of such a spec
+// (decode is serial by nature: the next context depends on the decoded bit, main.rs:131-140).
+// The slot model, its replacement policy and the APM are BUILD-DEFINED (SURVEY §8 A19 ii-v): the
+// reference has the primitives but no model that uses them.  Definitions: DESIGN.md §2.4.
+#pragma once
+#include "w3_generic.h"
+#include "w3_tables.h"
+
+namespace w3 {
+
+struct ApmParam {
+    uint8_t  ctx_kind;   // 0: row = c0 (partial byte, leading 1)   1: row = c0 | previous byte << 8
+    uint8_t  rate;
+    uint8_t  pad[6];
+    uint64_t off;        // byte offset of this stage's u16[rows][33] table inside the lane's region
+};
+
+struct CmArgs {
+    GenericArgs g;
+    int n_apm;
+    ApmParam apm[W3_MAX_APM];
+    const uint2   *st;        // [kStSize] {prob | next0 << 16, next1 | conf << 16}
+    const int16_t *stretch;   // [4096]
+    const uint16_t *squash;   // [4095] (APM table initialisation only)
+};
+
+// ---- Cell / Slot (hashmap.rs:31-129), byte-exact layout: 6 tag bytes + 90 state bytes ----------------
+// Slot::get_idx (hashmap.rs:80-84): half-byte index of state (bit_id, nib_ctx) of slot `id`.
+__device__ __forceinline__ uint32_t slot_idx(uint32_t id, uint32_t bit_id, uint32_t nib_ctx) {
+    return (3u << bit_id) + 3u * nib_ctx + 45u * id - 3u;
+}
+__device__ __forceinline__ uint32_t slot_get_state(const uint8_t *cell, uint32_t id, uint32_t bit_id, uint32_t nib_ctx) {  // :86-97
+    const uint32_t idx = slot_idx(id, bit_id, nib_ctx);
+    const uint8_t *p = cell + 6u + (idx >> 1);
+    const uint32_t v = ((uint32_t)p[0] << 8) | p[1];
+    return (idx & 1u) ? (v & 0xFFFu) : (v >> 4);
+}
+__device__ __forceinline__ void slot_set_state(uint8_t *cell, uint32_t id, uint32_t bit_id, uint32_t nib_ctx, uint32_t ns) {  // :99-112
+    const uint32_t idx = slot_idx(id, bit_id, nib_ctx);
+    uint8_t *p = cell + 6u + (idx >> 1);
+    if (!(idx & 1u)) {
+        p[0] = (uint8_t)(ns >> 4);
+        p[1] = (uint8_t)(((ns << 4) & 0xF0u) | (p[1] & 0x0Fu));
+    } else {
+        p[0] = (uint8_t)((ns >> 8) | (p[0] & 0xF0u));
+        p[1] = (uint8_t)ns;
+    }
+}
+
+// splitmix64 finaliser over (order, previous `order` bytes, nibble marker) — build-defined context hash
+__device__ __forceinline__ uint64_t slot_hash(uint32_t order, uint64_t hist_bytes, bool second, uint32_t hi_nib) {
+    uint64_t k = order ? (hist_bytes & ((1ull << (8u * order)) - 1ull)) : 0ull;
+    k = (k << 8) | (second ? (0x10u | hi_nib) : 0u);
+    k += (uint64_t)(order + 1u) * 0x9E3779B97F4A7C15ull;
+    k ^= k >> 30; k *= 0xBF58476D1CE4E5B9ull;
+    k ^= k >> 27; k *= 0x94D049BB133111EBull;
+    k ^= k >> 31;
+    return k;
+}
+
+// HashMap::get_slot + Cell::get_slot (hashmap.rs:25-28, 42-63): cell by the HIGH hash bits, 12-bit tags
+// compared in the order id 3, 2, 1, 0.  Miss (the reference's TODO, :64-68): victim = fewest observations
+// in the slot's first-bit state, candidates in the order 1, 0, 2, 3; tag stored, 15 states cleared.
+__device__ __forceinline__ uint8_t *slot_select(uint8_t *cells, uint32_t log_cells, uint64_t h, const uint2 *s_st, uint32_t &id_out) {
+    uint8_t *cell = cells + (h >> (64u - log_cells)) * 96ull;
+    const uint32_t tag = (uint32_t)h & 0xFFFu;
+    uint64_t hc = 0;
+#pragma unroll
+    for (int i = 0; i < 6; i++) hc = (hc << 8) | cell[i];
+    int id = -1;
+    if (tag == (uint32_t)(hc & 0xFFFu)) id = 3;
+    else if (tag == (uint32_t)((hc >> 12) & 0xFFFu)) id = 2;
+    else if (tag == (uint32_t)((hc >> 24) & 0xFFFu)) id = 1;
+    else if (tag == (uint32_t)((hc >> 36) & 0xFFFu)) id = 0;
+    if (id < 0) {
+        uint32_t best = 0xFFFFFFFFu;
+        const int cand[4] = {1, 0, 2, 3};
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const uint32_t conf = s_st[slot_get_state(cell, (uint32_t)cand[k], 0u, 0u)].y >> 16;
+            if (conf < best) { best = conf; id = cand[k]; }
+        }
+        const uint32_t sh = 12u * (3u - (uint32_t)id);
+        hc = (hc & ~(0xFFFull << sh)) | ((uint64_t)tag << sh);
+#pragma unroll
+        for (int i = 5; i >= 0; i--) { cell[i] = (uint8_t)hc; hc >>= 8; }
+        for (uint32_t bit_id = 0; bit_id < 4u; bit_id++)
+            for (uint32_t c = 0; c < (1u << bit_id); c++) slot_set_state(cell, (uint32_t)id, bit_id, c, 0u);
+    }
+    id_out = (uint32_t)id;
+    return cell;
+}
+
+// APM tables start as the identity map: t[row][j] = squash((j - 16) * 128)
+__global__ void __launch_bounds__(256) k_cm_init_apm(uint8_t *tables, uint64_t lane_stride, uint64_t off, uint32_t rows,
+                                                    uint32_t n_lanes, const uint16_t *squash) {
+    const uint64_t per_lane = (uint64_t)rows * 33u;
+    const uint64_t total = per_lane * n_lanes;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t lane = i / per_lane;
+        const uint32_t j = (uint32_t)((i - lane * per_lane) % 33u);
+        int d = ((int)j - 16) * 128;
+        d = d < -2047 ? -2047 : d > 2047 ? 2047 : d;
+        reinterpret_cast<uint16_t *>(tables + lane * lane_stride + off)[i - lane * per_lane] = squash[d + 2047];
+    }
+}
+
+template <bool DECODE>
+__global__ void __launch_bounds__(64) k_cm(CmArgs a) {
+    __shared__ uint2   s_st[kStSize];
+    __shared__ int16_t s_str[4096];
+    for (uint32_t i = threadIdx.x; i < (uint32_t)kStSize; i += 64u) s_st[i] = a.st[i];
+    for (uint32_t i = threadIdx.x; i < 4096u; i += 64u) s_str[i] = a.stretch[i];
+    __shared__ LeafParam s_leaf[W3_MAX_LEAVES];
+    __shared__ ApmParam s_apm[W3_MAX_APM];
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int k = 0; k < W3_MAX_APM; k++) s_apm[k] = a.apm[k];
+    }
+    stage_leaves(s_leaf, a.g);   // (also the barrier for the tables above)
+
+    const GenericArgs &g = a.g;
+    const uint32_t lane = blockIdx.x * blockDim.x + threadIdx.x;
+    if (lane >= g.n_lanes) return;
+    const uint32_t b = g.first_block + lane;
+    const uint64_t off = (uint64_t)b * g.block_size;
+    const uint32_t len = (uint32_t)((g.n - off) < g.block_size ? (g.n - off) : g.block_size);
+    uint8_t *lane_tbl = g.tables + (uint64_t)lane * g.lane_stride;
+
+    Encoder enc; Decoder dec;
+    if (DECODE) dec.init(g.cin + g.coffs[b], g.clens[b]);
+    else enc.init(g.stripes + (uint64_t)lane * g.stripe_cap, g.stripe_cap);
+
+    // slot leaves: the cell/slot of the current nibble (selected for an empty history at construction)
+    uint8_t *cellp[W3_MAX_LEAVES]; uint32_t sid[W3_MAX_LEAVES];
+    for (int l = 0; l < g.n_leaves; l++) {
+        cellp[l] = nullptr; sid[l] = 0;
+        if (s_leaf[l].kind == 1) cellp[l] = slot_select(lane_tbl + s_leaf[l].tbl_off, s_leaf[l].log_cells, slot_hash(s_leaf[l].order, 0ull, false, 0u), s_st, sid[l]);
+    }
+
+    uint64_t hist64 = 0, hist_bytes = 0; uint32_t t = 0, c0 = 1, c1 = 0;
+    for (uint32_t i = 0; i < len; i++) {
+        uint32_t byte = DECODE ? 0u : g.in[off + i];
+        for (int s = 7; s >= 0; s--) {
+            const uint32_t bit_id = (uint32_t)(7 - s) & 3u, nib_ctx = c0 & ((1u << bit_id) - 1u);
+            // predict: leftmost leaf of maximal |p - 1/2| (BestOfTwo tree, models/mod.rs:67-69)
+            uint32_t p = 32768u, best = 0u; bool first = true;
+            uint32_t *cslot[W3_MAX_LEAVES]; uint32_t st[W3_MAX_LEAVES];
+            for (int l = 0; l < g.n_leaves; l++) {
+                const LeafParam &lp = s_leaf[l];
+                uint32_t pl = 32768u;
+                cslot[l] = nullptr; st[l] = 0;
+                if (lp.kind == 1) {
+                    st[l] = slot_get_state(cellp[l], sid[l], bit_id, nib_ctx);
+                    pl = s_st[st[l]].x & 0xFFFFu;                       // StateTable::p  state_table/mod.rs:47-49
+                } else if (!lp.frozen) {
+                    cslot[l] = leaf_slot(lp, lane_tbl, leaf_ctx(lp, hist64, t));
+                    pl = counter_p_packed(*cslot[l]);
+                }
+                const uint32_t d = opinion_dist(pl);
+                if (first || d > best) { p = pl; best = d; first = false; }
+            }
+            // APM chain (build-defined): refine p through each stage
+            uint16_t *aslot[W3_MAX_APM];
+            for (int k = 0; k < a.n_apm; k++) {
+                const uint32_t row = s_apm[k].ctx_kind ? (c0 | (c1 << 8)) : c0;
+                const uint32_t pos = (uint32_t)((int)s_str[p >> 4] + 2048) * 32u;
+                const uint32_t j = pos >> 12, w = pos & 4095u;
+                uint16_t *tr = reinterpret_cast<uint16_t *>(lane_tbl + s_apm[k].off) + row * 33u + j;
+                const uint32_t pa = ((uint32_t)tr[0] * (4096u - w) + (uint32_t)tr[1] * w) >> 12;
+                aslot[k] = tr + (w >> 11);
+                uint32_t o = (p + 3u * pa + 2u) >> 2;
+                p = o < 1u ? 1u : o > 65535u ? 65535u : o;
+            }
+            uint32_t bit;
+            if (DECODE) { bit = dec.decode(p); byte = (byte << 1) | bit; }
+            else bit = (byte >> s) & 1u;
+            // Model::update = adapt (train the current context) then advance  models/mod.rs:28-31
+            for (int k = 0; k < a.n_apm; k++) {
+                const int tv = (int)*aslot[k];
+                *aslot[k] = (uint16_t)(tv + (((bit ? 65535 : 0) - tv) >> s_apm[k].rate));   // arithmetic shift = floor
+            }
+            for (int l = 0; l < g.n_leaves; l++) {
+                if (s_leaf[l].kind == 1) slot_set_state(cellp[l], sid[l], bit_id, nib_ctx, bit ? (s_st[st[l]].y & 0xFFFFu) : (s_st[st[l]].x >> 16));
+                else if (cslot[l]) *cslot[l] = counter_update_packed(*cslot[l], bit);
+            }
+            hist64 = (hist64 << 1) | bit;
+            t++;
+            c0 = (c0 << 1) | bit;
+            if (!DECODE) enc.encode(bit, p);
+            if (bit_id == 3u) {   // nibble boundary: one cell touch per nibble (hashslots.md:3-4)
+                const bool second = c0 < 256u;
+                if (!second) { hist_bytes = (hist_bytes << 8) | (c0 & 0xFFu); c1 = c0 & 0xFFu; c0 = 1u; }
+                if (i + 1u < len || second)
+                    for (int l = 0; l < g.n_leaves; l++)
+                        if (s_leaf[l].kind == 1)
+                            cellp[l] = slot_select(lane_tbl + s_leaf[l].tbl_off, s_leaf[l].log_cells,
+                                                   slot_hash(s_leaf[l].order, hist_bytes, second, c0 & 15u), s_st, sid[l]);
+            }
+        }
+        if (DECODE) g.dout[off + i] = (uint8_t)byte;
+    }
+    if (!DECODE) {
+        const uint32_t produced = enc.flush();
+        g.out_len[b] = produced;
+        if (produced > g.stripe_cap) atomicOr(g.overflow, 1u);
+    }
+}
+
+}  // namespace w3

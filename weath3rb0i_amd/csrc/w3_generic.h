@@ -9,7 +9,10 @@
 namespace w3 {
 
 struct LeafParam {
-    uint8_t  bits, align, hist, max_bits, frozen, use_hash, pad[2];
+    uint8_t  bits, align, hist, max_bits, frozen, use_hash;
+    uint8_t  kind;           // 0 = Counter table leaf, 1 = slot-state leaf (w3_cm.h)
+    uint8_t  log_cells;      // slot leaf: HashMap log_cell_count
+    uint8_t  order, pad;     // slot leaf: previous bytes in the context
     uint16_t table[8];       // StationaryModel table (ACHistory)
     uint64_t tbl_off;        // byte offset of this leaf's table inside the lane's region
     uint32_t hash_mask;      // slots-1 when use_hash
@@ -18,7 +21,7 @@ struct LeafParam {
 
 struct GenericArgs {
     int       n_leaves;
-    LeafParam leaf[16];
+    LeafParam leaf[W3_MAX_LEAVES];
     // geometry
     uint64_t  n;             // total original bytes
     uint32_t  block_size;
@@ -72,8 +75,23 @@ __device__ __forceinline__ uint32_t *leaf_slot(const LeafParam &lp, uint8_t *lan
     }
 }
 
+// The leaf parameters are read with a loop-variant index.  hipcc strength-reduces such reads of the kernel
+// arguments into s_load_dwordx2 from a byte-misaligned SGPR base (base = &leaf[l].<u8 field>), and the scalar
+// memory unit drops the two low bits of the BASE, not of base+offset: leaf[l].tbl_off came back shifted for
+// every l whose fields were not zero (found on MI355X as an aperture violation).  So the parameters are copied
+// to LDS once with compile-time offsets and read from there.
+__device__ __forceinline__ void stage_leaves(LeafParam *s_leaf, const GenericArgs &a) {
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int l = 0; l < W3_MAX_LEAVES; l++) s_leaf[l] = a.leaf[l];
+    }
+    __syncthreads();
+}
+
 template <bool DECODE>
 __global__ void __launch_bounds__(64) k_generic(GenericArgs a) {
+    __shared__ LeafParam s_leaf[W3_MAX_LEAVES];
+    stage_leaves(s_leaf, a);
     const uint32_t lane = blockIdx.x * blockDim.x + threadIdx.x;
     if (lane >= a.n_lanes) return;
     const uint32_t b = a.first_block + lane;
@@ -93,7 +111,7 @@ __global__ void __launch_bounds__(64) k_generic(GenericArgs a) {
             uint32_t p = 32768u, best = 0u; bool first = true;
             uint32_t *slot[16];
             for (int l = 0; l < a.n_leaves; l++) {
-                const LeafParam &lp = a.leaf[l];
+                const LeafParam &lp = s_leaf[l];
                 uint32_t pl = 32768u;
                 slot[l] = nullptr;
                 if (!lp.frozen) {                       // FrozenModel never adapts: Counter stays (0,0)

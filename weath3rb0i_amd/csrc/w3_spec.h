@@ -1,8 +1,13 @@
-// w3_spec.h — host-side parsed form of w3_model_spec: the leaves in in-order.
+// w3_spec.h — host-side parsed form of w3_model_spec: the leaves in in-order (a BestOfTwo tree of any
+// shape returns the leftmost leaf of maximal |p - 1/2|) followed by the APM chain applied at the root.
 #pragma once
 #include "../../include/w3hip.h"
 
 struct ParsedSpec {
     int n_leaves = 0;
     w3_node leaf[W3_MAX_LEAVES];
+    int n_apm = 0;
+    w3_node apm[W3_MAX_APM];
+    bool has_slot = false;
+    bool is_cm() const { return has_slot || n_apm > 0; }
 };

@@ -13,6 +13,7 @@
 
 #include "w3_spec.h"
 #include "w3_generic.h"
+#include "w3_cm.h"
 #include "w3_pack.h"
 #include "w3_twophase.h"
 #include "w3_selftest.h"
@@ -36,7 +37,7 @@ struct w3_ctx {
     w3_timing timing{};
     hipEvent_t ev[8]{};
     // workspace
-    DevBuf tables, stripes, lens, offs, total, flag, io_in, io_out, coffs, misc;
+    DevBuf tables, stripes, lens, offs, total, flag, io_in, io_out, coffs, misc, cm_luts;
     TwoPhaseWs tp;
 };
 
@@ -102,7 +103,7 @@ extern "C" void w3_ctx_destroy(w3_ctx *ctx) {
     (void)hipSetDevice(ctx->device);
     (void)hipDeviceSynchronize();
     DevBuf *bufs[] = {&ctx->tables, &ctx->stripes, &ctx->lens, &ctx->offs, &ctx->total, &ctx->flag,
-                      &ctx->io_in, &ctx->io_out, &ctx->coffs, &ctx->misc};
+                      &ctx->io_in, &ctx->io_out, &ctx->coffs, &ctx->misc, &ctx->cm_luts};
     for (DevBuf *b : bufs)
         if (b->p) (void)hipFree(b->p);
     ctx->tp.release();
@@ -154,9 +155,18 @@ extern "C" size_t w3_max_compressed_size(size_t n, size_t block_size) {
 static int parse_spec(const w3_model_spec *spec, ParsedSpec &ps) {
     if (!spec || spec->n_nodes == 0 || spec->n_nodes > W3_MAX_NODES) return W3_E_INVALID;
     int depth = 0;
-    ps.n_leaves = 0;
+    ps = ParsedSpec();
     for (uint32_t i = 0; i < spec->n_nodes; i++) {
         const w3_node &nd = spec->nodes[i];
+        if (nd.kind == W3_NODE_APM) {
+            // APM(model): one input.  Implemented as a chain at the root of the tree only.
+            if (depth < 1 || nd.align > W3_APM_ORDER1 || nd.max_bits < 1 || nd.max_bits > 15) return W3_E_INVALID;
+            if (depth != 1) return W3_E_UNSUPPORTED;
+            if (ps.n_apm == W3_MAX_APM) return W3_E_UNSUPPORTED;
+            ps.apm[ps.n_apm++] = nd;
+            continue;
+        }
+        if (ps.n_apm) return nd.kind == W3_NODE_ORDERN || nd.kind == W3_NODE_SLOT_STATE || nd.kind == W3_NODE_BEST_OF_TWO ? W3_E_UNSUPPORTED : W3_E_INVALID;
         if (nd.kind == W3_NODE_ORDERN) {
             // OrderN::new allocates 1<<bits counters; masks are u32/u8 (ordern.rs:35-43)
             if (nd.bits < 1 || nd.bits > 32 || nd.align > 7 || nd.align > nd.bits) return W3_E_INVALID;
@@ -165,6 +175,12 @@ static int parse_spec(const w3_model_spec *spec, ParsedSpec &ps) {
             if (nd.history == W3_HIST_AC && nd.max_bits > 32) return W3_E_INVALID;
             if (ps.n_leaves == W3_MAX_LEAVES) return W3_E_UNSUPPORTED;
             ps.leaf[ps.n_leaves++] = nd;
+            depth++;
+        } else if (nd.kind == W3_NODE_SLOT_STATE) {
+            if (nd.bits > 7 || nd.log_cells < 1 || nd.log_cells > 24 || nd.frozen) return W3_E_INVALID;
+            if (ps.n_leaves == W3_MAX_LEAVES) return W3_E_UNSUPPORTED;
+            ps.leaf[ps.n_leaves++] = nd;
+            ps.has_slot = true;
             depth++;
         } else if (nd.kind == W3_NODE_BEST_OF_TWO) {
             if (depth < 2) return W3_E_INVALID;
@@ -200,8 +216,13 @@ static uint64_t layout_generic(const ParsedSpec &ps, size_t block_size, GenericA
         memset(&lp, 0, sizeof lp);
         lp.bits = nd.bits; lp.align = nd.align; lp.hist = nd.history; lp.max_bits = nd.max_bits; lp.frozen = nd.frozen;
         memcpy(lp.table, nd.table, sizeof lp.table);
-        lp.hist_mask = (uint32_t)((1ull << (nd.bits - nd.align)) - 1ull);
         lp.tbl_off = off;
+        if (nd.kind == W3_NODE_SLOT_STATE) {   // HashMap of 2^log_cells 96-byte Cells (hashmap.rs:7-22)
+            lp.kind = 1; lp.order = nd.bits; lp.log_cells = nd.log_cells;
+            off += 96ull << nd.log_cells;
+            continue;
+        }
+        lp.hist_mask = (uint32_t)((1ull << (nd.bits - nd.align)) - 1ull);
         if (nd.frozen) continue;
         const uint64_t direct_bytes = 4ull << nd.bits;
         if (direct_bytes <= hash_bytes) { lp.use_hash = 0; off += direct_bytes; }
@@ -305,6 +326,93 @@ static int generic_decode(w3_ctx *ctx, hipStream_t s, const ParsedSpec &ps, cons
 }
 
 // ---------------------------------------------------------------------------
+// CM path (slot-state leaves and/or APM chain): k_cm, lane per block
+// ---------------------------------------------------------------------------
+static int cm_luts(w3_ctx *ctx, hipStream_t s, CmArgs &ca) {
+    const size_t st_bytes = (size_t)kStSize * 8, str_bytes = 4096 * 2, sq_bytes = 4096 * 2;
+    if (!ctx->cm_luts.p) {
+        ENSURE(ctx, ctx->cm_luts, st_bytes + str_bytes + sq_bytes);
+        std::vector<StEntry> t(kStSize);
+        build_state_table(t.data());
+        std::vector<uint32_t> packed(2 * kStSize);
+        for (int i = 0; i < kStSize; i++) {
+            packed[2 * i] = t[i].prob | ((uint32_t)t[i].next0 << 16);
+            packed[2 * i + 1] = t[i].next1 | ((uint32_t)t[i].conf << 16);
+        }
+        std::vector<int16_t> str(4096);
+        std::vector<uint16_t> sq(4096);
+        build_stretch_squash(str.data(), sq.data());
+        uint8_t *d = (uint8_t *)ctx->cm_luts.p;
+        HIPCHK(ctx, hipMemcpy(d, packed.data(), st_bytes, hipMemcpyHostToDevice));
+        HIPCHK(ctx, hipMemcpy(d + st_bytes, str.data(), str_bytes, hipMemcpyHostToDevice));
+        HIPCHK(ctx, hipMemcpy(d + st_bytes + str_bytes, sq.data(), sq_bytes, hipMemcpyHostToDevice));
+    }
+    (void)s;
+    uint8_t *d = (uint8_t *)ctx->cm_luts.p;
+    ca.st = (const uint2 *)d;
+    ca.stretch = (const int16_t *)(d + st_bytes);
+    ca.squash = (const uint16_t *)(d + st_bytes + str_bytes);
+    return W3_OK;
+}
+
+static uint64_t layout_cm(const ParsedSpec &ps, size_t block_size, CmArgs &ca) {
+    uint64_t off = (layout_generic(ps, block_size, ca.g) + 15) / 16 * 16;
+    ca.n_apm = ps.n_apm;
+    for (int k = 0; k < ps.n_apm; k++) {
+        ca.apm[k].ctx_kind = ps.apm[k].align;
+        ca.apm[k].rate = ps.apm[k].max_bits;
+        ca.apm[k].off = off;
+        off += ((ps.apm[k].align == W3_APM_ORDER1 ? 65536ull : 256ull) * 33 * 2 + 15) / 16 * 16;
+    }
+    return off;
+}
+
+template <bool DECODE>
+static int cm_run(w3_ctx *ctx, hipStream_t s, CmArgs &ca, uint64_t lane_stride, uint32_t nb, uint32_t stripe_cap) {
+    uint32_t lanes = 0;
+    int rc = table_budget(ctx, lane_stride, nb, lanes);
+    if (rc) return rc;
+    ENSURE(ctx, ctx->tables, (size_t)lanes * lane_stride);
+    if ((rc = cm_luts(ctx, s, ca))) return rc;
+    ca.g.tables = (uint8_t *)ctx->tables.p; ca.g.lane_stride = lane_stride;
+    for (uint32_t first = 0; first < nb; first += lanes) {
+        uint32_t cnt = std::min(lanes, nb - first);
+        ca.g.first_block = first; ca.g.n_lanes = cnt;
+        if (!DECODE) ca.g.stripes = (uint8_t *)ctx->stripes.p + (uint64_t)first * stripe_cap;
+        HIPCHK(ctx, hipMemsetAsync(ctx->tables.p, 0, (size_t)cnt * lane_stride, s));
+        for (int k = 0; k < ca.n_apm; k++)
+            hipLaunchKernelGGL(k_cm_init_apm, dim3(2048), dim3(256), 0, s, ca.g.tables, lane_stride, ca.apm[k].off,
+                               ca.apm[k].ctx_kind ? 65536u : 256u, cnt, ca.squash);
+        hipLaunchKernelGGL(k_cm<DECODE>, dim3((cnt + 63) / 64), dim3(64), 0, s, ca);
+        HIPCHK(ctx, hipGetLastError());
+    }
+    return W3_OK;
+}
+
+static int cm_encode(w3_ctx *ctx, hipStream_t s, const ParsedSpec &ps, const uint8_t *d_in, size_t n, size_t block_size,
+                     uint32_t nb, uint32_t stripe_cap, uint32_t *d_lens) {
+    CmArgs ca;
+    memset(&ca, 0, sizeof ca);
+    const uint64_t lane_stride = layout_cm(ps, block_size, ca);
+    ca.g.n = n; ca.g.block_size = (uint32_t)block_size;
+    ca.g.in = d_in; ca.g.stripe_cap = stripe_cap; ca.g.out_len = d_lens; ca.g.overflow = (uint32_t *)ctx->flag.p;
+    return cm_run<false>(ctx, s, ca, lane_stride, nb, stripe_cap);
+}
+
+static int cm_decode(w3_ctx *ctx, hipStream_t s, const ParsedSpec &ps, const uint8_t *d_cin, const uint32_t *d_lens, uint32_t nb,
+                     size_t block_size, uint64_t orig_len, uint8_t *d_out) {
+    CmArgs ca;
+    memset(&ca, 0, sizeof ca);
+    const uint64_t lane_stride = layout_cm(ps, block_size, ca);
+    ENSURE(ctx, ctx->coffs, (size_t)nb * 8);
+    ENSURE(ctx, ctx->total, 8);
+    hipLaunchKernelGGL(k_scan_lens, dim3(1), dim3(1024), 0, s, d_lens, (uint64_t *)ctx->coffs.p, (uint64_t *)ctx->total.p, nb);
+    ca.g.n = orig_len; ca.g.block_size = (uint32_t)block_size;
+    ca.g.cin = d_cin; ca.g.coffs = (const uint64_t *)ctx->coffs.p; ca.g.clens = d_lens; ca.g.dout = d_out;
+    return cm_run<true>(ctx, s, ca, lane_stride, nb, 0);
+}
+
+// ---------------------------------------------------------------------------
 // encode (device-resident)
 // ---------------------------------------------------------------------------
 static uint32_t default_stripe_cap(size_t block_size) {
@@ -344,7 +452,7 @@ extern "C" int w3_encode_blocks_device(w3_ctx *ctx, const w3_model_spec *spec, c
     if (!d_in || !d_out || !d_block_lens) return W3_E_INVALID;
     ENSURE(ctx, ctx->flag, 16);
 
-    bool two = twophase_supported(ps, block_size, n);
+    bool two = !ps.is_cm() && twophase_supported(ps, block_size, n);
     if (ctx->opt_path == W3_PATH_GENERIC) two = false;
     if (ctx->opt_path == W3_PATH_TWOPHASE && !two) { ctx->err = "spec/block size not covered by the two-phase path"; return W3_E_UNSUPPORTED; }
 
@@ -360,7 +468,8 @@ extern "C" int w3_encode_blocks_device(w3_ctx *ctx, const w3_model_spec *spec, c
             ctx->timing.path = W3_PATH_TWOPHASE;
         } else {
             tm.start(0);
-            rc = generic_encode(ctx, s, ps, d_in, n, block_size, nb, cap, d_block_lens);
+            rc = ps.is_cm() ? cm_encode(ctx, s, ps, d_in, n, block_size, nb, cap, d_block_lens)
+                            : generic_encode(ctx, s, ps, d_in, n, block_size, nb, cap, d_block_lens);
             tm.stop();
             ctx->timing.path = W3_PATH_GENERIC;
         }
@@ -413,7 +522,8 @@ extern "C" int w3_decode_blocks_device(w3_ctx *ctx, const w3_model_spec *spec, c
     if (!d_in || !d_block_lens || !d_out) return W3_E_INVALID;
     HIPCHK(ctx, hipSetDevice(ctx->device));
     hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
-    rc = generic_decode(ctx, s, ps, d_in, d_block_lens, (uint32_t)nb, block_size, orig_len, d_out);
+    rc = ps.is_cm() ? cm_decode(ctx, s, ps, d_in, d_block_lens, (uint32_t)nb, block_size, orig_len, d_out)
+                    : generic_decode(ctx, s, ps, d_in, d_block_lens, (uint32_t)nb, block_size, orig_len, d_out);
     if (rc) return rc;
     HIPCHK(ctx, hipStreamSynchronize(s));
     return W3_OK;
@@ -553,7 +663,7 @@ extern "C" int w3_predict_blocks(w3_ctx *ctx, const w3_model_spec *spec, const u
     if ((rc = parse_spec(spec, ps))) return rc;
     if (n == 0) return W3_OK;
     if (!in || !p_out) return W3_E_INVALID;
-    if (!twophase_supported(ps, block_size, n)) { ctx->err = "spec not covered by the two-phase predict kernels"; return W3_E_UNSUPPORTED; }
+    if (ps.is_cm() || !twophase_supported(ps, block_size, n)) { ctx->err = "spec not covered by the two-phase predict kernels"; return W3_E_UNSUPPORTED; }
     HIPCHK(ctx, hipSetDevice(ctx->device));
     hipStream_t s = ctx->stream;
     const uint32_t nb = (uint32_t)((n + block_size - 1) / block_size);
@@ -564,6 +674,23 @@ extern "C" int w3_predict_blocks(w3_ctx *ctx, const w3_model_spec *spec, const u
     if (rc) return rc;
     HIPCHK(ctx, hipStreamSynchronize(s));
     HIPCHK(ctx, hipMemcpy(p_out, d_p, n * 16, hipMemcpyDeviceToHost));
+    return W3_OK;
+}
+
+// ---------------------------------------------------------------------------
+// read-only tables (host-side known-answer surface)
+// ---------------------------------------------------------------------------
+extern "C" int w3_state_table(uint16_t *out) {
+    if (!out) return W3_E_INVALID;
+    std::vector<StEntry> t(kStSize);
+    build_state_table(t.data());
+    for (int i = 0; i < kStSize; i++) { out[3 * i] = t[i].prob; out[3 * i + 1] = t[i].next0; out[3 * i + 2] = t[i].next1; }
+    return W3_OK;
+}
+
+extern "C" int w3_stretch_squash(int16_t *stretch, uint16_t *squash) {
+    if (!stretch || !squash) return W3_E_INVALID;
+    build_stretch_squash(stretch, squash);
     return W3_OK;
 }
 

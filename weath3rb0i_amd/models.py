@@ -193,6 +193,116 @@ class BestOfTwoModel(Model):
         return self.m1._nodes() + self.m2._nodes() + [nd]
 
 
+# ---- build-defined models (SURVEY §8 A19 ii-v; include/w3hip.h) ----------------------
+class StateTable:
+    """trait StateTable (state_table/mod.rs:3-23) over NaiveStateTable (state_table/naive.rs): associated
+    functions only, evaluated from the library's host-side copy of the table the kernels stage in LDS."""
+    _rows = None
+
+    @classmethod
+    def rows(cls):
+        if cls._rows is None:
+            t = np.zeros(3963 * 3, dtype=np.uint16)
+            rc = L.load().w3_state_table(t.ctypes.data_as(C.c_void_p))
+            if rc:
+                raise W3Error(rc)
+            cls._rows = t.reshape(3963, 3)
+        return cls._rows
+
+    @classmethod
+    def next(cls, state, bit):
+        return int(cls.rows()[state, 1 + bit])
+
+    @classmethod
+    def p(cls, state):
+        return int(cls.rows()[state, 0])
+
+    @classmethod
+    def next4(cls, states, nib):  # mod.rs:5-12: nibble applied MSB first
+        return [cls.next(states[i], (nib >> (3 - i)) & 1) for i in range(4)]
+
+    @classmethod
+    def p4(cls, states):  # mod.rs:15-22
+        return [cls.p(s) for s in states]
+
+
+class HashMap:
+    """hashmap.rs:7-22 — HashMap::new(size): only the sizing rule lives on the host; the table itself is
+    per-block device state."""
+
+    def __init__(self, size):
+        import math
+        self.log_cell_count = int(math.log2(float(size)) - math.log2(96.0))  # f64 arithmetic, truncated (hashmap.rs:9)
+
+    @classmethod
+    def new(cls, size):
+        return cls(size)
+
+
+class SlotModel(Model):
+    """State-table CM leaf (docs/hashslots.md): context = previous `order` bytes, one Cell touch per nibble,
+    probabilities and updates through the 12-bit NaiveStateTable.  BUILD-DEFINED wiring of hashmap.rs +
+    state_table/naive.rs, which no reference model uses."""
+
+    def __init__(self, order, hashmap):
+        self.order = int(order)
+        self.log_cells = hashmap.log_cell_count if isinstance(hashmap, HashMap) else int(hashmap)
+
+    @classmethod
+    def new(cls, order, hashmap):
+        return cls(order, hashmap)
+
+    def _nodes(self):
+        nd = L.Node()
+        nd.kind = L.W3_NODE_SLOT_STATE
+        if not (0 <= self.order <= 255 and 0 <= self.log_cells <= 255):
+            raise W3Error(L.W3_E_INVALID, "u8 parameter out of range")
+        nd.bits, nd.log_cells = self.order, self.log_cells
+        return [nd]
+
+
+class Mixer:
+    """The mixer surface (SURVEY §8 A19 v): OpinionMixer2 (mixers/opinion_mixer2.rs) is the stateless
+    two-input instance used by BestOfTwoModel; APM is the adaptive one-input instance."""
+
+
+class OpinionMixer2(Mixer):
+    @staticmethod
+    def mix(p1, p2):  # opinion_mixer2.rs:5-10 (host-side convenience; the kernels apply it per step)
+        d1, d2 = abs(p1 - 32768), abs(p2 - 32768)
+        return p1 if d1 >= d2 else p2
+
+
+class APM(Model, Mixer):
+    """Adaptive probability map ("APM mixers", README.md:10): BUILD-DEFINED, 33 interpolated buckets over
+    stretch(p) per context row, output (p + 3 apm) / 4."""
+    ORDER0, ORDER1 = L.W3_APM_ORDER0, L.W3_APM_ORDER1
+
+    def __init__(self, model, ctx=L.W3_APM_ORDER0, rate=7):
+        self.model, self.ctx, self.rate = model, int(ctx), int(rate)
+
+    @classmethod
+    def new(cls, model, ctx=L.W3_APM_ORDER0, rate=7):
+        return cls(model, ctx, rate)
+
+    def _nodes(self):
+        nd = L.Node()
+        nd.kind = L.W3_NODE_APM
+        if not (0 <= self.ctx <= 255 and 0 <= self.rate <= 255):
+            raise W3Error(L.W3_E_INVALID, "u8 parameter out of range")
+        nd.align, nd.max_bits = self.ctx, self.rate
+        return self.model._nodes() + [nd]
+
+
+def full_cm(log_cells=14):
+    """BASELINE.json configs[2] — "full 12-bit state-table CM (all src/models + APM chain)": the three Counter
+    orders, four slot-state orders, OpinionMixer2 selection, two APM stages."""
+    m = BestOfTwoModel(BestOfTwoModel(Order0(), Order1()), OrderN(27, 3))
+    for order in (1, 2, 3, 4):
+        m = BestOfTwoModel(m, SlotModel(order, log_cells))
+    return APM(APM(m, APM.ORDER0, 7), APM.ORDER1, 6)
+
+
 def init_model():
     """main.rs:146-152 — the main binary's default model."""
     return OrderNEntropy.new(11, 3, ACHistory.new(8, StationaryModel.for_book1()))
