@@ -154,7 +154,7 @@ def main():
     for _ in range(args.warmup):
         step()
     ctx.set_timing(True)
-    kern_ms = {"predict_ms": 0.0, "coder_ms": 0.0, "pack_ms": 0.0, "generic_ms": 0.0}
+    kern_ms = {"predict_ms": 0.0, "apm_ms": 0.0, "coder_ms": 0.0, "pack_ms": 0.0, "generic_ms": 0.0}
     coder_bytes = 0
     launches = 0
     sync()

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define W3_ABI_VERSION 2
+#define W3_ABI_VERSION 3
 
 /* ---- error codes --------------------------------------------------------- */
 enum {
@@ -194,7 +194,7 @@ typedef struct w3_timing {
     uint64_t coder_bytes;  /* algorithmic HBM bytes of the coder launches    */
     uint64_t predict_bytes;
     uint32_t n_recoded_blocks; /* blocks the fast coder handed to the robust coder */
-    uint32_t reserved;
+    float    apm_ms;       /* APM stage kernels of the two-phase path (k_apm0 / k_apm1) */
 } w3_timing;
 int w3_get_timing(const w3_ctx *ctx, w3_timing *out);
 

@@ -63,12 +63,25 @@ NAMES = ["slot0", "slot1", "slot2", "slot3_tiny_table", "slot7", "slot2_hashmap_
          "apm_rate1", "o012_apm", "apm_chain4", "slot_mix", "apm_frozen", "apm_main_default", "full_cm", "full_cm_small_tables"]
 
 
+TWOPHASE_APM = {"apm0_order0", "apm1_order0_r3", "apm_rate15", "apm_rate1", "o012_apm", "apm_chain4", "apm_frozen", "apm_main_default"}
+
+
 def check(ctx, oracle, name, data, bs, decode=True):
     dev, orc = pair(oracle, name)
     out, lens = ctx.encode_blocks(dev(), data, bs)
     want, wlens = oracle.encode_blocks(orc(), data, bs, nthreads=8)
     assert lens.tolist() == wlens.tolist(), name
     assert out.tobytes() == want.tobytes(), name
+    if name in TWOPHASE_APM and len(data) >= 4:
+        # APM chains over Counter leaves run on the two-phase path (k_apm0 / k_apm1); k_cm must agree with it
+        assert ctx.timing()["path"] == 2, name
+        ctx.set_path("generic")
+        try:
+            out2, lens2 = ctx.encode_blocks(dev(), data, bs)
+            assert ctx.timing()["path"] == 1
+        finally:
+            ctx.set_path("auto")
+        assert lens2.tolist() == wlens.tolist() and out2.tobytes() == want.tobytes(), name + " (k_cm)"
     if decode:
         assert ctx.decode_blocks(dev(), out, lens, bs, len(data)).tobytes() == bytes(data), name
     return out, lens
@@ -116,6 +129,48 @@ def test_cm_full_block_64k(ctx, oracle):
     data = markov_text(3 * 65536 + 1000, seed=77)
     check(ctx, oracle, "full_cm", data, 65536)
     check(ctx, oracle, "o012_apm", data, 65536)
+
+
+@pytest.mark.parametrize("name", ["o012_apm", "apm1_order0_r3", "apm_chain4"])
+def test_apm_twophase_shapes(ctx, oracle, name):
+    """k_apm0 / k_apm1 corner cases: more blocks than one workgroup's waves, ragged last block, lengths that are not a
+    multiple of the 8-position round, every previous-byte group present (random bytes), one giant group (constant
+    bytes), group boundaries inside a round (short alternating runs)."""
+    rng = np.random.default_rng(9)
+    runs = b"".join(bytes([int(v)]) * int(r) for v, r in zip(rng.integers(0, 256, 3000), rng.integers(1, 12, 3000)))
+    cases = [
+        (markov_text(11 * 4096 + 1234, seed=12), 4096),
+        (rng.integers(0, 256, 30011, dtype=np.uint8).tobytes(), 8192),
+        (b"\x00" * 20003, 8192), (b"ab" * 9001, 4096), (runs, 4096),
+        (markov_text(2 * 65536 + 777, seed=13), 65536),
+        (lcg_text(5, seed=3), 4096), (lcg_text(9, seed=3), 8), (lcg_text(4, seed=3), 4096),
+    ]
+    for data, bs in cases:
+        check(ctx, oracle, name, data, bs, decode=False)
+
+
+def test_apm_predict_blocks(ctx, oracle):
+    """Model::predict of an APM chain for every step, straight from the predict + APM kernels."""
+    data = markov_text(40000, seed=21)
+    for name in ("o012_apm", "apm_chain4"):
+        dev, orc = pair(oracle, name)
+        p = ctx.predict_blocks(dev(), data, 16384)
+        want = np.concatenate([oracle.predict_all(orc(), data[o:min(o + 16384, 40000)]) for o in range(0, 40000, 16384)])
+        assert np.array_equal(p, want), name
+
+
+def test_apm_robust_coder_handback(ctx, oracle):
+    """A lowered accumulator limit makes the fast coder hand blocks to the robust coder, which reads the APM's final stream."""
+    data = markov_text(50000, seed=5)
+    dev, orc = pair(oracle, "o012_apm")
+    want, wlens = oracle.encode_blocks(orc(), data, 8192, nthreads=8)
+    ctx.set_acc_limit(19)
+    try:
+        out, lens = ctx.encode_blocks(dev(), data, 8192)
+        assert ctx.timing()["n_recoded_blocks"] > 0
+    finally:
+        ctx.set_acc_limit(46)
+    assert lens.tolist() == wlens.tolist() and out.tobytes() == want.tobytes()
 
 
 def test_cm_reference_container(ctx, oracle):

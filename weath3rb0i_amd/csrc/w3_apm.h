@@ -1,0 +1,254 @@
+// w3_apm.h — APM stages of the two-phase encoder (gfx950).
+//
+// The APM ("APM mixers", README.md:10 — a goal of the reference, no code; BUILD-DEFINED here, DESIGN.md §2.4,
+// the CPU checker restates it as apm_pp/apm_update) refines the probability p of its input model through a table
+// t[row][33] of u16 interpolated over stretch(p):
+//     pos = (stretch(p) + 2048) * 32, j = pos >> 12, w = pos & 4095
+//     pa  = (t[row][j] * (4096 - w) + t[row][j+1] * w) >> 12,      p' = clamp((p + 3 pa + 2) >> 2, 1, 65535)
+//     update: the nearer entry t[row][j + (w >> 11)] moves towards 65535*bit by (delta >> rate) (floor).
+//
+// In the two-phase encoder the stage's INPUT p is known for every step before the stage runs (the predict
+// kernels produced it), and so are the row (a function of the input bits) and the coded bit.  What stays
+// serial is only the history of each table entry.  One wavefront owns one table in LDS (256 rows x 33 x u16 =
+// 16.5 KiB; four waves share the 8 KiB stretch LUT: two workgroups per CU) and walks its positions in time
+// order, 8 positions x 8 bit positions per round:  lane = (k = position in the round, j = bit position).
+// The 8 lanes of one position touch 8 different rows (the partial byte c0 has a different length per j), so they
+// are conflict free; the 8 positions of a round are committed one after another (LDS executes one wave's
+// instructions in order), everything else — loads, OpinionMixer2 over the leaf streams, stretch, interpolation,
+// the output store — is done for the 64 steps at once.
+//
+//   k_apm0<L> : row = c0 (W3_APM_ORDER0).  One wave per block, time order; reads the L leaf streams (mixing them
+//               on the fly) or the previous stage's stream, writes the stage's stream.  Coalesced 128-B accesses.
+//   k_apm1    : row = c0 | c1 << 8 (W3_APM_ORDER1) = 256 independent order-0 tables keyed by the previous byte.
+//               Walks the block's records sorted by c1 (k_partition<1>): each group is a contiguous, time-ordered
+//               run that starts from a fresh table.  Jobs = (block, slice) handed out block-major (as in
+//               k_rank_sorted) so the in-place 16-byte gathers/scatters of P stay in the Infinity Cache.
+#pragma once
+#include "w3_predict.h"
+
+namespace w3 {
+
+#define W3_APM_WAVES 4
+#define W3_APM_TBL (256 * 33)
+#define W3_APM_PF 4   // rounds whose loads are in flight together
+
+struct ApmArgs {
+    const uint8_t *in;
+    uint64_t n;
+    uint32_t block_size, nblocks;
+    const uint16_t *src[4];    // k_apm0: L input streams (8 x u16 per input byte); k_apm1: unused
+    uint16_t *P;               // the stage's output stream (k_apm1: input as well, in place)
+    const int16_t *stretch;    // [4096]
+    const uint16_t *squash;    // [4095]
+    uint32_t rate;
+    const uint2 *rec;          // k_apm1: records sorted by c1 (k_partition<1>)
+    const uint32_t *splits;    // k_apm1: [nblocks][W3_SLICES + 1]
+    uint32_t *job_counter;     // k_apm1
+};
+
+// LDS pointers keep their address space (a generic pointer turns every access into a flat_* instruction).
+// Lanes of one wave communicate through the table: ordering comes from the hardware (LDS executes one wave's
+// instructions in order) plus a compiler barrier wherever one lane group's write must precede another's read.
+typedef __attribute__((address_space(3))) uint16_t lds_u16;
+typedef __attribute__((address_space(3))) uint32_t lds_u32;
+typedef __attribute__((address_space(3))) int16_t lds_i16;
+#define W3_LDS_FENCE() __asm__ volatile("" ::: "memory")
+
+// identity map: t[row][j] = squash((j - 16) * 128)
+__device__ __forceinline__ void apm_table_init(lds_u16 *tab, const lds_u16 *s_row, int lane) {
+    lds_u32 *t32 = (lds_u32 *)tab;
+    W3_LDS_FENCE();
+    for (uint32_t i = (uint32_t)lane; i < W3_APM_TBL / 2u; i += 64u) {
+        const uint32_t e = 2u * i;
+        t32[i] = (uint32_t)s_row[e % 33u] | ((uint32_t)s_row[(e + 1u) % 33u] << 16);
+    }
+    W3_LDS_FENCE();
+}
+
+// One round: 64 steps = 8 positions (k) x 8 bit positions (j).  Returns the refined probability of this lane's step.
+__device__ __forceinline__ uint32_t apm_round(lds_u16 *tab, const lds_i16 *s_str, uint32_t p, uint32_t row, uint32_t bit,
+                                              bool valid, uint32_t rate, int k) {
+    const uint32_t pos = (uint32_t)((int)s_str[p >> 4] + 2048) * 32u;
+    const uint32_t w = pos & 4095u, hi = w >> 11;
+    const uint32_t e = row * 33u + (pos >> 12);
+    const int target = bit ? 65535 : 0;
+    uint32_t t0 = 0u, t1 = 0u;
+#pragma unroll
+    for (int kk = 0; kk < 8; kk++) {
+        if (k == kk && valid) {
+            t0 = tab[e]; t1 = tab[e + 1u];
+            const int tv = (int)(hi ? t1 : t0);
+            tab[e + hi] = (uint16_t)(tv + ((target - tv) >> rate));   // arithmetic shift = floor
+        }
+        W3_LDS_FENCE();
+    }
+    const uint32_t pa = (t0 * (4096u - w) + t1 * w) >> 12;
+    const uint32_t o = (p + 3u * pa + 2u) >> 2;
+    return o < 1u ? 1u : o > 65535u ? 65535u : o;
+}
+
+template <int L>
+__global__ void __launch_bounds__(64 * W3_APM_WAVES) k_apm0(ApmArgs a) {
+    __shared__ uint16_t s_tab[W3_APM_WAVES][W3_APM_TBL];
+    __shared__ int16_t s_str[4096];
+    __shared__ uint16_t s_row[34];
+    for (uint32_t i = threadIdx.x; i < 4096u; i += blockDim.x) s_str[i] = a.stretch[i];
+    if (threadIdx.x < 33u) {
+        int d = ((int)threadIdx.x - 16) * 128;
+        d = d < -2047 ? -2047 : d > 2047 ? 2047 : d;
+        s_row[threadIdx.x] = a.squash[d + 2047];
+    }
+    __syncthreads();
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, k = lane >> 3, j = lane & 7;
+    lds_u16 *tab = (lds_u16 *)&s_tab[wave][0];
+    const lds_i16 *l_str = (const lds_i16 *)&s_str[0];
+    const lds_u16 *l_row = (const lds_u16 *)&s_row[0];
+    const uint32_t b = blockIdx.x * W3_APM_WAVES + wave;
+    if (b >= a.nblocks) return;   // (no barrier below)
+    apm_table_init(tab, l_row, lane);
+    const uint64_t off = (uint64_t)b * a.block_size;
+    const uint32_t len = (uint32_t)((a.n - off) < a.block_size ? (a.n - off) : a.block_size);
+    const uint32_t last = len - 1u;
+    const uint8_t *blk = a.in + off;
+    uint16_t *out = a.P + off * 8u;
+    // operands of W3_APM_PF rounds are loaded one batch ahead, unconditionally (index clamped; see k_coder_fast)
+    uint32_t pn[W3_APM_PF][L], bn[W3_APM_PF];
+#pragma unroll
+    for (int r = 0; r < W3_APM_PF; r++) {
+        const uint32_t ic = min((uint32_t)(r * 8 + k), last);
+        bn[r] = blk[ic];
+#pragma unroll
+        for (int l = 0; l < L; l++) pn[r][l] = a.src[l][(off + ic) * 8u + (uint32_t)j];
+    }
+    for (uint32_t base = 0; base < len; base += 8u * W3_APM_PF) {
+        uint32_t pc[W3_APM_PF][L], bc[W3_APM_PF];
+#pragma unroll
+        for (int r = 0; r < W3_APM_PF; r++) {
+            bc[r] = bn[r];
+#pragma unroll
+            for (int l = 0; l < L; l++) pc[r][l] = pn[r][l];
+        }
+#pragma unroll
+        for (int r = 0; r < W3_APM_PF; r++) {
+            const uint32_t ic = min(base + (uint32_t)((W3_APM_PF + r) * 8 + k), last);
+            bn[r] = blk[ic];
+#pragma unroll
+            for (int l = 0; l < L; l++) pn[r][l] = a.src[l][(off + ic) * 8u + (uint32_t)j];
+        }
+#pragma unroll
+        for (int r = 0; r < W3_APM_PF; r++) {
+            if (base + (uint32_t)(r * 8) >= len) break;
+            const uint32_t i = base + (uint32_t)(r * 8 + k);
+            const bool valid = i < len;
+            uint32_t p = pc[r][0];
+            if constexpr (L > 1) {   // OpinionMixer2 over the leaves: leftmost of maximal |p - 1/2| (models/mod.rs:67-69)
+                uint32_t d = opinion_dist(p);
+#pragma unroll
+                for (int l = 1; l < L; l++) {
+                    const uint32_t q = pc[r][l], dq = opinion_dist(q);
+                    if (dq > d) { p = q; d = dq; }
+                }
+            }
+            const uint32_t byte = bc[r];
+            const uint32_t c0 = (1u << j) | (byte >> (8 - j));        // partial byte with a leading 1
+            const uint32_t bit = (byte >> (7 - j)) & 1u;
+            const uint32_t o = apm_round(tab, l_str, p, c0, bit, valid, a.rate, k);
+            if (valid) out[(uint64_t)i * 8u + (uint32_t)j] = (uint16_t)o;
+        }
+    }
+}
+
+__global__ void __launch_bounds__(64 * W3_APM_WAVES) k_apm1(ApmArgs a) {
+    __shared__ uint16_t s_tab[W3_APM_WAVES][W3_APM_TBL];
+    __shared__ int16_t s_str[4096];
+    __shared__ uint16_t s_row[34];
+    for (uint32_t i = threadIdx.x; i < 4096u; i += blockDim.x) s_str[i] = a.stretch[i];
+    if (threadIdx.x < 33u) {
+        int d = ((int)threadIdx.x - 16) * 128;
+        d = d < -2047 ? -2047 : d > 2047 ? 2047 : d;
+        s_row[threadIdx.x] = a.squash[d + 2047];
+    }
+    __syncthreads();
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, k = lane >> 3, j = lane & 7;
+    lds_u16 *tab = (lds_u16 *)&s_tab[wave][0];
+    const lds_i16 *l_str = (const lds_i16 *)&s_str[0];
+    const lds_u16 *l_row = (const lds_u16 *)&s_row[0];
+    const uint32_t njobs = a.nblocks * W3_SLICES;
+    for (;;) {
+        uint32_t job = 0;
+        if (lane == 0) job = atomicAdd(a.job_counter, 1u);
+        job = __builtin_amdgcn_readfirstlane(job);
+        if (job >= njobs) break;
+        const uint32_t b = job / W3_SLICES, sl = job % W3_SLICES;
+        const uint64_t off = (uint64_t)b * a.block_size;
+        const uint32_t *sp = a.splits + (uint64_t)b * (W3_SLICES + 1u);
+        const uint32_t lo = sp[sl], hi_e = sp[sl + 1];
+        if (lo >= hi_e) continue;
+        const uint32_t len = hi_e - lo, last = len - 1u;
+        const uint2 *rec = a.rec + off + lo;
+        uint16_t *P = a.P + off * 8u;
+        uint32_t open_g = 0xFFFFFFFFu;   // the group the table describes (none yet)
+        // two-level pipeline: records two batches ahead, the P gathers they address one batch ahead
+        uint2 rn[W3_APM_PF], rnn[W3_APM_PF];
+        uint32_t pn[W3_APM_PF];
+#pragma unroll
+        for (int r = 0; r < W3_APM_PF; r++) {
+            rn[r] = rec[min((uint32_t)(r * 8 + k), last)];
+            rnn[r] = rec[min((uint32_t)((W3_APM_PF + r) * 8 + k), last)];
+        }
+#pragma unroll
+        for (int r = 0; r < W3_APM_PF; r++) pn[r] = P[(uint64_t)rn[r].x * 8u + (uint32_t)j];
+        for (uint32_t base = 0; base < len; base += 8u * W3_APM_PF) {
+            uint2 rc[W3_APM_PF];
+            uint32_t pc[W3_APM_PF];
+#pragma unroll
+            for (int r = 0; r < W3_APM_PF; r++) { rc[r] = rn[r]; pc[r] = pn[r]; rn[r] = rnn[r]; }
+#pragma unroll
+            for (int r = 0; r < W3_APM_PF; r++) rnn[r] = rec[min(base + (uint32_t)((2 * W3_APM_PF + r) * 8 + k), last)];
+#pragma unroll
+            for (int r = 0; r < W3_APM_PF; r++) pn[r] = P[(uint64_t)rn[r].x * 8u + (uint32_t)j];
+#pragma unroll
+            for (int r = 0; r < W3_APM_PF; r++) {
+                if (base + (uint32_t)(r * 8) >= len) break;
+                const uint32_t e = base + (uint32_t)(r * 8 + k);
+                const bool valid = e < len;
+                const uint32_t wv = rc[r].y, byte = wv & 0xFFu, g = (wv >> 8) & 0xFFu;
+                const uint32_t c0 = (1u << j) | (byte >> (8 - j));
+                const uint32_t bit = (byte >> (7 - j)) & 1u;
+                const uint32_t p = pc[r];
+                // groups (previous byte c1) are contiguous and time ordered; each starts from a fresh table
+                const uint64_t vm = __ballot(valid);
+                const uint64_t same = __ballot(valid && g == open_g);
+                uint32_t o;
+                if (same == vm) {
+                    o = apm_round(tab, l_str, p, c0, bit, valid, a.rate, k);
+                } else {
+                    // a group boundary inside the round: commit position by position, re-initialising between groups
+                    const uint32_t pos = (uint32_t)((int)l_str[p >> 4] + 2048) * 32u;
+                    const uint32_t w = pos & 4095u, hi = w >> 11;
+                    const uint32_t ent = c0 * 33u + (pos >> 12);
+                    const int target = bit ? 65535 : 0;
+                    uint32_t t0 = 0u, t1 = 0u;
+#pragma unroll 1
+                    for (int kk = 0; kk < 8; kk++) {
+                        if (!((vm >> (kk * 8)) & 1ull)) break;
+                        const uint32_t gk = readlane_u32(g, kk * 8);
+                        if (gk != open_g) { apm_table_init(tab, l_row, lane); open_g = gk; }
+                        if (k == kk) {
+                            t0 = tab[ent]; t1 = tab[ent + 1u];
+                            const int tv = (int)(hi ? t1 : t0);
+                            tab[ent + hi] = (uint16_t)(tv + ((target - tv) >> a.rate));
+                        }
+                        W3_LDS_FENCE();
+                    }
+                    const uint32_t pa = (t0 * (4096u - w) + t1 * w) >> 12;
+                    o = (p + 3u * pa + 2u) >> 2;
+                    o = o < 1u ? 1u : o > 65535u ? 65535u : o;
+                }
+                if (valid) P[(uint64_t)rc[r].x * 8u + (uint32_t)j] = (uint16_t)o;
+            }
+        }
+    }
+}
+
+}  // namespace w3

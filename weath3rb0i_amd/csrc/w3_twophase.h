@@ -11,6 +11,7 @@
 #include <cstdlib>
 #include <string>
 
+#include "w3_apm.h"
 #include "w3_coder.h"
 #include "w3_predict.h"
 #include "w3_spec.h"
@@ -22,6 +23,8 @@ struct TwoPhaseWs {
     bool P_valid = false;      // ws.P holds the merged stream of the last predict
     void *dbg = nullptr;       // 8 x u64 phase stamps of the last wide predict kernel (W3_OPT_DEBUG_STAMPS)
     int debug_stamps = 0;
+    const int16_t *stretch = nullptr;   // APM LUTs (device; owned by the ctx)
+    const uint16_t *squash = nullptr;
     int coder_mode = 0;        // 0 = k_coder_x3 (mix+recurrence+output waves), 1 = k_coder_fast, 2 = k_coder only, 3 = k_coder_x2
     uint32_t acc_limit = 46;   // test hook: lower values force the fast coder's fallback
     void release() {
@@ -64,6 +67,7 @@ static inline int leaf_class(const w3_node &nd) {
 
 static inline bool twophase_supported(const ParsedSpec &ps, size_t block_size, size_t n) {
     if (block_size > (1u << 24) || n < 4) return false;   // the window loads read 4 bytes at once
+    if (ps.has_slot) return false;                        // slot-state leaves: k_cm
     for (int l = 0; l < ps.n_leaves; l++)
         if (leaf_class(ps.leaf[l]) == LEAF_NONE) return false;
     return true;
@@ -193,14 +197,76 @@ static inline int twophase_predict(TwoPhaseWs &ws, hipStream_t s, const ParsedSp
     return W3_OK;
 }
 
+// APM chain at the root (w3_apm.h): turns the leaves' streams into the final stream ws.P, stage by stage.
+static inline int twophase_apm(TwoPhaseWs &ws, hipStream_t s, const ParsedSpec &ps, const uint8_t *d_in, size_t n, size_t block_size,
+                               uint32_t nb, hipEvent_t *ev, w3_timing *tm, std::string &err) {
+    if (ps.n_apm == 0) return W3_OK;
+    if (!ws.stretch || !ws.squash) { err = "APM LUTs not staged"; return W3_E_HIP; }
+    int rc = tp_ensure(ws.P, ws.P_cap, n * 16, err);
+    if (rc) return rc;
+    if (ev) (void)hipEventRecord(ev[8], s);
+    uint64_t bytes = 0;
+    bool partitioned = false;
+    for (int k = 0; k < ps.n_apm; k++) {
+        w3::ApmArgs aa;
+        memset(&aa, 0, sizeof aa);
+        aa.in = d_in; aa.n = n; aa.block_size = (uint32_t)block_size; aa.nblocks = nb;
+        aa.P = (uint16_t *)ws.P; aa.stretch = ws.stretch; aa.squash = ws.squash; aa.rate = ps.apm[k].max_bits;
+        if (ps.apm[k].align == W3_APM_ORDER0) {
+            int L = 1;
+            if (ws.P_valid) aa.src[0] = (const uint16_t *)ws.P;
+            else if (ws.mix.n_src <= 4) { L = ws.mix.n_src; for (int l = 0; l < L; l++) aa.src[l] = (const uint16_t *)ws.mix.src[l]; }
+            else { if ((rc = twophase_mix(ws, s, n, err))) return rc; aa.src[0] = (const uint16_t *)ws.P; bytes += n * 16 * (ws.mix.n_src + 1); }
+            const dim3 grid((nb + W3_APM_WAVES - 1) / W3_APM_WAVES), blk(64 * W3_APM_WAVES);
+            switch (L) {
+            case 1: hipLaunchKernelGGL(w3::k_apm0<1>, grid, blk, 0, s, aa); break;
+            case 2: hipLaunchKernelGGL(w3::k_apm0<2>, grid, blk, 0, s, aa); break;
+            case 3: hipLaunchKernelGGL(w3::k_apm0<3>, grid, blk, 0, s, aa); break;
+            default: hipLaunchKernelGGL(w3::k_apm0<4>, grid, blk, 0, s, aa); break;
+            }
+            bytes += n * (16 * (uint64_t)L + 1 + 16);
+        } else {
+            if (!ws.P_valid) { if ((rc = twophase_mix(ws, s, n, err))) return rc; bytes += n * 16 * (ws.mix.n_src + 1); }
+            if ((rc = tp_ensure(ws.splits, ws.splits_cap, (size_t)nb * (W3_SLICES + 1) * 4 + 64, err))) return rc;
+            uint32_t *job_counter = (uint32_t *)ws.splits + (size_t)nb * (W3_SLICES + 1);
+            if (!partitioned) {   // records sorted by the previous byte (the leaves' own partitions may have reused ws.rec since)
+                const uint32_t grid_wide = std::min<uint32_t>(nb, 256 * 16);
+                if ((rc = tp_ensure(ws.perm, ws.perm_cap, (size_t)grid_wide * 2 * block_size * 8, err))) return rc;
+                if ((rc = tp_ensure(ws.rec, ws.rec_cap, n * 8, err))) return rc;
+                w3::PredictArgs pa;
+                memset(&pa, 0, sizeof pa);
+                pa.in = d_in; pa.n = n; pa.block_size = (uint32_t)block_size; pa.nblocks = nb;
+                pa.perm = (uint32_t *)ws.perm; pa.rec = (uint2 *)ws.rec; pa.splits = (uint32_t *)ws.splits; pa.job_counter = job_counter;
+                hipLaunchKernelGGL(w3::k_partition<1>, dim3(grid_wide), dim3(64), 0, s, pa);
+                partitioned = true;
+                bytes += n * (4 + 32);
+            }
+            (void)hipMemsetAsync(job_counter, 0, 4, s);
+            aa.rec = (const uint2 *)ws.rec; aa.splits = (const uint32_t *)ws.splits; aa.job_counter = job_counter;
+            const uint32_t grid = std::min<uint32_t>((nb * W3_SLICES + W3_APM_WAVES - 1) / W3_APM_WAVES, 512u);   // 2 workgroups per CU: ~128 blocks live
+            hipLaunchKernelGGL(w3::k_apm1, dim3(grid), dim3(64 * W3_APM_WAVES), 0, s, aa);
+            bytes += n * (8 + 16 + 16);
+        }
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) { err = std::string("apm launch: ") + hipGetErrorString(e); return W3_E_HIP; }
+        ws.P_valid = true;
+    }
+    memset(&ws.mix, 0, sizeof ws.mix);
+    ws.mix.src[0] = (const uint4 *)ws.P; ws.mix.n_src = 1; ws.mix.P = (uint4 *)ws.P; ws.mix.n = n;
+    if (ev) (void)hipEventRecord(ev[9], s);
+    if (tm) tm->predict_bytes += bytes;
+    return W3_OK;
+}
+
 static inline int twophase_encode(TwoPhaseWs &ws, hipStream_t s, const ParsedSpec &ps, const uint8_t *d_in, size_t n, size_t block_size,
                                   uint32_t nb, uint8_t *stripes, uint32_t stripe_cap, uint32_t *d_lens, uint32_t *d_flag, hipEvent_t *ev,
                                   w3_timing *tm, std::string &err) {
     int n_live = 0;
     for (int l = 0; l < ps.n_leaves; l++) n_live += leaf_class(ps.leaf[l]) != LEAF_FROZEN;
-    const bool x3 = ws.coder_mode == 0 && n_live <= 4;   // more leaves: merge with k_mix first, then k_coder_x2
-    int rc = twophase_predict(ws, s, ps, d_in, n, block_size, nb, !x3, nullptr, ev, tm, err);
+    const bool x3 = ws.coder_mode == 0 && (n_live <= 4 || ps.n_apm > 0);   // more leaves: merge with k_mix first, then k_coder_x2
+    int rc = twophase_predict(ws, s, ps, d_in, n, block_size, nb, !x3 && ps.n_apm == 0, nullptr, ev, tm, err);
     if (rc) return rc;
+    if ((rc = twophase_apm(ws, s, ps, d_in, n, block_size, nb, ev, tm, err))) return rc;   // leaves ws.P as the one source stream
     if (getenv("W3_DEBUG_NOSTORE")) { err = "W3_DEBUG_NOSTORE: predict-only timing experiment"; return W3_E_UNSUPPORTED; }
     if ((rc = tp_ensure(ws.redo, ws.redo_cap, (size_t)nb * 4, err))) return rc;
     const uint32_t limit = std::min<uint32_t>(ws.acc_limit, 46u);

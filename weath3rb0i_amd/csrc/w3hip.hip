@@ -35,7 +35,7 @@ struct w3_ctx {
     int opt_path = W3_PATH_AUTO;
     int opt_timing = 0;
     w3_timing timing{};
-    hipEvent_t ev[8]{};
+    hipEvent_t ev[10]{};
     // workspace
     DevBuf tables, stripes, lens, offs, total, flag, io_in, io_out, coffs, misc, cm_luts;
     TwoPhaseWs tp;
@@ -452,8 +452,13 @@ extern "C" int w3_encode_blocks_device(w3_ctx *ctx, const w3_model_spec *spec, c
     if (!d_in || !d_out || !d_block_lens) return W3_E_INVALID;
     ENSURE(ctx, ctx->flag, 16);
 
-    bool two = !ps.is_cm() && twophase_supported(ps, block_size, n);
+    bool two = twophase_supported(ps, block_size, n);   // Counter leaves + APM chain; slot-state leaves run on k_cm
     if (ctx->opt_path == W3_PATH_GENERIC) two = false;
+    if (two && ps.n_apm) {
+        CmArgs lut;
+        if ((rc = cm_luts(ctx, s, lut))) return rc;
+        ctx->tp.stretch = lut.stretch; ctx->tp.squash = lut.squash;
+    }
     if (ctx->opt_path == W3_PATH_TWOPHASE && !two) { ctx->err = "spec/block size not covered by the two-phase path"; return W3_E_UNSUPPORTED; }
 
     Timer tm{ctx, s, 0};
@@ -502,7 +507,10 @@ extern "C" int w3_encode_blocks_device(w3_ctx *ctx, const w3_model_spec *spec, c
     HIPCHK(ctx, hipStreamSynchronize(s));
     if (ctx->opt_timing) {
         if (!two) ctx->timing.generic_ms = elapsed(ctx, 0);
-        else { ctx->timing.predict_ms = elapsed(ctx, 0); ctx->timing.coder_ms = elapsed(ctx, 1); ctx->timing.coder_bytes += total; }
+        else {
+            ctx->timing.predict_ms = elapsed(ctx, 0); ctx->timing.coder_ms = elapsed(ctx, 1); ctx->timing.coder_bytes += total;
+            ctx->timing.apm_ms = ps.n_apm ? elapsed(ctx, 4) : 0.f;
+        }
         ctx->timing.pack_ms = elapsed(ctx, 2);
         ctx->timing.total_ms = elapsed(ctx, 3);
     }
@@ -663,15 +671,22 @@ extern "C" int w3_predict_blocks(w3_ctx *ctx, const w3_model_spec *spec, const u
     if ((rc = parse_spec(spec, ps))) return rc;
     if (n == 0) return W3_OK;
     if (!in || !p_out) return W3_E_INVALID;
-    if (ps.is_cm() || !twophase_supported(ps, block_size, n)) { ctx->err = "spec not covered by the two-phase predict kernels"; return W3_E_UNSUPPORTED; }
+    if (!twophase_supported(ps, block_size, n)) { ctx->err = "spec not covered by the two-phase predict kernels"; return W3_E_UNSUPPORTED; }
     HIPCHK(ctx, hipSetDevice(ctx->device));
     hipStream_t s = ctx->stream;
+    if (ps.n_apm) {
+        CmArgs lut;
+        if ((rc = cm_luts(ctx, s, lut))) return rc;
+        ctx->tp.stretch = lut.stretch; ctx->tp.squash = lut.squash;
+    }
     const uint32_t nb = (uint32_t)((n + block_size - 1) / block_size);
     ENSURE(ctx, ctx->io_in, n);
     HIPCHK(ctx, hipMemcpyAsync(ctx->io_in.p, in, n, hipMemcpyHostToDevice, s));
     const uint16_t *d_p = nullptr;
-    rc = twophase_predict(ctx->tp, s, ps, (const uint8_t *)ctx->io_in.p, n, block_size, nb, true, &d_p, nullptr, &ctx->timing, ctx->err);
+    rc = twophase_predict(ctx->tp, s, ps, (const uint8_t *)ctx->io_in.p, n, block_size, nb, ps.n_apm == 0, &d_p, nullptr, &ctx->timing, ctx->err);
     if (rc) return rc;
+    if ((rc = twophase_apm(ctx->tp, s, ps, (const uint8_t *)ctx->io_in.p, n, block_size, nb, nullptr, &ctx->timing, ctx->err))) return rc;
+    d_p = (const uint16_t *)ctx->tp.P;
     HIPCHK(ctx, hipStreamSynchronize(s));
     HIPCHK(ctx, hipMemcpy(p_out, d_p, n * 16, hipMemcpyDeviceToHost));
     return W3_OK;
