@@ -89,7 +89,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--model", default="order012", help="order0 | order01 | order012 | default | order012apm | fullcm")
+    ap.add_argument("--model", default="order012apm", help="order0 | order01 | order012 | default | order012apm (BASELINE configs[1]) | fullcm (configs[2])")
     ap.add_argument("--size", type=int, default=1_000_000_000, help="input bytes PER GPU (enwik9-class = 1e9)")
     ap.add_argument("--block-size", type=int, default=65536)
     ap.add_argument("--path", default="auto", help="auto | generic | twophase")

@@ -63,7 +63,6 @@ NAMES = ["slot0", "slot1", "slot2", "slot3_tiny_table", "slot7", "slot2_hashmap_
          "apm_rate1", "o012_apm", "apm_chain4", "slot_mix", "apm_frozen", "apm_main_default", "full_cm", "full_cm_small_tables"]
 
 
-TWOPHASE_APM = {"apm0_order0", "apm1_order0_r3", "apm_rate15", "apm_rate1", "o012_apm", "apm_chain4", "apm_frozen", "apm_main_default"}
 
 
 def check(ctx, oracle, name, data, bs, decode=True):
@@ -72,8 +71,8 @@ def check(ctx, oracle, name, data, bs, decode=True):
     want, wlens = oracle.encode_blocks(orc(), data, bs, nthreads=8)
     assert lens.tolist() == wlens.tolist(), name
     assert out.tobytes() == want.tobytes(), name
-    if name in TWOPHASE_APM and len(data) >= 4:
-        # APM chains over Counter leaves run on the two-phase path (k_apm0 / k_apm1); k_cm must agree with it
+    if len(data) >= 4:
+        # encode runs on the two-phase path (Counter kernels, k_slot, k_apm0 / k_apm1); the lane-per-block k_cm must agree with it
         assert ctx.timing()["path"] == 2, name
         ctx.set_path("generic")
         try:

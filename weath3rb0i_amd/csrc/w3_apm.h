@@ -52,6 +52,7 @@ struct ApmArgs {
 typedef __attribute__((address_space(3))) uint16_t lds_u16;
 typedef __attribute__((address_space(3))) uint32_t lds_u32;
 typedef __attribute__((address_space(3))) int16_t lds_i16;
+typedef __attribute__((address_space(3))) uint64_t lds_u64;
 #define W3_LDS_FENCE() __asm__ volatile("" ::: "memory")
 
 // identity map: t[row][j] = squash((j - 16) * 128)

@@ -14,6 +14,7 @@
 #include "w3_apm.h"
 #include "w3_coder.h"
 #include "w3_predict.h"
+#include "w3_slot.h"
 #include "w3_spec.h"
 
 struct TwoPhaseWs {
@@ -25,6 +26,9 @@ struct TwoPhaseWs {
     int debug_stamps = 0;
     const int16_t *stretch = nullptr;   // APM LUTs (device; owned by the ctx)
     const uint16_t *squash = nullptr;
+    const uint2 *st = nullptr;          // NaiveStateTable rows for the slot-state leaves (device; owned by the ctx)
+    void *slot_tables = nullptr;        // per-lane HashMaps of the slot-state leaves
+    size_t slot_tables_cap = 0;
     int coder_mode = 0;        // 0 = k_coder_x3 (mix+recurrence+output waves), 1 = k_coder_fast, 2 = k_coder only, 3 = k_coder_x2
     uint32_t acc_limit = 46;   // test hook: lower values force the fast coder's fallback
     void release() {
@@ -32,6 +36,8 @@ struct TwoPhaseWs {
         if (keys) (void)hipFree(keys);
         if (perm) (void)hipFree(perm);
         if (redo) (void)hipFree(redo);
+        if (slot_tables) (void)hipFree(slot_tables);
+        slot_tables = nullptr; slot_tables_cap = 0;
         if (streams) (void)hipFree(streams);
         if (rec) (void)hipFree(rec);
         if (splits) (void)hipFree(splits);
@@ -52,9 +58,10 @@ static inline int tp_ensure(void *&p, size_t &cap, size_t bytes, std::string &er
     return W3_OK;
 }
 
-enum { LEAF_FROZEN = 0, LEAF_SMALL = 1, LEAF_SMALL_AC = 2, LEAF_WIDE1 = 3, LEAF_WIDE2 = 4, LEAF_NONE = -1 };
+enum { LEAF_FROZEN = 0, LEAF_SMALL = 1, LEAF_SMALL_AC = 2, LEAF_WIDE1 = 3, LEAF_WIDE2 = 4, LEAF_SLOT = 5, LEAF_NONE = -1 };
 
 static inline int leaf_class(const w3_node &nd) {
+    if (nd.kind == W3_NODE_SLOT_STATE) return LEAF_SLOT;
     if (nd.frozen) return LEAF_FROZEN;
     if (nd.align != 3 || nd.bits < 3) return LEAF_NONE;
     const int H = nd.bits - 3;
@@ -67,7 +74,9 @@ static inline int leaf_class(const w3_node &nd) {
 
 static inline bool twophase_supported(const ParsedSpec &ps, size_t block_size, size_t n) {
     if (block_size > (1u << 24) || n < 4) return false;   // the window loads read 4 bytes at once
-    if (ps.has_slot) return false;                        // slot-state leaves: k_cm
+    int n_slot = 0;
+    for (int l = 0; l < ps.n_leaves; l++) n_slot += ps.leaf[l].kind == W3_NODE_SLOT_STATE;
+    if (n_slot > W3_MAX_SLOT_LEAVES) return false;
     for (int l = 0; l < ps.n_leaves; l++)
         if (leaf_class(ps.leaf[l]) == LEAF_NONE) return false;
     return true;
@@ -132,6 +141,9 @@ static inline int twophase_predict(TwoPhaseWs &ws, hipStream_t s, const ParsedSp
     uint64_t bytes = 0;
     w3::MixArgs &ma = ws.mix;
     memset(&ma, 0, sizeof ma);
+    w3::SlotArgs sa;
+    memset(&sa, 0, sizeof sa);
+    uint64_t slot_stride = 0;
     if (n_live == 0) {
         hipLaunchKernelGGL(w3::k_fill_half, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (uint4 *)ws.P, (uint64_t)n);
         bytes += n * 16;
@@ -146,6 +158,12 @@ static inline int twophase_predict(TwoPhaseWs &ws, hipStream_t s, const ParsedSp
         pa.in = d_in; pa.n = n; pa.block_size = (uint32_t)block_size; pa.nblocks = nb;
         pa.P = n_live == 1 ? (uint4 *)ws.P : (uint4 *)ws.streams + (size_t)k * n;   // a single leaf writes P directly
         ma.src[k] = pa.P;
+        if (c == LEAF_SLOT) {   // all slot-state leaves run in one k_slot launch after the Counter leaves
+            w3::SlotLeaf &sl = sa.leaf[sa.n_leaves++];
+            sl.order = nd.bits; sl.log_cells = nd.log_cells; sl.tbl_off = slot_stride; sl.P = pa.P;
+            slot_stride += 96ull << nd.log_cells;
+            continue;
+        }
         pa.hbits = nd.bits - 3;
         bytes += n * 17;
         if (c == LEAF_SMALL_AC) {
@@ -184,6 +202,29 @@ static inline int twophase_predict(TwoPhaseWs &ws, hipStream_t s, const ParsedSp
         }
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) { err = std::string("predict launch: ") + hipGetErrorString(e); return W3_E_HIP; }
+    }
+    if (sa.n_leaves) {
+        // HashMaps in HBM, one per (block, leaf), zeroed per batch of blocks; as many blocks at once as the budget allows
+        if (!ws.st) { err = "state table not staged"; return W3_E_HIP; }
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); err = "hipMemGetInfo failed"; return W3_E_HIP; }
+        uint64_t budget = std::min<uint64_t>((uint64_t)((free_b + ws.slot_tables_cap) * 0.7), 120ull << 30);
+        if (const char *ev_ = getenv("W3_SLOT_BUDGET_MB")) budget = (uint64_t)std::max(1, atoi(ev_)) << 20;   // test / tuning hook
+        uint64_t lanes = std::min<uint64_t>(budget / slot_stride, nb);
+        if (lanes < nb) lanes = lanes / 64 * 64;
+        if (lanes == 0) { err = "slot-leaf hash maps of one wavefront (" + std::to_string(slot_stride * 64) + " B) exceed the device budget"; return W3_E_NOMEM; }
+        if ((rc = tp_ensure(ws.slot_tables, ws.slot_tables_cap, (size_t)(lanes * slot_stride), err))) return rc;
+        sa.in = d_in; sa.n = n; sa.block_size = (uint32_t)block_size; sa.tables = (uint8_t *)ws.slot_tables; sa.lane_stride = slot_stride;
+        sa.st = ws.st;
+        for (uint32_t first = 0; first < nb; first += (uint32_t)lanes) {
+            const uint32_t cnt = std::min<uint32_t>((uint32_t)lanes, nb - first);
+            sa.first_block = first; sa.n_lanes = cnt;
+            (void)hipMemsetAsync(ws.slot_tables, 0, (size_t)cnt * slot_stride, s);
+            hipLaunchKernelGGL(w3::k_slot, dim3((cnt + 63) / 64, sa.n_leaves), dim3(64), 0, s, sa);
+        }
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) { err = std::string("slot predict launch: ") + hipGetErrorString(e); return W3_E_HIP; }
+        bytes += (uint64_t)sa.n_leaves * n * (1 + 16 + 2 * 192);   // 2 nibbles x (96 B read + 96 B written) per input byte
     }
     if (n_live >= 1) ma.n_src = n_live;
     if (n_live == 1) ws.P_valid = true;   // the single leaf wrote ws.P itself

@@ -452,12 +452,12 @@ extern "C" int w3_encode_blocks_device(w3_ctx *ctx, const w3_model_spec *spec, c
     if (!d_in || !d_out || !d_block_lens) return W3_E_INVALID;
     ENSURE(ctx, ctx->flag, 16);
 
-    bool two = twophase_supported(ps, block_size, n);   // Counter leaves + APM chain; slot-state leaves run on k_cm
+    bool two = twophase_supported(ps, block_size, n);   // Counter and slot-state leaves + APM chain (decode: k_generic / k_cm)
     if (ctx->opt_path == W3_PATH_GENERIC) two = false;
-    if (two && ps.n_apm) {
+    if (two && ps.is_cm()) {
         CmArgs lut;
         if ((rc = cm_luts(ctx, s, lut))) return rc;
-        ctx->tp.stretch = lut.stretch; ctx->tp.squash = lut.squash;
+        ctx->tp.stretch = lut.stretch; ctx->tp.squash = lut.squash; ctx->tp.st = lut.st;
     }
     if (ctx->opt_path == W3_PATH_TWOPHASE && !two) { ctx->err = "spec/block size not covered by the two-phase path"; return W3_E_UNSUPPORTED; }
 
@@ -674,10 +674,10 @@ extern "C" int w3_predict_blocks(w3_ctx *ctx, const w3_model_spec *spec, const u
     if (!twophase_supported(ps, block_size, n)) { ctx->err = "spec not covered by the two-phase predict kernels"; return W3_E_UNSUPPORTED; }
     HIPCHK(ctx, hipSetDevice(ctx->device));
     hipStream_t s = ctx->stream;
-    if (ps.n_apm) {
+    if (ps.is_cm()) {
         CmArgs lut;
         if ((rc = cm_luts(ctx, s, lut))) return rc;
-        ctx->tp.stretch = lut.stretch; ctx->tp.squash = lut.squash;
+        ctx->tp.stretch = lut.stretch; ctx->tp.squash = lut.squash; ctx->tp.st = lut.st;
     }
     const uint32_t nb = (uint32_t)((n + block_size - 1) / block_size);
     ENSURE(ctx, ctx->io_in, n);
