@@ -8,18 +8,18 @@
 // Like a Counter leaf, its prediction never depends on the other leaves, the mixer or the coder, and the encoder
 // knows every future context — so the leaf runs in the predict phase and leaves a u16 stream.  What is serial is
 // the table itself (hits, evictions and state walks are a function of the whole history of the block), so this
-// kernel is the north star's literal design: ONE WAVEFRONT LANE PER BLOCK, the hash map in HBM (2^log_cells x 96 B
-// per lane), the 12-bit state table staged in LDS.  Per nibble a lane
-//   * has the cell of THIS nibble staged in LDS ([6][64] x 16 B: byte-granular dynamic indexing without scratch; six
-//     16-byte loads issued one nibble earlier: the hash of the next nibble's context is a function of input bytes
+// kernel is the north star's literal design: ONE WAVEFRONT LANE PER BLOCK, the hash map in HBM (2^log_cells Cells
+// per lane, one 128-byte line each), the 12-bit state table staged in LDS.  Per nibble a lane
+//   * has the cell of THIS nibble staged in LDS ([8][64] x 16 B: byte-granular dynamic indexing without scratch; eight
+//     16-byte loads issued two nibbles earlier: the hash of the next nibble's context is a function of input bytes
 //     only) and issues the loads of the NEXT nibble's cell,
 //   * matches the tag
 //     (or evicts: the policy hashmap.rs:64-68 leaves as TODO), walks 4 states (2 dependent LDS reads per bit),
-//   * writes the cell back with six 16-byte stores, and stages the prefetched cell of the next nibble in its place
-//     (or simply keeps the LDS copy when the next nibble falls into the same cell).
+//   * writes the slot's 32-byte sector back (two 16-byte stores), and stages the prefetched cell of the next nibble in
+//     its place (or keeps the LDS copy when the next nibble falls into the same cell).
 // All slot leaves of a model run in ONE launch (blockIdx.y = leaf): 4 leaves x 239 wavefronts at enwik9 size put
-// one wavefront on nearly every SIMD, and the kernel is bound by HBM: 2 x (96 B read + 96 B written) per input byte
-// and leaf — the algorithmic figure of SURVEY §8(d).
+// one wavefront on nearly every SIMD.  Algorithmic HBM bytes: 2 x (96 B read + 96 B written) per input byte
+// and leaf; the device layout actually reads 128 B and writes 32 B per nibble.
 #pragma once
 #include "w3_apm.h"
 #include "w3_cm.h"
@@ -42,55 +42,66 @@ struct SlotArgs {
     uint64_t lane_stride;
     const uint2 *st;      // [kStSize] {prob | next0 << 16, next1 | conf << 16}
     int n_leaves;
+    uint32_t dbg_flags;   // timing experiments only (results wrong): 1 = no cell write-back, 2 = every prefetch reads cell 0
     SlotLeaf leaf[W3_MAX_SLOT_LEAVES];
 };
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));   // native vector: stays in registers (HIP's uint4 class went to scratch)
 
-// The lane's cell in LDS: dword d of lane l is s_cell[d >> 2][l].{x,y,z,w}[d & 3]; `cb` points at s_cell[0][l].
-__device__ __forceinline__ uint32_t cb_off(uint32_t d) { return (d >> 2) * 256u + (d & 3u); }
+// DEVICE LAYOUT of a Cell in HBM (this kernel's own; the reference's packed 96-byte layout, hashmap.rs:31-36, is kept
+// byte-exact by k_cm): one 128-byte line = 4 sectors of 32 bytes, sector id = slot id = 15 states as u16 (node order of
+// Slot::get_idx: node = (1 << bit_id) - 1 + nib_ctx, i.e. idx / 3) followed by the slot's 12-bit tag as u16.
+// Same logical content (4 tags + 60 12-bit states, all zero in a fresh map); a nibble then reads ONE line and rewrites
+// ONE 32-byte sector, with aligned u16 accesses instead of nibble arithmetic.
+#define W3_CELL_STRIDE 128ull
 
-struct CellRef {          // the big-endian u16 at a byte offset of the staged cell (hashmap.rs:86-97 reads exactly this)
-    uint32_t olo, ohi, lo, hi, sh;
-};
-__device__ __forceinline__ uint32_t cell_get16(lds_u32 *cb, uint32_t byte, CellRef &r) {
-    const uint32_t d = byte >> 2;
-    r.olo = cb_off(d);
-    r.ohi = cb_off(d == 23u ? 22u : d + 1u);   // byte <= 94: the pair only spills out of dword 23 never; 22 is a harmless stand-in
-    r.lo = cb[r.olo]; r.hi = cb[r.ohi];
-    r.sh = 8u * (byte & 3u);
-    const uint32_t q = (uint32_t)((((uint64_t)r.hi << 32) | r.lo) >> r.sh);
-    return ((q & 0xFFu) << 8) | ((q >> 8) & 0xFFu);
-}
-__device__ __forceinline__ void cell_put16(lds_u32 *cb, const CellRef &r, uint32_t v) {
-    const uint64_t x = ((v >> 8) & 0xFFu) | ((v & 0xFFu) << 8);
-    const uint64_t Q = (((((uint64_t)r.hi << 32) | r.lo)) & ~(0xFFFFull << r.sh)) | (x << r.sh);
-    cb[r.olo] = (uint32_t)Q;
-    cb[r.ohi] = (uint32_t)(Q >> 32);   // unchanged unless the pair straddles two dwords
-}
+// The lane's cell in LDS: chunk q (16 bytes) of lane l is s_cell[q][l]; u16 element x of the cell sits at
+// u16 offset (x >> 3) * 512 + (x & 7) from the lane's base.
+__device__ __forceinline__ uint32_t cx(uint32_t x) { return (x >> 3) * 512u + (x & 7u); }
 
-// zero the nibbles [s, s + 45) of the staged cell (the 15 states of one slot), s = 12 + 45 * id
-template <int ID>
-__device__ __forceinline__ void cell_clear_slot(lds_u32 *cb) {
-    constexpr int s = 12 + 45 * ID, e = s + 45;
-#pragma unroll
-    for (int d = s / 8; d <= (e - 1) / 8; d++) {
-        uint32_t keep = 0u;   // mask of the bits that survive (little-endian dword: byte b at bits 8b; even nibble = high half)
-#pragma unroll
-        for (int k = 0; k < 8; k++) {
-            const int nib = 8 * d + k;
-            const bool in = nib >= s && nib < e;
-            const int byte_in_dw = k >> 1, high = (k & 1) == 0;
-            if (!in) keep |= (high ? 0xF0u : 0x0Fu) << (8 * byte_in_dw);
-        }
-        if (keep == 0u) cb[cb_off(d)] = 0u;
-        else cb[cb_off(d)] &= keep;
+// Everything one nibble does on the cell staged in LDS: slot lookup (or eviction), the four state steps.
+// Returns the slot id; p[0..3] = StateTable::p of the four states BEFORE their update.
+__device__ __forceinline__ uint32_t slot_nibble(lds_u16 *cb, const lds_u64 *st, uint32_t tag, uint32_t nib, uint32_t p[4]) {
+    // Cell::get_slot (hashmap.rs:42-63): compare the tags of slot 3, 2, 1, 0 in this order
+    const uint32_t t3 = cb[cx(63u)], t2 = cb[cx(47u)], t1 = cb[cx(31u)], t0 = cb[cx(15u)];
+    int id = tag == t3 ? 3 : tag == t2 ? 2 : tag == t1 ? 1 : tag == t0 ? 0 : -1;
+    if (id < 0) {
+        // miss (hashmap.rs:64-68 TODO; policy as in w3_cm.h slot_select): victim = fewest observations in the
+        // slot's first-bit state, candidates in the order 1, 0, 2, 3; tag stored, 15 states cleared
+        const uint32_t f1 = cb[cx(16u)], f0 = cb[cx(0u)], f2 = cb[cx(32u)], f3 = cb[cx(48u)];
+        uint32_t best = (uint32_t)(st[f1] >> 48); id = 1;
+        uint32_t c = (uint32_t)(st[f0] >> 48); if (c < best) { best = c; id = 0; }
+        c = (uint32_t)(st[f2] >> 48); if (c < best) { best = c; id = 2; }
+        c = (uint32_t)(st[f3] >> 48); if (c < best) { best = c; id = 3; }
+        W3_LDS_FENCE();
+        typedef __attribute__((address_space(3))) u32x4 lds_u32x4;
+        lds_u32x4 *sec = (lds_u32x4 *)(cb + cx(16u * (uint32_t)id));
+        u32x4 z; z.x = 0u; z.y = 0u; z.z = 0u; z.w = 0u;
+        sec[0] = z;
+        z.w = tag << 16;
+        sec[64] = z;            // next chunk row: 64 lanes x 16 bytes further
+        W3_LDS_FENCE();
     }
+    // the nibble's four states (Slot::get_nib / set_nib, hashmap.rs:114-128), StateTable::p / next (state_table/mod.rs)
+    uint32_t nib_ctx = 0u;
+    const uint32_t base = 16u * (uint32_t)id;
+#pragma unroll
+    for (int bit_id = 0; bit_id < 4; bit_id++) {
+        const uint32_t bit = (nib >> (3 - bit_id)) & 1u;
+        const uint32_t x = cx(base + (1u << bit_id) - 1u + nib_ctx);   // Slot::get_idx / 3, hashmap.rs:80-84
+        const uint32_t sv = cb[x];
+        const uint64_t e = st[sv];
+        p[bit_id] = (uint32_t)e & 0xFFFFu;
+        cb[x] = (uint16_t)(bit ? ((uint32_t)(e >> 32) & 0xFFFFu) : ((uint32_t)e >> 16));
+        W3_LDS_FENCE();
+        nib_ctx = (nib_ctx << 1) | bit;
+    }
+    return (uint32_t)id;
 }
 
 __global__ void __launch_bounds__(64) k_slot(SlotArgs a) {
     __shared__ uint2 s_st[kStSize];
-    __shared__ u32x4 s_cell[6][64];
+    __shared__ u32x4 s_cell[8][64];
     __shared__ SlotLeaf s_leaf[W3_MAX_SLOT_LEAVES];
     for (uint32_t i = threadIdx.x; i < (uint32_t)kStSize; i += 64u) s_st[i] = a.st[i];
     if (threadIdx.x == 0) {
@@ -106,116 +117,82 @@ __global__ void __launch_bounds__(64) k_slot(SlotArgs a) {
     const uint32_t len = (uint32_t)((a.n - off) < a.block_size ? (a.n - off) : a.block_size);
     const uint8_t *blk = a.in + off;
     uint8_t *cells = a.tables + (uint64_t)lane * a.lane_stride + lf.tbl_off;
-    uint4 *Pout = lf.P + off;
-    lds_u32 *cb = (lds_u32 *)&s_cell[0][threadIdx.x];
+    // (lf came through LDS: without the explicit address space the stream stores become flat_store, which forces vmcnt(0) waits)
+    typedef __attribute__((address_space(1))) u32x4 g_u32x4;
+    g_u32x4 *Pout = (g_u32x4 *)(lf.P + off);
+    lds_u16 *cb = (lds_u16 *)&s_cell[0][threadIdx.x];
     const lds_u64 *st = (const lds_u64 *)&s_st[0];   // {prob | next0 << 16, next1 | conf << 16} as one 64-bit LDS read
     const uint32_t order = lf.order, lshift = 64u - lf.log_cells;
+    const uint32_t last = len - 1u;
 
+    // Software pipeline over the nibbles ("events"; event e = nibble e & 1 of byte e >> 1).  The cell of event e is staged
+    // in LDS; the cells of e+1 and e+2 are in flight / in registers (B[half of the event]); the loads of e+2 are issued
+    // when e starts.  A prefetched cell is stale if an event processed after its loads were issued wrote the same cell:
+    // e+1's cell equal to e's (take the LDS copy) or to e-1's (take G, e-1's cell as it was written back).
+    // Every global load and store below is unconditional and their number per event is fixed: hipcc waits vmcnt(0) —
+    // i.e. for the prefetches just issued — as soon as a branch makes the count of outstanding operations uncertain.
+    uint32_t b0 = blk[0], b1 = blk[min(1u, last)], b2 = blk[min(2u, last)];
     uint64_t hist = 0ull;
-    uint64_t h = slot_hash(order, 0ull, false, 0u);
-    uint64_t cidx = h >> lshift;
-    {   // invariant of the loop below: the lane's LDS staging area holds the cell of the current nibble
-        const u32x4 *cp = reinterpret_cast<const u32x4 *>(cells + cidx * 96ull);
-        u32x4 cur[6];
+    uint64_t h_cur = slot_hash(order, 0ull, false, 0u), h_1 = slot_hash(order, 0ull, true, b0 >> 4);
+    uint64_t c_cur = h_cur >> lshift, c_1 = h_1 >> lshift, c_prev = ~0ull;
+    u32x4 B0[8], B1[8], G0[8], G1[8];
+    {
+        const u32x4 *cp = reinterpret_cast<const u32x4 *>(cells + c_cur * W3_CELL_STRIDE);
+        const u32x4 *cq = reinterpret_cast<const u32x4 *>(cells + c_1 * W3_CELL_STRIDE);
 #pragma unroll
-        for (int q = 0; q < 6; q++) cur[q] = cp[q];
+        for (int q = 0; q < 8; q++) { B0[q] = cp[q]; B1[q] = cq[q]; G0[q] = 0u; G1[q] = 0u; }
 #pragma unroll
-        for (int q = 0; q < 6; q++) s_cell[q][threadIdx.x] = cur[q];
+        for (int q = 0; q < 8; q++) s_cell[q][threadIdx.x] = B0[q];
         W3_LDS_FENCE();
     }
-    const uint32_t last = len - 1u;
-    uint32_t nbyte = blk[0];
     for (uint32_t i = 0; i < len; i++) {
-        const uint32_t byte = nbyte;
-        nbyte = blk[min(i + 1u, last)];
+        const uint32_t byte = b0;
+        const uint32_t b3 = blk[min(i + 3u, last)];
         uint32_t pw[4];
 #pragma unroll
         for (int half = 0; half < 2; half++) {
-            // the next nibble's cell: loads in flight while this nibble is processed
-            const uint64_t hn = half == 0 ? slot_hash(order, hist, true, byte >> 4) : slot_hash(order, (hist << 8) | byte, false, 0u);
-            const uint64_t cidx_n = hn >> lshift;
-            u32x4 nxt[6];
+            u32x4 (&Bn)[8] = half == 0 ? B1 : B0;    // the cell of e+1 (loaded while e-1 ran)
+            u32x4 (&Bl)[8] = half == 0 ? B0 : B1;    // receives the cell of e+2
+            u32x4 (&Gp)[8] = half == 0 ? G1 : G0;    // e-1's cell as written back
+            u32x4 (&Gc)[8] = half == 0 ? G0 : G1;    // receives e's
+            const uint64_t h_2 = half == 0 ? slot_hash(order, (hist << 8) | byte, false, 0u)
+                                           : slot_hash(order, (hist << 8) | byte, true, b1 >> 4);
+            const uint64_t c_2 = h_2 >> lshift;
             {
-                const u32x4 *cp = reinterpret_cast<const u32x4 *>(cells + cidx_n * 96ull);
+                const u32x4 *cp = reinterpret_cast<const u32x4 *>(cells + ((a.dbg_flags & 2u) ? 0ull : c_2) * W3_CELL_STRIDE);
 #pragma unroll
-                for (int q = 0; q < 6; q++) nxt[q] = cp[q];
+                for (int q = 0; q < 8; q++) Bl[q] = cp[q];
             }
             W3_LDS_FENCE();
-            // Cell::get_slot (hashmap.rs:42-63): the four 12-bit tags are the big-endian bytes 0..5; compare id 3, 2, 1, 0
-            const uint32_t tag = (uint32_t)h & 0xFFFu;
-            const uint32_t tw0 = cb[cb_off(0)], tw1 = cb[cb_off(1)];
-            const uint64_t hc = ((uint64_t)__builtin_bswap32(tw0) << 16) | (__builtin_bswap32(tw1) >> 16);
-            int id = -1;
-            if (tag == (uint32_t)(hc & 0xFFFu)) id = 3;
-            else if (tag == (uint32_t)((hc >> 12) & 0xFFFu)) id = 2;
-            else if (tag == (uint32_t)((hc >> 24) & 0xFFFu)) id = 1;
-            else if (tag == (uint32_t)((hc >> 36) & 0xFFFu)) id = 0;
-            if (id < 0) {
-                // miss (hashmap.rs:64-68 TODO; policy as in w3_cm.h slot_select): victim = fewest observations in the
-                // slot's first-bit state, candidates in the order 1, 0, 2, 3; tag stored, 15 states cleared
-                uint32_t best = 0xFFFFFFFFu;
-                const int cand[4] = {1, 0, 2, 3};
-#pragma unroll
-                for (int k = 0; k < 4; k++) {
-                    const uint32_t idx = 45u * (uint32_t)cand[k];
-                    CellRef r;
-                    const uint32_t v = cell_get16(cb, 6u + (idx >> 1), r);
-                    const uint32_t s0 = (idx & 1u) ? (v & 0xFFFu) : (v >> 4);
-                    const uint32_t conf = (uint32_t)(st[s0] >> 48);
-                    if (conf < best) { best = conf; id = cand[k]; }
-                }
-                const uint32_t shv = 12u * (3u - (uint32_t)id);
-                const uint64_t hc2 = (hc & ~(0xFFFull << shv)) | ((uint64_t)tag << shv);
-                // bytes 0..5 back (big-endian), bytes 6, 7 of dword 1 kept
-                W3_LDS_FENCE();
-                cb[cb_off(0)] = __builtin_bswap32((uint32_t)(hc2 >> 16));
-                cb[cb_off(1)] = (tw1 & 0xFFFF0000u) | (__builtin_bswap32((uint32_t)(hc2 << 16)) & 0x0000FFFFu);
-                W3_LDS_FENCE();
-                switch (id) {
-                case 0: cell_clear_slot<0>(cb); break;
-                case 1: cell_clear_slot<1>(cb); break;
-                case 2: cell_clear_slot<2>(cb); break;
-                default: cell_clear_slot<3>(cb); break;
-                }
-                W3_LDS_FENCE();
-            }
-            // the nibble's four states (Slot::get_nib / set_nib, hashmap.rs:114-128), StateTable::p / next (state_table/mod.rs)
-            const uint32_t nib = half == 0 ? (byte >> 4) : (byte & 15u);
-            uint32_t nib_ctx = 0u, pq[4];
-#pragma unroll
-            for (int bit_id = 0; bit_id < 4; bit_id++) {
-                const uint32_t bit = (nib >> (3 - bit_id)) & 1u;
-                const uint32_t idx = (3u << bit_id) + 3u * nib_ctx + 45u * (uint32_t)id - 3u;   // Slot::get_idx, hashmap.rs:80-84
-                CellRef r;
-                const uint32_t v = cell_get16(cb, 6u + (idx >> 1), r);
-                const uint32_t sv = (idx & 1u) ? (v & 0xFFFu) : (v >> 4);
-                const uint64_t e = st[sv];
-                pq[bit_id] = (uint32_t)e & 0xFFFFu;
-                const uint32_t ns = bit ? ((uint32_t)(e >> 32) & 0xFFFFu) : ((uint32_t)e >> 16);
-                cell_put16(cb, r, (idx & 1u) ? ((v & 0xF000u) | ns) : ((ns << 4) | (v & 0xFu)));
-                W3_LDS_FENCE();
-                nib_ctx = (nib_ctx << 1) | bit;
-            }
+            uint32_t pq[4];
+            const uint32_t id = slot_nibble(cb, st, (uint32_t)h_cur & 0xFFFu, half == 0 ? (byte >> 4) : (byte & 15u), pq);
             pw[2 * half] = pq[0] | (pq[1] << 16);
             pw[2 * half + 1] = pq[2] | (pq[3] << 16);
-            // write the cell back; the next nibble may be in the same cell: forward it from LDS
-            u32x4 g[6];
-#pragma unroll
-            for (int q = 0; q < 6; q++) g[q] = s_cell[q][threadIdx.x];
+            // write back the slot's sector (states + tag): two 16-byte stores into one line
             {
-                u32x4 *cp = reinterpret_cast<u32x4 *>(cells + cidx * 96ull);
-#pragma unroll
-                for (int q = 0; q < 6; q++) cp[q] = g[q];
+                u32x4 *cw = reinterpret_cast<u32x4 *>(cells + c_cur * W3_CELL_STRIDE);
+                const u32x4 w0 = s_cell[2u * id][threadIdx.x], w1 = s_cell[2u * id + 1u][threadIdx.x];
+                if (!(a.dbg_flags & 4u)) { cw[2u * id] = w0; cw[2u * id + 1u] = w1; }
             }
-            if (cidx_n != cidx) {
 #pragma unroll
-                for (int q = 0; q < 6; q++) s_cell[q][threadIdx.x] = nxt[q];
+            for (int q = 0; q < 8; q++) Gc[q] = s_cell[q][threadIdx.x];
+            W3_LDS_FENCE();
+            {
+                const bool from_prev = c_1 == c_prev, restage = c_1 != c_cur;
+                u32x4 v[8];
+#pragma unroll
+                for (int q = 0; q < 8; q++) v[q] = from_prev ? Gp[q] : Bn[q];
+                if (restage) {
+#pragma unroll
+                    for (int q = 0; q < 8; q++) s_cell[q][threadIdx.x] = v[q];
+                }
             }
             W3_LDS_FENCE();
-            h = hn; cidx = cidx_n;
+            c_prev = c_cur; h_cur = h_1; c_cur = c_1; h_1 = h_2; c_1 = c_2;
         }
         hist = (hist << 8) | byte;
-        Pout[i] = make_uint4(pw[0], pw[1], pw[2], pw[3]);
+        b0 = b1; b1 = b2; b2 = b3;
+        { u32x4 pv; pv.x = pw[0]; pv.y = pw[1]; pv.z = pw[2]; pv.w = pw[3]; Pout[i] = pv; }
     }
 }
 

@@ -161,7 +161,7 @@ static inline int twophase_predict(TwoPhaseWs &ws, hipStream_t s, const ParsedSp
         if (c == LEAF_SLOT) {   // all slot-state leaves run in one k_slot launch after the Counter leaves
             w3::SlotLeaf &sl = sa.leaf[sa.n_leaves++];
             sl.order = nd.bits; sl.log_cells = nd.log_cells; sl.tbl_off = slot_stride; sl.P = pa.P;
-            slot_stride += 96ull << nd.log_cells;
+            slot_stride += W3_CELL_STRIDE << nd.log_cells;
             continue;
         }
         pa.hbits = nd.bits - 3;
@@ -216,6 +216,7 @@ static inline int twophase_predict(TwoPhaseWs &ws, hipStream_t s, const ParsedSp
         if ((rc = tp_ensure(ws.slot_tables, ws.slot_tables_cap, (size_t)(lanes * slot_stride), err))) return rc;
         sa.in = d_in; sa.n = n; sa.block_size = (uint32_t)block_size; sa.tables = (uint8_t *)ws.slot_tables; sa.lane_stride = slot_stride;
         sa.st = ws.st;
+        if (const char *ev_ = getenv("W3_SLOT_DEBUG")) sa.dbg_flags = (uint32_t)atoi(ev_);   // timing experiments only
         for (uint32_t first = 0; first < nb; first += (uint32_t)lanes) {
             const uint32_t cnt = std::min<uint32_t>((uint32_t)lanes, nb - first);
             sa.first_block = first; sa.n_lanes = cnt;
