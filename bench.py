@@ -154,7 +154,7 @@ def main():
     for _ in range(args.warmup):
         step()
     ctx.set_timing(True)
-    kern_ms = {"predict_ms": 0.0, "apm_ms": 0.0, "coder_ms": 0.0, "pack_ms": 0.0, "generic_ms": 0.0}
+    kern_ms = {"predict_ms": 0.0, "slot_ms": 0.0, "apm_ms": 0.0, "coder_ms": 0.0, "pack_ms": 0.0, "generic_ms": 0.0}
     coder_bytes = 0
     launches = 0
     sync()
@@ -181,24 +181,30 @@ def main():
         ratio = total_out / n
         ms_per_step = dt / args.steps * 1e3
         value = world * n * args.steps / dt / 2**20
-        # dominant kernel: the lane-per-block coder (two-phase) or the fused generic kernel
+        # dominant kernel = the longest-running one of this model's two-phase kernels (or the fused lane-per-block kernel)
         traffic = None
+        ncnt, nslot, napm = MODEL_SHAPE[args.model]
         if path == 2:
-            dom_ms = kern_ms["coder_ms"] / launches
-            dom_bytes = coder_bytes / launches
-            dom_name = "k_coder_x3 (mix + recurrence + output wavefronts)"
+            # algorithmic HBM bytes per step: coder = streams + input + compressed bytes; k_apm0 = L streams +
+            # input + its output stream; k_slot = per leaf and input byte 2 nibbles x (96 B read + 96 B written) + input + stream
+            cands = [("k_coder_x3 (mix + recurrence + output wavefronts)", kern_ms["coder_ms"] / launches, coder_bytes / launches)]
+            if napm == 1:
+                cands.append(("k_apm0<%d> (APM stage: wave per block, table in LDS)" % (ncnt + nslot), kern_ms["apm_ms"] / args.steps,
+                              n * (16 * (ncnt + nslot) + 1 + 16)))
+            if nslot:
+                cands.append(("k_slot (slot-state leaves: lane per block, hash map in HBM; all batches of a step)",
+                              kern_ms["slot_ms"] / args.steps, nslot * n * (1 + 16 + 2 * 192)))
+            dom_name, dom_ms, dom_bytes = max(cands, key=lambda c: c[1])
             try:  # PMC-measured HBM bytes of this kernel for this exact config (profiles/, separate rocprofv3 --pmc passes)
-                tj = json.load(open(os.path.join(ROOT, "profiles", "r1_traffic.json")))
-                if tj["config"] == {"model": args.model, "bytes_per_gpu": n, "block_size": bs}:
-                    traffic = tj["traffic_bytes_per_launch"]
+                for tj in json.load(open(os.path.join(ROOT, "profiles", "r1_traffic.json")))["entries"]:
+                    if tj["config"] == {"model": args.model, "bytes_per_gpu": n, "block_size": bs} and dom_name.startswith(tj["kernel"]):
+                        traffic = tj["traffic_bytes_per_step"]
             except (OSError, KeyError, ValueError):
                 pass
         else:
             dom_ms = kern_ms["generic_ms"] / args.steps
             # A = 1 + c (stream write) + 64 B of Counter RMW per table model and input byte
-            from weath3rb0i_amd import _lib as L  # noqa: F401
             # + 384 B per slot-state leaf (2 nibbles x 96-B cell read + write) + 48 B per APM stage (8 x (4 B read + 2 B write))
-            ncnt, nslot, napm = MODEL_SHAPE[args.model]
             dom_bytes = n * (1 + ratio + 64 * ncnt + 384 * nslot + 48 * napm)
             dom_name = "k_cm" if (nslot or napm) else "k_generic"
         achieved = dom_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0

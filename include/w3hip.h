@@ -194,7 +194,9 @@ typedef struct w3_timing {
     uint64_t coder_bytes;  /* algorithmic HBM bytes of the coder launches    */
     uint64_t predict_bytes;
     uint32_t n_recoded_blocks; /* blocks the fast coder handed to the robust coder */
-    float    apm_ms;       /* APM stage kernels of the two-phase path (k_apm0 / k_apm1) */
+    float    apm_ms;       /* APM stage kernels of the two-phase path (k_apm0 / k_apm1, + k_mix / k_partition they need) */
+    float    slot_ms;      /* slot-state leaves: table zero-fill + k_slot launches (also inside predict_ms) */
+    uint32_t n_slot_launches; /* k_slot launches (block batches sized to the device memory budget) */
 } w3_timing;
 int w3_get_timing(const w3_ctx *ctx, w3_timing *out);
 

@@ -36,7 +36,7 @@ struct ApmArgs {
     const uint8_t *in;
     uint64_t n;
     uint32_t block_size, nblocks;
-    const uint16_t *src[4];    // k_apm0: L input streams (8 x u16 per input byte); k_apm1: unused
+    const uint16_t *src[8];    // k_apm0: L input streams (8 x u16 per input byte); k_apm1: unused
     uint16_t *P;               // the stage's output stream (k_apm1: input as well, in place)
     const int16_t *stretch;    // [4096]
     const uint16_t *squash;    // [4095]
@@ -67,20 +67,25 @@ __device__ __forceinline__ void apm_table_init(lds_u16 *tab, const lds_u16 *s_ro
 }
 
 // One round: 64 steps = 8 positions (k) x 8 bit positions (j).  Returns the refined probability of this lane's step.
+// The 8 positions are committed one after another WITHOUT branches: in sub-step kk every lane reads its two entries
+// (one unaligned 32-bit LDS read), lanes of position kk keep what they read and write their updated entry, all other
+// lanes write to a dummy slot behind the table (s_and_saveexec + branch per sub-step cost as much as the LDS round trip).
 __device__ __forceinline__ uint32_t apm_round(lds_u16 *tab, const lds_i16 *s_str, uint32_t p, uint32_t row, uint32_t bit,
                                               bool valid, uint32_t rate, int k) {
     const uint32_t pos = (uint32_t)((int)s_str[p >> 4] + 2048) * 32u;
     const uint32_t w = pos & 4095u, hi = w >> 11;
     const uint32_t e = row * 33u + (pos >> 12);
     const int target = bit ? 65535 : 0;
+    const uint32_t dummy = (uint32_t)W3_APM_TBL + 2u * (uint32_t)(threadIdx.x & 63u);   // 64 private u16 pairs behind the table
+    const uint32_t er = valid ? e : dummy, ew = valid ? e + hi : dummy;
     uint32_t t0 = 0u, t1 = 0u;
 #pragma unroll
     for (int kk = 0; kk < 8; kk++) {
-        if (k == kk && valid) {
-            t0 = tab[e]; t1 = tab[e + 1u];
-            const int tv = (int)(hi ? t1 : t0);
-            tab[e + hi] = (uint16_t)(tv + ((target - tv) >> rate));   // arithmetic shift = floor
-        }
+        const bool mine = k == kk;
+        const uint32_t a0 = tab[er], a1 = tab[er + 1u];   // (one unaligned ds_read_b32 instead: 44 -> 113 ms, measured)
+        t0 = mine ? a0 : t0; t1 = mine ? a1 : t1;
+        const int tv = (int)(hi ? a1 : a0);
+        tab[mine ? ew : dummy] = (uint16_t)(tv + ((target - tv) >> rate));   // arithmetic shift = floor
         W3_LDS_FENCE();
     }
     const uint32_t pa = (t0 * (4096u - w) + t1 * w) >> 12;
@@ -90,7 +95,7 @@ __device__ __forceinline__ uint32_t apm_round(lds_u16 *tab, const lds_i16 *s_str
 
 template <int L>
 __global__ void __launch_bounds__(64 * W3_APM_WAVES) k_apm0(ApmArgs a) {
-    __shared__ uint16_t s_tab[W3_APM_WAVES][W3_APM_TBL];
+    __shared__ uint16_t s_tab[W3_APM_WAVES][W3_APM_TBL + 128];   // + 64 dummy u16 pairs (apm_round)
     __shared__ int16_t s_str[4096];
     __shared__ uint16_t s_row[34];
     for (uint32_t i = threadIdx.x; i < 4096u; i += blockDim.x) s_str[i] = a.stretch[i];
@@ -160,7 +165,7 @@ __global__ void __launch_bounds__(64 * W3_APM_WAVES) k_apm0(ApmArgs a) {
 }
 
 __global__ void __launch_bounds__(64 * W3_APM_WAVES) k_apm1(ApmArgs a) {
-    __shared__ uint16_t s_tab[W3_APM_WAVES][W3_APM_TBL];
+    __shared__ uint16_t s_tab[W3_APM_WAVES][W3_APM_TBL + 128];   // + 64 dummy u16 pairs (apm_round)
     __shared__ int16_t s_str[4096];
     __shared__ uint16_t s_row[34];
     for (uint32_t i = threadIdx.x; i < 4096u; i += blockDim.x) s_str[i] = a.stretch[i];

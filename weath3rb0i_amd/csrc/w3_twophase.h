@@ -217,12 +217,15 @@ static inline int twophase_predict(TwoPhaseWs &ws, hipStream_t s, const ParsedSp
         sa.in = d_in; sa.n = n; sa.block_size = (uint32_t)block_size; sa.tables = (uint8_t *)ws.slot_tables; sa.lane_stride = slot_stride;
         sa.st = ws.st;
         if (const char *ev_ = getenv("W3_SLOT_DEBUG")) sa.dbg_flags = (uint32_t)atoi(ev_);   // timing experiments only
+        if (ev) (void)hipEventRecord(ev[10], s);
         for (uint32_t first = 0; first < nb; first += (uint32_t)lanes) {
             const uint32_t cnt = std::min<uint32_t>((uint32_t)lanes, nb - first);
             sa.first_block = first; sa.n_lanes = cnt;
             (void)hipMemsetAsync(ws.slot_tables, 0, (size_t)cnt * slot_stride, s);
             hipLaunchKernelGGL(w3::k_slot, dim3((cnt + 63) / 64, sa.n_leaves), dim3(64), 0, s, sa);
+            if (tm) tm->n_slot_launches++;
         }
+        if (ev) (void)hipEventRecord(ev[11], s);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) { err = std::string("slot predict launch: ") + hipGetErrorString(e); return W3_E_HIP; }
         bytes += (uint64_t)sa.n_leaves * n * (1 + 16 + 2 * 192);   // 2 nibbles x (96 B read + 96 B written) per input byte
@@ -257,14 +260,18 @@ static inline int twophase_apm(TwoPhaseWs &ws, hipStream_t s, const ParsedSpec &
         if (ps.apm[k].align == W3_APM_ORDER0) {
             int L = 1;
             if (ws.P_valid) aa.src[0] = (const uint16_t *)ws.P;
-            else if (ws.mix.n_src <= 4) { L = ws.mix.n_src; for (int l = 0; l < L; l++) aa.src[l] = (const uint16_t *)ws.mix.src[l]; }
+            else if (ws.mix.n_src <= 8) { L = ws.mix.n_src; for (int l = 0; l < L; l++) aa.src[l] = (const uint16_t *)ws.mix.src[l]; }
             else { if ((rc = twophase_mix(ws, s, n, err))) return rc; aa.src[0] = (const uint16_t *)ws.P; bytes += n * 16 * (ws.mix.n_src + 1); }
             const dim3 grid((nb + W3_APM_WAVES - 1) / W3_APM_WAVES), blk(64 * W3_APM_WAVES);
             switch (L) {
             case 1: hipLaunchKernelGGL(w3::k_apm0<1>, grid, blk, 0, s, aa); break;
             case 2: hipLaunchKernelGGL(w3::k_apm0<2>, grid, blk, 0, s, aa); break;
             case 3: hipLaunchKernelGGL(w3::k_apm0<3>, grid, blk, 0, s, aa); break;
-            default: hipLaunchKernelGGL(w3::k_apm0<4>, grid, blk, 0, s, aa); break;
+            case 4: hipLaunchKernelGGL(w3::k_apm0<4>, grid, blk, 0, s, aa); break;
+            case 5: hipLaunchKernelGGL(w3::k_apm0<5>, grid, blk, 0, s, aa); break;
+            case 6: hipLaunchKernelGGL(w3::k_apm0<6>, grid, blk, 0, s, aa); break;
+            case 7: hipLaunchKernelGGL(w3::k_apm0<7>, grid, blk, 0, s, aa); break;
+            default: hipLaunchKernelGGL(w3::k_apm0<8>, grid, blk, 0, s, aa); break;
             }
             bytes += n * (16 * (uint64_t)L + 1 + 16);
         } else {
