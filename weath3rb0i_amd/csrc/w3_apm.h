@@ -44,6 +44,7 @@ struct ApmArgs {
     const uint2 *rec;          // k_apm1: records sorted by c1 (k_partition<1>)
     const uint32_t *splits;    // k_apm1: [nblocks][W3_SLICES + 1]
     uint32_t *job_counter;     // k_apm1
+    uint16_t *dummy;           // [64] sink for the stores of lanes past the block end (keeps every store unconditional)
 };
 
 // LDS pointers keep their address space (a generic pointer turns every access into a flat_* instruction).
@@ -66,10 +67,20 @@ __device__ __forceinline__ void apm_table_init(lds_u16 *tab, const lds_u16 *s_ro
     W3_LDS_FENCE();
 }
 
-// One round: 64 steps = 8 positions (k) x 8 bit positions (j).  Returns the refined probability of this lane's step.
-// The 8 positions are committed one after another WITHOUT branches: in sub-step kk every lane reads its two entries
-// (one unaligned 32-bit LDS read), lanes of position kk keep what they read and write their updated entry, all other
-// lanes write to a dummy slot behind the table (s_and_saveexec + branch per sub-step cost as much as the LDS round trip).
+// lane i receives the value of lane i - 8 / i + 8 of its 16-lane DPP row (lanes without a source get 0)
+__device__ __forceinline__ uint32_t dpp_from_lane_minus8(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118 /* row_shr:8 */, 0xF, 0xF, false);
+}
+__device__ __forceinline__ uint32_t dpp_from_lane_plus8(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x108 /* row_shl:8 */, 0xF, 0xF, false);
+}
+
+// One round: 64 steps = 8 positions (k) x 8 bit positions (j), lane = 8 k + j.  Returns the refined probability of this
+// lane's step.  The positions are committed in PAIRS (2m, 2m+1), four LDS round trips per round and no branches: in a
+// sub-step every lane reads its two entries, the lanes of the pair keep what they read and write their updated entry
+// (all other lanes write to a dummy slot behind the table).  The two positions of a pair sit 8 lanes apart in one
+// 16-lane DPP row: the later one takes the earlier one's new value over row_shr:8 where their entries coincide, and the
+// earlier one leaves the store to the later one when both update the same entry.
 __device__ __forceinline__ uint32_t apm_round(lds_u16 *tab, const lds_i16 *s_str, uint32_t p, uint32_t row, uint32_t bit,
                                               bool valid, uint32_t rate, int k) {
     const uint32_t pos = (uint32_t)((int)s_str[p >> 4] + 2048) * 32u;
@@ -78,14 +89,23 @@ __device__ __forceinline__ uint32_t apm_round(lds_u16 *tab, const lds_i16 *s_str
     const int target = bit ? 65535 : 0;
     const uint32_t dummy = (uint32_t)W3_APM_TBL + 2u * (uint32_t)(threadIdx.x & 63u);   // 64 private u16 pairs behind the table
     const uint32_t er = valid ? e : dummy, ew = valid ? e + hi : dummy;
+    // hazards inside the pair (entries of an invalid lane are its private dummies: they never coincide with anything)
+    const bool odd = (k & 1) != 0;
+    const uint32_t w_prev = dpp_from_lane_minus8(ew), w_next = dpp_from_lane_plus8(ew);
+    const bool fwd0 = odd && w_prev == er, fwd1 = odd && w_prev == er + 1u;   // the earlier position writes an entry I read
+    const uint32_t ewr = (!odd && w_next == ew) ? dummy : ew;                  // the later position rewrites my entry: it stores
     uint32_t t0 = 0u, t1 = 0u;
 #pragma unroll
-    for (int kk = 0; kk < 8; kk++) {
-        const bool mine = k == kk;
-        const uint32_t a0 = tab[er], a1 = tab[er + 1u];   // (one unaligned ds_read_b32 instead: 44 -> 113 ms, measured)
+    for (int kk = 0; kk < 8; kk += 2) {
+        const bool mine = (k >> 1) == (kk >> 1);
+        uint32_t a0 = tab[er], a1 = tab[er + 1u];   // (one unaligned ds_read_b32 instead: 44 -> 113 ms, measured)
+        const int tvp = (int)(hi ? a1 : a0);
+        const uint32_t nvp = (uint32_t)(tvp + ((target - tvp) >> rate));       // arithmetic shift = floor; final on the earlier position
+        const uint32_t f = dpp_from_lane_minus8(nvp) & 0xFFFFu;
+        a0 = fwd0 ? f : a0; a1 = fwd1 ? f : a1;
         t0 = mine ? a0 : t0; t1 = mine ? a1 : t1;
         const int tv = (int)(hi ? a1 : a0);
-        tab[mine ? ew : dummy] = (uint16_t)(tv + ((target - tv) >> rate));   // arithmetic shift = floor
+        tab[mine ? ewr : dummy] = (uint16_t)(tv + ((target - tv) >> rate));
         W3_LDS_FENCE();
     }
     const uint32_t pa = (t0 * (4096u - w) + t1 * w) >> 12;
@@ -117,30 +137,20 @@ __global__ void __launch_bounds__(64 * W3_APM_WAVES) k_apm0(ApmArgs a) {
     const uint32_t last = len - 1u;
     const uint8_t *blk = a.in + off;
     uint16_t *out = a.P + off * 8u;
-    // operands of W3_APM_PF rounds are loaded one batch ahead, unconditionally (index clamped; see k_coder_fast)
-    uint32_t pn[W3_APM_PF][L], bn[W3_APM_PF];
-#pragma unroll
-    for (int r = 0; r < W3_APM_PF; r++) {
-        const uint32_t ic = min((uint32_t)(r * 8 + k), last);
-        bn[r] = blk[ic];
-#pragma unroll
-        for (int l = 0; l < L; l++) pn[r][l] = a.src[l][(off + ic) * 8u + (uint32_t)j];
-    }
-    for (uint32_t base = 0; base < len; base += 8u * W3_APM_PF) {
-        uint32_t pc[W3_APM_PF][L], bc[W3_APM_PF];
+    // Operands of W3_APM_PF rounds are loaded one batch ahead, unconditionally (index clamped; see k_coder_fast), into
+    // two register sets used alternately: rotating one set through copies at the loop top made hipcc wait for the
+    // previous batch's STORES (vmcnt counts loads and stores in one queue) before every copy.
+    uint32_t pA[W3_APM_PF][L], bA[W3_APM_PF], pB[W3_APM_PF][L], bB[W3_APM_PF];
+    auto load = [&](uint32_t (&pp)[W3_APM_PF][L], uint32_t (&bb)[W3_APM_PF], uint32_t base) {
 #pragma unroll
         for (int r = 0; r < W3_APM_PF; r++) {
-            bc[r] = bn[r];
+            const uint32_t ic = min(base + (uint32_t)(r * 8 + k), last);
+            bb[r] = blk[ic];
 #pragma unroll
-            for (int l = 0; l < L; l++) pc[r][l] = pn[r][l];
+            for (int l = 0; l < L; l++) pp[r][l] = a.src[l][(off + ic) * 8u + (uint32_t)j];
         }
-#pragma unroll
-        for (int r = 0; r < W3_APM_PF; r++) {
-            const uint32_t ic = min(base + (uint32_t)((W3_APM_PF + r) * 8 + k), last);
-            bn[r] = blk[ic];
-#pragma unroll
-            for (int l = 0; l < L; l++) pn[r][l] = a.src[l][(off + ic) * 8u + (uint32_t)j];
-        }
+    };
+    auto process = [&](const uint32_t (&pc)[W3_APM_PF][L], const uint32_t (&bc)[W3_APM_PF], uint32_t base) {
 #pragma unroll
         for (int r = 0; r < W3_APM_PF; r++) {
             if (base + (uint32_t)(r * 8) >= len) break;
@@ -159,8 +169,19 @@ __global__ void __launch_bounds__(64 * W3_APM_WAVES) k_apm0(ApmArgs a) {
             const uint32_t c0 = (1u << j) | (byte >> (8 - j));        // partial byte with a leading 1
             const uint32_t bit = (byte >> (7 - j)) & 1u;
             const uint32_t o = apm_round(tab, l_str, p, c0, bit, valid, a.rate, k);
-            if (valid) out[(uint64_t)i * 8u + (uint32_t)j] = (uint16_t)o;
+            // unconditional store (a branch around it makes hipcc wait vmcnt(0) — store latency included — before it
+            // touches the prefetched operands of the next batch)
+            uint16_t *dst = valid ? out + ((uint64_t)i * 8u + (uint32_t)j) : a.dummy + lane;
+            *dst = (uint16_t)o;
         }
+    };
+    load(pA, bA, 0u);
+    for (uint32_t base = 0; base < len; base += 16u * W3_APM_PF) {
+        load(pB, bB, base + 8u * W3_APM_PF);
+        process(pA, bA, base);
+        if (base + 8u * W3_APM_PF >= len) break;
+        load(pA, bA, base + 16u * W3_APM_PF);
+        process(pB, bB, base + 8u * W3_APM_PF);
     }
 }
 
@@ -251,7 +272,8 @@ __global__ void __launch_bounds__(64 * W3_APM_WAVES) k_apm1(ApmArgs a) {
                     o = (p + 3u * pa + 2u) >> 2;
                     o = o < 1u ? 1u : o > 65535u ? 65535u : o;
                 }
-                if (valid) P[(uint64_t)rc[r].x * 8u + (uint32_t)j] = (uint16_t)o;
+                uint16_t *dst = valid ? P + ((uint64_t)rc[r].x * 8u + (uint32_t)j) : a.dummy + lane;
+                *dst = (uint16_t)o;
             }
         }
     }

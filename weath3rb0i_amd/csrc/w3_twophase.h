@@ -27,6 +27,8 @@ struct TwoPhaseWs {
     const int16_t *stretch = nullptr;   // APM LUTs (device; owned by the ctx)
     const uint16_t *squash = nullptr;
     const uint2 *st = nullptr;          // NaiveStateTable rows for the slot-state leaves (device; owned by the ctx)
+    void *dummy = nullptr;              // 256-byte sink for predicated-off stores (w3_apm.h)
+    size_t dummy_cap = 0;
     void *slot_tables = nullptr;        // per-lane HashMaps of the slot-state leaves
     size_t slot_tables_cap = 0;
     int coder_mode = 0;        // 0 = k_coder_x3 (mix+recurrence+output waves), 1 = k_coder_fast, 2 = k_coder only, 3 = k_coder_x2
@@ -36,6 +38,8 @@ struct TwoPhaseWs {
         if (keys) (void)hipFree(keys);
         if (perm) (void)hipFree(perm);
         if (redo) (void)hipFree(redo);
+        if (dummy) (void)hipFree(dummy);
+        dummy = nullptr; dummy_cap = 0;
         if (slot_tables) (void)hipFree(slot_tables);
         slot_tables = nullptr; slot_tables_cap = 0;
         if (streams) (void)hipFree(streams);
@@ -249,6 +253,7 @@ static inline int twophase_apm(TwoPhaseWs &ws, hipStream_t s, const ParsedSpec &
     if (!ws.stretch || !ws.squash) { err = "APM LUTs not staged"; return W3_E_HIP; }
     int rc = tp_ensure(ws.P, ws.P_cap, n * 16, err);
     if (rc) return rc;
+    if ((rc = tp_ensure(ws.dummy, ws.dummy_cap, 256, err))) return rc;
     if (ev) (void)hipEventRecord(ev[8], s);
     uint64_t bytes = 0;
     bool partitioned = false;
@@ -257,6 +262,7 @@ static inline int twophase_apm(TwoPhaseWs &ws, hipStream_t s, const ParsedSpec &
         memset(&aa, 0, sizeof aa);
         aa.in = d_in; aa.n = n; aa.block_size = (uint32_t)block_size; aa.nblocks = nb;
         aa.P = (uint16_t *)ws.P; aa.stretch = ws.stretch; aa.squash = ws.squash; aa.rate = ps.apm[k].max_bits;
+        aa.dummy = (uint16_t *)ws.dummy;
         if (ps.apm[k].align == W3_APM_ORDER0) {
             int L = 1;
             if (ws.P_valid) aa.src[0] = (const uint16_t *)ws.P;
