@@ -41,8 +41,9 @@ struct SlotArgs {
     uint8_t *tables;      // lane l owns [tables + l * lane_stride, + lane_stride), zeroed before the launch
     uint64_t lane_stride;
     const uint2 *st;      // [kStSize] {prob | next0 << 16, next1 | conf << 16}
+    uint8_t *dummy;       // >= 1 KiB sink for predicated-off stores
     int n_leaves;
-    uint32_t dbg_flags;   // timing experiments only (results wrong): 1 = no cell write-back, 2 = every prefetch reads cell 0
+    uint32_t dbg_flags;   // timing experiments only (results wrong): 2 = every prefetch reads cell 0, 4 = no cell write-back
     SlotLeaf leaf[W3_MAX_SLOT_LEAVES];
 };
 
@@ -101,98 +102,128 @@ __device__ __forceinline__ uint32_t slot_nibble(lds_u16 *cb, const lds_u64 *st, 
 
 __global__ void __launch_bounds__(64) k_slot(SlotArgs a) {
     __shared__ uint2 s_st[kStSize];
-    __shared__ u32x4 s_cell[8][64];
-    __shared__ SlotLeaf s_leaf[W3_MAX_SLOT_LEAVES];
+    __shared__ u32x4 s_cell[8][64];     // [chunk][owner lane]: the cell of every lane's current nibble
+    __shared__ uint32_t s_x[3][64];     // owner -> holder mailboxes: [0] cell index to prefetch, [1] write-back word, [2] staging flag
     for (uint32_t i = threadIdx.x; i < (uint32_t)kStSize; i += 64u) s_st[i] = a.st[i];
-    if (threadIdx.x == 0) {
-#pragma unroll
-        for (int l = 0; l < W3_MAX_SLOT_LEAVES; l++) s_leaf[l] = a.leaf[l];
-    }
     __syncthreads();
-    const SlotLeaf lf = s_leaf[blockIdx.y];
-    const uint32_t lane = blockIdx.x * 64u + threadIdx.x;
-    if (lane >= a.n_lanes) return;
-    const uint32_t b = a.first_block + lane;
-    const uint64_t off = (uint64_t)b * a.block_size;
-    const uint32_t len = (uint32_t)((a.n - off) < a.block_size ? (a.n - off) : a.block_size);
-    const uint8_t *blk = a.in + off;
-    uint8_t *cells = a.tables + (uint64_t)lane * a.lane_stride + lf.tbl_off;
-    // (lf came through LDS: without the explicit address space the stream stores become flat_store, which forces vmcnt(0) waits)
     typedef __attribute__((address_space(1))) u32x4 g_u32x4;
-    g_u32x4 *Pout = (g_u32x4 *)(lf.P + off);
-    lds_u16 *cb = (lds_u16 *)&s_cell[0][threadIdx.x];
-    const lds_u64 *st = (const lds_u64 *)&s_st[0];   // {prob | next0 << 16, next1 | conf << 16} as one 64-bit LDS read
-    const uint32_t order = lf.order, lshift = 64u - lf.log_cells;
+    typedef __attribute__((address_space(3))) u32x4 lds_u32x4;
+    const uint32_t tid = threadIdx.x;
+    const SlotLeaf &lf = a.leaf[blockIdx.y];
+    const uint32_t lane0 = blockIdx.x * 64u, nl = a.n_lanes;
+    // ---- owner role: lane `tid` owns block first_block + lane0 + tid (model state, hashes, state walks) ----
+    const uint32_t olane = min(lane0 + tid, nl - 1u);                     // lanes past the batch mirror the last one, with len 0
+    const uint64_t off = (uint64_t)(a.first_block + olane) * a.block_size;
+    uint32_t len = (uint32_t)((a.n - off) < a.block_size ? (a.n - off) : a.block_size);
     const uint32_t last = len - 1u;
+    if (lane0 + tid >= nl) len = 0u;
+    const uint8_t *blk = a.in + off;
+    g_u32x4 *Pout = (g_u32x4 *)(lf.P + off);
+    g_u32x4 *sink = (g_u32x4 *)a.dummy + tid;                             // where predicated-off stores go
+    lds_u16 *cb = (lds_u16 *)&s_cell[0][tid];
+    const lds_u64 *st = (const lds_u64 *)&s_st[0];
+    const uint32_t order = lf.order, lshift = 64u - lf.log_cells;
+    uint32_t maxlen = len;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) maxlen = max(maxlen, (uint32_t)__shfl_xor((int)maxlen, d, 64));
+    maxlen = __builtin_amdgcn_readfirstlane(maxlen);
+    // ---- holder role: global memory is touched LINE-WISE.  In load kq, lane tid fetches 16-byte chunk (tid & 7) of the
+    // cell of owner 8 kq + (tid >> 3): the 8 lanes of an owner cover its 128-byte line in one request (a lane loading its
+    // own cell chunk by chunk issues 8 scattered requests, and the request count is what bounds this kernel, DESIGN.md
+    // §2.5).  In store s, lanes 2o', 2o'+1 write the two chunks of the slot sector of owner 32 s + o'.
+    const uint32_t hc = tid & 7u, ho = tid >> 3;
+    uint8_t *tbl_leaf = a.tables + lf.tbl_off;
+    uint8_t *gbase[8];
+#pragma unroll
+    for (int kq = 0; kq < 8; kq++) gbase[kq] = tbl_leaf + (uint64_t)min(lane0 + 8u * kq + ho, nl - 1u) * a.lane_stride + 16u * hc;
+    uint8_t *sbase[2];
+#pragma unroll
+    for (int sq = 0; sq < 2; sq++) sbase[sq] = tbl_leaf + (uint64_t)min(lane0 + 32u * sq + (tid >> 1), nl - 1u) * a.lane_stride;
+    lds_u32x4 *hcell = (lds_u32x4 *)&s_cell[hc][ho];                      // + 8 kq owners
+    lds_u32 *mb0 = (lds_u32 *)&s_x[0][0], *mb1 = (lds_u32 *)&s_x[1][0], *mb2 = (lds_u32 *)&s_x[2][0];
 
-    // Software pipeline over the nibbles ("events"; event e = nibble e & 1 of byte e >> 1).  The cell of event e is staged
-    // in LDS; the cells of e+1 and e+2 are in flight / in registers (B[half of the event]); the loads of e+2 are issued
-    // when e starts.  A prefetched cell is stale if an event processed after its loads were issued wrote the same cell:
-    // e+1's cell equal to e's (take the LDS copy) or to e-1's (take G, e-1's cell as it was written back).
-    // Every global load and store below is unconditional and their number per event is fixed: hipcc waits vmcnt(0) —
-    // i.e. for the prefetches just issued — as soon as a branch makes the count of outstanding operations uncertain.
+    // Software pipeline over the nibbles ("events"; event e = nibble e & 1 of byte e >> 1).  The cell of event e is staged in
+    // LDS; the cells of e+1 and e+2 are in flight / in the holders' registers (B[half of the event]); the loads of e+2 are
+    // issued when e starts.  A prefetched cell is stale if an event processed after its loads were issued wrote the same
+    // cell: e+1's cell equal to e's (keep the LDS copy) or to e-1's (take G, e-1's cell as it was written back).
+    // Every global load and store is unconditional and their number per event is fixed (predicated-off ones go to a sink):
+    // hipcc waits vmcnt(0) — i.e. for the prefetches just issued — as soon as a branch makes the count uncertain.
     uint32_t b0 = blk[0], b1 = blk[min(1u, last)], b2 = blk[min(2u, last)];
     uint64_t hist = 0ull;
     uint64_t h_cur = slot_hash(order, 0ull, false, 0u), h_1 = slot_hash(order, 0ull, true, b0 >> 4);
-    uint64_t c_cur = h_cur >> lshift, c_1 = h_1 >> lshift, c_prev = ~0ull;
+    uint32_t c_cur = (uint32_t)(h_cur >> lshift), c_1 = (uint32_t)(h_1 >> lshift), c_prev = 0xFFFFFFFFu;
     u32x4 B0[8], B1[8], G0[8], G1[8];
-    {
-        const u32x4 *cp = reinterpret_cast<const u32x4 *>(cells + c_cur * W3_CELL_STRIDE);
-        const u32x4 *cq = reinterpret_cast<const u32x4 *>(cells + c_1 * W3_CELL_STRIDE);
+    mb0[tid] = c_cur; mb1[tid] = c_1;
+    W3_LDS_FENCE();
 #pragma unroll
-        for (int q = 0; q < 8; q++) { B0[q] = cp[q]; B1[q] = cq[q]; G0[q] = 0u; G1[q] = 0u; }
-#pragma unroll
-        for (int q = 0; q < 8; q++) s_cell[q][threadIdx.x] = B0[q];
-        W3_LDS_FENCE();
+    for (int kq = 0; kq < 8; kq++) {
+        B0[kq] = *(const g_u32x4 *)(gbase[kq] + (uint64_t)mb0[8u * kq + ho] * W3_CELL_STRIDE);
+        B1[kq] = *(const g_u32x4 *)(gbase[kq] + (uint64_t)mb1[8u * kq + ho] * W3_CELL_STRIDE);
+        G0[kq] = 0u; G1[kq] = 0u;
     }
-    for (uint32_t i = 0; i < len; i++) {
+#pragma unroll
+    for (int kq = 0; kq < 8; kq++) hcell[8 * kq] = B0[kq];
+    W3_LDS_FENCE();
+    for (uint32_t i = 0; i < maxlen; i++) {
         const uint32_t byte = b0;
         const uint32_t b3 = blk[min(i + 3u, last)];
+        const bool act = i < len, act_next = i + 1u < len;
         uint32_t pw[4];
 #pragma unroll
         for (int half = 0; half < 2; half++) {
-            u32x4 (&Bn)[8] = half == 0 ? B1 : B0;    // the cell of e+1 (loaded while e-1 ran)
-            u32x4 (&Bl)[8] = half == 0 ? B0 : B1;    // receives the cell of e+2
-            u32x4 (&Gp)[8] = half == 0 ? G1 : G0;    // e-1's cell as written back
-            u32x4 (&Gc)[8] = half == 0 ? G0 : G1;    // receives e's
+            u32x4 (&Bn)[8] = half == 0 ? B1 : B0;    // the cells of e+1 (loaded while e-1 ran)
+            u32x4 (&Bl)[8] = half == 0 ? B0 : B1;    // receive the cells of e+2
+            u32x4 (&Gp)[8] = half == 0 ? G1 : G0;    // e-1's cells as written back
+            u32x4 (&Gc)[8] = half == 0 ? G0 : G1;    // receive e's
+            // owner: where is the cell of e+2?   holders: fetch it
             const uint64_t h_2 = half == 0 ? slot_hash(order, (hist << 8) | byte, false, 0u)
                                            : slot_hash(order, (hist << 8) | byte, true, b1 >> 4);
-            const uint64_t c_2 = h_2 >> lshift;
-            {
-                const u32x4 *cp = reinterpret_cast<const u32x4 *>(cells + ((a.dbg_flags & 2u) ? 0ull : c_2) * W3_CELL_STRIDE);
-#pragma unroll
-                for (int q = 0; q < 8; q++) Bl[q] = cp[q];
-            }
+            const uint32_t c_2 = (uint32_t)(h_2 >> lshift);
+            mb0[tid] = (a.dbg_flags & 2u) ? 0u : c_2;
             W3_LDS_FENCE();
-            uint32_t pq[4];
-            const uint32_t id = slot_nibble(cb, st, (uint32_t)h_cur & 0xFFFu, half == 0 ? (byte >> 4) : (byte & 15u), pq);
+#pragma unroll
+            for (int kq = 0; kq < 8; kq++) Bl[kq] = *(const g_u32x4 *)(gbase[kq] + (uint64_t)mb0[8u * kq + ho] * W3_CELL_STRIDE);
+            // owner: this nibble on the staged cell
+            uint32_t pq[4] = {0u, 0u, 0u, 0u}, id = 0u;
+            if (act) id = slot_nibble(cb, st, (uint32_t)h_cur & 0xFFFu, half == 0 ? (byte >> 4) : (byte & 15u), pq);
             pw[2 * half] = pq[0] | (pq[1] << 16);
             pw[2 * half + 1] = pq[2] | (pq[3] << 16);
-            // write back the slot's sector (states + tag): two 16-byte stores into one line
-            {
-                u32x4 *cw = reinterpret_cast<u32x4 *>(cells + c_cur * W3_CELL_STRIDE);
-                const u32x4 w0 = s_cell[2u * id][threadIdx.x], w1 = s_cell[2u * id + 1u][threadIdx.x];
-                if (!(a.dbg_flags & 4u)) { cw[2u * id] = w0; cw[2u * id + 1u] = w1; }
-            }
-#pragma unroll
-            for (int q = 0; q < 8; q++) Gc[q] = s_cell[q][threadIdx.x];
+            mb1[tid] = c_cur | (id << 24) | ((act && !(a.dbg_flags & 4u)) ? (1u << 26) : 0u);
             W3_LDS_FENCE();
-            {
-                const bool from_prev = c_1 == c_prev, restage = c_1 != c_cur;
-                u32x4 v[8];
+            // holders: write the slot's 32-byte sector back (two lanes per owner), keep every cell as written (G)
 #pragma unroll
-                for (int q = 0; q < 8; q++) v[q] = from_prev ? Gp[q] : Bn[q];
-                if (restage) {
+            for (int sq = 0; sq < 2; sq++) {
+                const uint32_t o = 32u * sq + (tid >> 1), wb = mb1[o];
+                const uint32_t chunk = 2u * ((wb >> 24) & 3u) + (tid & 1u);
+                const u32x4 data = s_cell[chunk][o];
+                g_u32x4 *dst = (wb >> 26) ? (g_u32x4 *)(sbase[sq] + (uint64_t)(wb & 0xFFFFFFu) * W3_CELL_STRIDE + 16u * chunk) : sink;
+                *dst = data;
+            }
+            // (G is only ever read when some lane's event e+2 returns to the cell of e: skip the read-back otherwise)
+            if (__ballot(c_2 == c_cur)) {
 #pragma unroll
-                    for (int q = 0; q < 8; q++) s_cell[q][threadIdx.x] = v[q];
-                }
+                for (int kq = 0; kq < 8; kq++) Gc[kq] = hcell[8 * kq];
+            }
+            // owner: is the prefetched cell of e+1 still good?   holders: stage it
+            const bool nact = half == 0 ? act : act_next;
+            mb2[tid] = (!nact || c_1 == c_cur) ? 0u : (c_1 == c_prev ? 1u : 2u);
+            W3_LDS_FENCE();
+#pragma unroll
+            for (int kq = 0; kq < 8; kq++) {
+                const uint32_t f = mb2[8u * kq + ho];
+                const u32x4 v = f == 1u ? Gp[kq] : Bn[kq];
+                if (f) hcell[8 * kq] = v;
             }
             W3_LDS_FENCE();
             c_prev = c_cur; h_cur = h_1; c_cur = c_1; h_1 = h_2; c_1 = c_2;
         }
         hist = (hist << 8) | byte;
         b0 = b1; b1 = b2; b2 = b3;
-        { u32x4 pv; pv.x = pw[0]; pv.y = pw[1]; pv.z = pw[2]; pv.w = pw[3]; Pout[i] = pv; }
+        {
+            u32x4 pv; pv.x = pw[0]; pv.y = pw[1]; pv.z = pw[2]; pv.w = pw[3];
+            g_u32x4 *dst = act ? Pout + i : sink;
+            *dst = pv;
+        }
     }
 }
 

@@ -215,11 +215,17 @@ static inline int twophase_predict(TwoPhaseWs &ws, hipStream_t s, const ParsedSp
         uint64_t budget = std::min<uint64_t>((uint64_t)((free_b + ws.slot_tables_cap) * 0.7), 120ull << 30);
         if (const char *ev_ = getenv("W3_SLOT_BUDGET_MB")) budget = (uint64_t)std::max(1, atoi(ev_)) << 20;   // test / tuning hook
         uint64_t lanes = std::min<uint64_t>(budget / slot_stride, nb);
-        if (lanes < nb) lanes = lanes / 64 * 64;
+        if (lanes < nb) {
+            // equal batches: a batch costs at least the lone-wave latency of a whole block, however few lanes it has
+            lanes = lanes / 64 * 64;
+            if (lanes) { const uint64_t nbatch = (nb + lanes - 1) / lanes; lanes = std::min<uint64_t>(lanes, ((nb + nbatch - 1) / nbatch + 63) / 64 * 64); }
+        }
         if (lanes == 0) { err = "slot-leaf hash maps of one wavefront (" + std::to_string(slot_stride * 64) + " B) exceed the device budget"; return W3_E_NOMEM; }
         if ((rc = tp_ensure(ws.slot_tables, ws.slot_tables_cap, (size_t)(lanes * slot_stride), err))) return rc;
         sa.in = d_in; sa.n = n; sa.block_size = (uint32_t)block_size; sa.tables = (uint8_t *)ws.slot_tables; sa.lane_stride = slot_stride;
         sa.st = ws.st;
+        if ((rc = tp_ensure(ws.dummy, ws.dummy_cap, 2048, err))) return rc;
+        sa.dummy = (uint8_t *)ws.dummy;
         if (const char *ev_ = getenv("W3_SLOT_DEBUG")) sa.dbg_flags = (uint32_t)atoi(ev_);   // timing experiments only
         if (ev) (void)hipEventRecord(ev[10], s);
         for (uint32_t first = 0; first < nb; first += (uint32_t)lanes) {
@@ -253,7 +259,7 @@ static inline int twophase_apm(TwoPhaseWs &ws, hipStream_t s, const ParsedSpec &
     if (!ws.stretch || !ws.squash) { err = "APM LUTs not staged"; return W3_E_HIP; }
     int rc = tp_ensure(ws.P, ws.P_cap, n * 16, err);
     if (rc) return rc;
-    if ((rc = tp_ensure(ws.dummy, ws.dummy_cap, 256, err))) return rc;
+    if ((rc = tp_ensure(ws.dummy, ws.dummy_cap, 2048, err))) return rc;
     if (ev) (void)hipEventRecord(ev[8], s);
     uint64_t bytes = 0;
     bool partitioned = false;
