@@ -365,7 +365,7 @@ namespace w3 {
 //           the two operands it needs: p32 = p<<16 and the bit as a 0/~0 mask.
 //           This replaces the separate k_mix pass (48+16 GB of traffic per GB
 //           of input at L = 3) and keeps memory latency out of the recurrence.
-//   X-wave: (x1, x2) recurrence only, LDS in, LDS out (see k_coder_x2).
+//   X-wave: (x1, x2) recurrence only, LDS in, LDS out: 17 instructions, 9 deep (comment at the wave).
 //   O-wave: accumulator, flushes, final ACWriter::flush (see k_coder_x2).
 // Two LDS rings of 16 input bytes each (M->X operands, X->O tokens): 128 KiB.
 // ---------------------------------------------------------------------------
@@ -395,7 +395,7 @@ __device__ __forceinline__ uint32_t spin_until_ge(const volatile uint32_t *ctr, 
 template <int L>
 __global__ void __launch_bounds__(192) k_coder_x3(Coder3Args a) {
     __shared__ uint2 opq[W3_X2_RING * 8u * 64u];   // M -> X: (p32, bitmask) per step   [ring byte][bit][lane]
-    __shared__ uint2 tok[W3_X2_RING * 8u * 64u];   // X -> O: (x1 after update, c)      [ring byte][bit][lane]
+    __shared__ uint2 tok[W3_X2_RING * 8u * 64u];   // X -> O: (x1 after update, s)      [ring byte][bit][lane]
     __shared__ uint32_t fin_x2[64];
     __shared__ uint32_t sync_w[8];                 // [0] M produced, [1] X consumed, [2] X produced, [3] O consumed, [4] abort
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
@@ -476,7 +476,18 @@ __global__ void __launch_bounds__(192) k_coder_x3(Coder3Args a) {
 
     if (wave == 1) {
         // ------------------------------ X-wave ------------------------------
-        uint32_t x1 = 0u, x2 = 0xFFFFFFFFu;
+        // The recurrence (arithmetic_coder.rs:41-65) as a 9-deep dependency chain of 18 VALU instructions per step.
+        // (Measured: the shorter chain bought nothing — 30.2 -> 29.8 ms — because ONE wave issues a VALU instruction only
+        // every ~7-8 cycles whether it is dependent or not; the step costs its instruction COUNT, ~20 with the LDS ops.)
+        //   m    = mulhi(d, p32)                                  d = x2 - x1, carried from the previous step
+        //   x2n  = bit ? x1 + m : x2 ;  x1n = bit ? x1 : x1 + m + 1            (1 takes the low sub-interval, :45-48)
+        //   s    = clz((x1n ^ x2n) & ((~x1n | x2n) << 1 | 1))     both renormalisation loops in ONE count: n equal
+        //          leading bits, then the m E3 positions where x1n = 1 and x2n = 0 (position q survives the mask iff
+        //          x1n, x2n differ at q and q+1 is not an E3 position); s = n + m <= 18 because p is a Counter::p
+        //   X1   = x1n << s ;  X2 = ((x2n + 1) << s) - 1          the raw shifts; the top-bit fix-ups of loop 2
+        //          (x1 &= 0x7FFFFFFF, x2 |= 0x80000000, :59-60) swap a (1, 0) pair of top bits or do nothing, so
+        //          d = X2 - X1 (mod 2^32) needs neither and they run beside the next step's mulhi
+        uint32_t x1 = 0u, x2 = 0xFFFFFFFFu, d = 0xFFFFFFFFu;
         uint32_t seen_m = 0, seen_o = 0;
         for (uint32_t i = 0; i < maxlen && !dead; i += 8) {
             const uint32_t need = min(i + 8u, maxlen);
@@ -492,18 +503,23 @@ __global__ void __launch_bounds__(192) k_coder_x3(Coder3Args a) {
                     for (int j = 0; j < 8; j++) op[j] = opq[ring + j * 64];
 #pragma unroll
                     for (int j = 0; j < 8; j++) {
-                        const uint32_t p32 = op[j].x, bitmask = op[j].y;
-                        const uint32_t xmid = x1 + __umulhi(x2 - x1, p32);
-                        const uint32_t xmid1 = xmid + 1u;
+                        const uint32_t p32 = op[j].x, bitmask = op[j].y;   // ~0 when the coded bit is 1
+                        const uint32_t m = __umulhi(d, p32);
+                        const uint32_t xmid = x1 + m;
+                        uint32_t x1n, x2n, e, t, nb1;
                         // v_bfi_b32: (mask & a) | (~mask & b).  hipcc turns the C form into v_cmp + 2 v_cndmask + s_nop.
-                        asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(x1) : "v"(bitmask), "v"(x1), "v"(xmid1));
-                        asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(x2) : "v"(bitmask), "v"(xmid), "v"(x2));
-                        const uint32_t n = (uint32_t)__builtin_clz(x1 ^ x2);
-                        const uint32_t u = ~(x1 & ~x2) & (0x7FFFFFFFu >> n);
-                        const uint32_t c = (uint32_t)__builtin_clz(u);
-                        tok[ring + j * 64] = make_uint2(x1, c);
-                        x1 = (x1 << c) >> 1;
-                        x2 = ~((~x2 << c) >> 1);
+                        asm("v_bfi_b32 %0, %1, 0, %2" : "=v"(t) : "v"(bitmask), "v"(m));          // bit ? 0 : m
+                        asm("v_bfi_b32 %0, %1, 0, 1" : "=v"(nb1) : "v"(bitmask));                // bit ? 0 : 1
+                        asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(x2n) : "v"(bitmask), "v"(xmid), "v"(x2));
+                        asm("v_add3_u32 %0, %1, %2, %3" : "=v"(x1n) : "v"(x1), "v"(t), "v"(nb1));
+                        asm("v_bfi_b32 %0, %1, %2, -1" : "=v"(e) : "v"(x1n), "v"(x2n));          // ~x1n | x2n
+                        const uint32_t u = (x1n ^ x2n) & ((e << 1) | 1u);
+                        const uint32_t sft = (uint32_t)__builtin_clz(u);
+                        tok[ring + j * 64] = make_uint2(x1n, sft);
+                        const uint32_t X1 = x1n << sft, X2 = ((x2n + 1u) << sft) - 1u;
+                        d = X2 - X1;
+                        x1 = X1 & 0x7FFFFFFFu;
+                        x2 = X2 | 0x80000000u;
                     }
                     if (i + k + 1u == len) fin_x2[lane] = x2;
                 }
@@ -544,9 +560,9 @@ __global__ void __launch_bounds__(192) k_coder_x3(Coder3Args a) {
                         }
                         if (nb > limit) { failed = true; acc = 0ull; nb = 1u; }
                     }
-                    const uint32_t x1v = t[j].x, c = t[j].y, s = c - 1u;
+                    const uint32_t x1v = t[j].x, s = t[j].y;   // token = (x1 after the update, shift count)
                     acc += x1v >> 31;
-                    acc = (acc << s) | __builtin_amdgcn_ubfe(x1v, 32u - c, s);
+                    acc = (acc << s) | __builtin_amdgcn_ubfe(x1v, 31u - s, s);
                     nb += s;
                 }
                 const uint32_t lo = (uint32_t)acc;

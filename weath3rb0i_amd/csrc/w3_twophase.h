@@ -212,7 +212,19 @@ static inline int twophase_predict(TwoPhaseWs &ws, hipStream_t s, const ParsedSp
         if (!ws.st) { err = "state table not staged"; return W3_E_HIP; }
         size_t free_b = 0, total_b = 0;
         if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); err = "hipMemGetInfo failed"; return W3_E_HIP; }
-        uint64_t budget = std::min<uint64_t>((uint64_t)((free_b + ws.slot_tables_cap) * 0.7), 120ull << 30);
+        // budget = what is free now minus what this call still has to allocate after the slot leaves (the merged / APM
+        // stream P, the records and scratch of an ORDER1 APM stage) and 4 GiB of slack for the caller
+        uint64_t later = 4ull << 30;
+        if (ws.P_cap < n * 16) later += n * 16;
+        bool apm1 = false;
+        for (int k = 0; k < ps.n_apm; k++) apm1 |= ps.apm[k].align == W3_APM_ORDER1;
+        if (apm1) {
+            if (ws.rec_cap < n * 8) later += n * 8;
+            const uint64_t perm_need = (uint64_t)std::min<uint32_t>(nb, 256 * 16) * 2 * block_size * 8;
+            if (ws.perm_cap < perm_need) later += perm_need;
+        }
+        const uint64_t avail = (uint64_t)free_b + ws.slot_tables_cap;
+        uint64_t budget = avail > later ? avail - later : 0;
         if (const char *ev_ = getenv("W3_SLOT_BUDGET_MB")) budget = (uint64_t)std::max(1, atoi(ev_)) << 20;   // test / tuning hook
         uint64_t lanes = std::min<uint64_t>(budget / slot_stride, nb);
         if (lanes < nb) {
