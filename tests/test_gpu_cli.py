@@ -1,0 +1,87 @@
+"""The C++ host above the C ABI (tools/w3cli.cpp, the mirror of src/main.rs:24-87) on the GPU: `w3 <c|d|t> <path>`,
+output names, both containers, directory traversal, model selection.  Its streams must be the library's streams."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import weath3rb0i_amd as w3
+from tests.synth import markov_text, mixed_bytes
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CLI = os.path.join(ROOT, "tools", "w3")
+
+
+@pytest.fixture(scope="module")
+def cli():
+    src = os.path.join(ROOT, "tools", "w3cli.cpp")
+    if not os.path.exists(CLI) or os.path.getmtime(CLI) < os.path.getmtime(src):
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-o", CLI, src, "-L" + os.path.join(ROOT, "weath3rb0i_amd"), "-lw3hip",
+                               "-Wl,-rpath,$ORIGIN/../weath3rb0i_amd", "-Wl,-rpath,/opt/rocm/lib"])
+    return CLI
+
+
+def run(cli, cwd, *args, **env):
+    e = dict(os.environ)
+    e.update(env)
+    return subprocess.run([cli, *args], cwd=cwd, env=e, capture_output=True, text=True, timeout=300)
+
+
+def parse_block_container(blob):
+    assert blob[:4] == b"w3bk" and blob[4] == 1
+    orig = int.from_bytes(blob[5:13], "big")
+    bs = int.from_bytes(blob[13:17], "big")
+    nb = int.from_bytes(blob[17:21], "big")
+    lens = [int.from_bytes(blob[21 + 4 * b:25 + 4 * b], "big") for b in range(nb)]
+    return orig, bs, lens, blob[21 + 4 * nb:]
+
+
+@pytest.mark.parametrize("model", ["default", "order012apm", "fullcm"])
+def test_cli_test_action_block_container(cli, tmp_path, model):
+    data = markov_text(200000, seed=31) + mixed_bytes(70000, seed=32)
+    (tmp_path / "in").mkdir()
+    f = tmp_path / "in" / "corpus.txt"
+    f.write_bytes(data)
+    r = run(cli, tmp_path, "t", str(f), W3_MODEL=model)
+    assert r.returncode == 0, r.stderr
+    assert "Compression took" in r.stdout and "Decompression took" in r.stdout          # main.rs:70-78
+    blob = (tmp_path / "corpus.bin").read_bytes()                                        # <name>.bin in the cwd, main.rs:58-68
+    assert (tmp_path / "corpus.orig").read_bytes() == data
+    orig, bs, lens, body = parse_block_container(blob)
+    assert orig == len(data) and bs == 65536 and sum(lens) == len(body)
+    ctx = w3.Context(0)
+    try:
+        m = {"default": w3.init_model, "fullcm": w3.full_cm,
+             "order012apm": lambda: w3.APM(w3.BestOfTwoModel(w3.BestOfTwoModel(w3.Order0(), w3.Order1()), w3.OrderN(27, 3)))}[model]()
+        out, wl = ctx.encode_blocks(m, data, 65536)
+    finally:
+        ctx.close()
+    assert lens == wl.tolist() and body == out.tobytes()
+
+
+def test_cli_reference_container_and_directory(cli, tmp_path, oracle):
+    d = tmp_path / "dir"
+    d.mkdir()
+    a, b = markov_text(30000, seed=5), bytes(range(256)) * 20
+    (d / "a.txt").write_bytes(a)
+    (d / "b.dat").write_bytes(b)
+    (d / "sub").mkdir()                                                                  # shallow traversal: not entered, main.rs:41-50
+    r = run(cli, tmp_path, "c", str(d), W3_CONTAINER="w30i")
+    assert r.returncode == 0, r.stderr
+    blob = (tmp_path / "a.bin").read_bytes()
+    assert blob[:4] == b"w30i" and int.from_bytes(blob[4:12], "big") == len(a)           # main.rs:14-15,95-96
+    ref = oracle.OrderNEntropy(11, 3, oracle.ACHistory(8, oracle.StationaryModel.for_book1()))
+    assert blob == oracle.compress(ref, a)
+    r = run(cli, tmp_path, "d", str(tmp_path / "b.bin"))
+    assert r.returncode == 0 and (tmp_path / "b.orig").read_bytes() == b
+
+
+def test_cli_errors(cli, tmp_path):
+    assert run(cli, tmp_path, "x", "nothing").returncode == 1                             # usage, main.rs:154-161
+    assert run(cli, tmp_path, "c", str(tmp_path / "missing")).returncode == 1
+    bad = tmp_path / "bad.bin"
+    bad.write_bytes(b"not a container at all....")
+    r = run(cli, tmp_path, "d", str(bad))
+    assert r.returncode == 1 and "Magic numbers" in r.stderr

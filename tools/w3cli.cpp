@@ -21,14 +21,35 @@
 
 static const uint32_t kBlock = 65536;
 
+static void push(w3_model_spec &s, uint8_t kind, uint8_t bits = 0, uint8_t align = 0, uint8_t max_bits = 0, uint8_t log_cells = 0) {
+    w3_node &n = s.nodes[s.n_nodes++];
+    n.kind = kind; n.bits = bits; n.align = align; n.max_bits = max_bits; n.log_cells = log_cells;
+}
+
+// The reference chooses its model at compile time in init_model() (main.rs:146-152); here W3_MODEL picks one:
+//   (unset) / default : main.rs:151, OrderNEntropy(11, 3, ACHistory(8, StationaryModel::for_book1()))
+//   order012          : the commented alternative of main.rs:148-150 in today's types, BestOfTwo(BestOfTwo(Order0, Order1), OrderN(27,3))
+//   order012apm       : + one APM stage (BASELINE configs[1]; build-defined)
+//   fullcm            : + slot-state leaves of order 1-4 and two APM stages (BASELINE configs[2])
 static w3_model_spec init_model() {
     w3_model_spec s;
     memset(&s, 0, sizeof s);
-    s.n_nodes = 1;
-    w3_node &n = s.nodes[0];
-    n.kind = W3_NODE_ORDERN; n.bits = 11; n.align = 3; n.history = W3_HIST_AC; n.max_bits = 8;
-    const uint16_t book1[8] = {1, 50188, 62497, 15819, 22545, 31499, 22988, 29616};  // stationary.rs:41
-    memcpy(n.table, book1, sizeof book1);
+    const char *m = getenv("W3_MODEL");
+    const std::string name = m ? m : "default";
+    if (name == "default") {
+        push(s, W3_NODE_ORDERN, 11, 3, 8);
+        s.nodes[0].history = W3_HIST_AC;
+        const uint16_t book1[8] = {1, 50188, 62497, 15819, 22545, 31499, 22988, 29616};  // stationary.rs:41
+        memcpy(s.nodes[0].table, book1, sizeof book1);
+        return s;
+    }
+    if (name != "order012" && name != "order012apm" && name != "fullcm") { fprintf(stderr, "unknown W3_MODEL %s\n", name.c_str()); exit(1); }
+    push(s, W3_NODE_ORDERN, 11, 3); push(s, W3_NODE_ORDERN, 19, 3); push(s, W3_NODE_BEST_OF_TWO);
+    push(s, W3_NODE_ORDERN, 27, 3); push(s, W3_NODE_BEST_OF_TWO);
+    if (name == "fullcm")
+        for (uint8_t order = 1; order <= 4; order++) { push(s, W3_NODE_SLOT_STATE, order, 0, 0, 14); push(s, W3_NODE_BEST_OF_TWO); }
+    if (name != "order012") push(s, W3_NODE_APM, 0, W3_APM_ORDER0, 7);
+    if (name == "fullcm") push(s, W3_NODE_APM, 0, W3_APM_ORDER1, 6);
     return s;
 }
 
