@@ -21,7 +21,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, data, bs, q):
+def _worker(rank, world, port, data, bs, q, async_op=False):
     import sys
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     from oracle import pyoracle as orc
@@ -33,7 +33,11 @@ def _worker(rank, world, port, data, bs, q):
     out, lens = orc.encode_blocks(orc.Order0(), data[lo:hi], bs)
     stream = torch.from_numpy(np.concatenate([out, np.zeros(7, dtype=np.uint8)]))  # slack past `total` must be ignored
     tl = torch.from_numpy(lens.astype(np.int32))
-    allb, alll, totals = shard.gather_streams(stream, len(out), tl, dst=0)
+    if async_op:   # split-phase form used by bench.py to overlap the exchange with the next encode
+        allb, alll, totals, reqs = shard.gather_streams(stream, len(out), tl, dst=0, async_op=True)
+        shard.wait_all(reqs)
+    else:
+        allb, alll, totals = shard.gather_streams(stream, len(out), tl, dst=0)
     if rank == 0:
         q.put((allb.numpy().tobytes(), alll.numpy().astype(np.uint32).tolist(), totals))
     else:
@@ -42,13 +46,14 @@ def _worker(rank, world, port, data, bs, q):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,n,bs", [(2, 70000, 8192), (3, 20000, 4096), (2, 4096, 8192), (3, 5, 4096)])
-def test_gather_matches_single_process(oracle, world, n, bs):
+@pytest.mark.parametrize("world,n,bs,async_op", [(2, 70000, 8192, False), (3, 20000, 4096, False), (2, 4096, 8192, False), (3, 5, 4096, False),
+                                                 (2, 70000, 8192, True), (3, 5, 4096, True)])
+def test_gather_matches_single_process(oracle, world, n, bs, async_op):
     data = lcg_text(n, seed=77)
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, data, bs, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, data, bs, q, async_op)) for r in range(world)]
     for p in procs:
         p.start()
     got = q.get(timeout=120)

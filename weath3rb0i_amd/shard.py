@@ -27,10 +27,13 @@ def byte_range(rank, world, n, block_size):
     return min(lo * block_size, n), min(hi * block_size, n)
 
 
-def gather_streams(stream, total, lens, dst=0, group=None, out=None):
+def gather_streams(stream, total, lens, dst=0, group=None, out=None, async_op=False):
     """Concatenate every rank's packed stream (stream[:total], uint8) and block lengths (lens, int32) on `dst`.
 
     Returns (all_streams, all_lens, totals) on dst — views into `out` when given — and (None, None, totals) elsewhere.
+    async_op=True returns a 4th element, the outstanding point-to-point requests: the transfers then overlap whatever the
+    caller enqueues next (RCCL runs them on its own stream); call wait_all() on them before touching `stream`, `lens` or
+    the returned views again.
     """
     rank, world = dist.get_rank(group), dist.get_world_size(group)
     dev = stream.device
@@ -45,8 +48,10 @@ def gather_streams(stream, total, lens, dst=0, group=None, out=None):
             ops.append(dist.P2POp(dist.isend, stream[: totals[rank]], dst, group))
         if counts[rank]:
             ops.append(dist.P2POp(dist.isend, lens, dst, group))
-        for req in dist.batch_isend_irecv(ops) if ops else []:
-            req.wait()
+        reqs = dist.batch_isend_irecv(ops) if ops else []
+        if async_op:
+            return None, None, totals, reqs
+        wait_all(reqs)
         return None, None, totals
     need = sum(totals)
     if out is None or out.numel() < need:
@@ -64,6 +69,13 @@ def gather_streams(stream, total, lens, dst=0, group=None, out=None):
                 ops.append(dist.P2POp(dist.irecv, all_lens[lo: lo + counts[r]], r, group))
         so += totals[r]
         lo += counts[r]
-    for req in dist.batch_isend_irecv(ops) if ops else []:
-        req.wait()
+    reqs = dist.batch_isend_irecv(ops) if ops else []
+    if async_op:
+        return out[:need], all_lens[: sum(counts)], totals, reqs
+    wait_all(reqs)
     return out[:need], all_lens[: sum(counts)], totals
+
+
+def wait_all(reqs):
+    for req in reqs:
+        req.wait()
