@@ -99,3 +99,11 @@ def test_product_never_imports_oracle():
             if f.endswith((".py", ".h", ".hip", ".cpp", ".hpp")):
                 txt = open(os.path.join(dirpath, f), errors="ignore").read()
                 assert "pyoracle" not in txt and "w3_oracle" not in txt and "libw3oracle" not in txt, f
+
+
+def test_ac_history_cached_is_ac_history():
+    """ACHistoryCached (history/ac_history_cached.rs) memoises coder states; its hash equals ACHistory's, so the spec is the same."""
+    import weath3rb0i_amd as w3
+    a = w3.OrderNEntropy(20, 3, w3.ACHistory(8, w3.StationaryModel.for_book1())).spec()
+    b = w3.OrderNEntropy(20, 3, w3.ACHistoryCached.new(8, w3.StationaryModel.for_book1(), 24)).spec()
+    assert bytes(a) == bytes(b)

@@ -70,6 +70,23 @@ class ACHistory:
         return cls(max_bits, model)
 
 
+class ACHistoryCached(ACHistory):
+    """history/ac_history_cached.rs:31-76 — ACHistory with a std HashMap memo of coder states keyed by the low
+    cache_size (and cache_size/2) history bits and the alignment.  The memo only skips re-encoding a prefix whose
+    coder state is a pure function of its key, so hash() returns exactly ACHistory's value: cache_size changes the
+    reference's CPU time, not its output (its own logs agree: bin/entropy-hashing-ac-cached/book1.mc.3.log:362 and
+    bin/entropy-hashing-ac/book1.log:139 both give 262,871 bytes at (20, 3)).  On the GPU every step's hash is computed
+    in parallel (k_achash), so there is nothing to memoise: same spec as ACHistory."""
+
+    def __init__(self, max_bits, model, cache_size=0):
+        super().__init__(max_bits, model)
+        self.cache_size = int(cache_size)
+
+    @classmethod
+    def new(cls, max_bits, model, cache_size):
+        return cls(max_bits, model, cache_size)
+
+
 class Model:
     """trait Model (models/mod.rs:12-15), as a spec tree."""
 
