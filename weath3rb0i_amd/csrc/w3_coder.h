@@ -369,6 +369,18 @@ namespace w3 {
 //   O-wave: accumulator, flushes, final ACWriter::flush (see k_coder_x2).
 // Two LDS rings of 16 input bytes each (M->X operands, X->O tokens): 128 KiB.
 // ---------------------------------------------------------------------------
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+typedef short i16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ u16x2 as_u16x2(uint32_t v) { return __builtin_bit_cast(u16x2, v); }
+__device__ __forceinline__ i16x2 as_i16x2(u16x2 v) { return __builtin_bit_cast(i16x2, v); }
+__device__ __forceinline__ uint32_t as_u32(u16x2 v) { return __builtin_bit_cast(uint32_t, v); }
+__device__ __forceinline__ uint32_t as_u32(i16x2 v) { return __builtin_bit_cast(uint32_t, v); }
+// |p - 32768| of two u16 probabilities at once (mixers/opinion_mixer2.rs:5-10)
+__device__ __forceinline__ u16x2 pk_opinion_dist(u16x2 p) {
+    const u16x2 half = {32768, 32768};
+    return __builtin_elementwise_max(p, half) - __builtin_elementwise_min(p, half);
+}
+
 struct Coder3Args {
     const uint8_t *in;
     uint64_t n;
@@ -451,18 +463,24 @@ __global__ void __launch_bounds__(192) k_coder_x3(Coder3Args a) {
 #pragma unroll
                     for (int q = 0; q < 4; q++) {   // one dword = two steps
                         uint32_t w0 = q == 0 ? cur[0][k].x : q == 1 ? cur[0][k].y : q == 2 ? cur[0][k].z : cur[0][k].w;
-                        uint32_t plo = w0 & 0xFFFFu, phi = w0 >> 16;
                         if constexpr (L > 1) {
-                            uint32_t dlo = opinion_dist(plo), dhi = opinion_dist(phi);
+                            // OpinionMixer2 for both steps of the dword at once with packed 16-bit VALU (the M-wave, not the
+                            // recurrence, was the slowest wave for L >= 2: a lone wave pays per instruction).  Distances
+                            // |p - 32768| <= 32767 because Counter::p is in [1, 65535], so their difference fits an i16 and its
+                            // sign is the "strictly farther" mask (ties keep the left leaf).
+                            u16x2 P = as_u16x2(w0), D = pk_opinion_dist(P);
 #pragma unroll
                             for (int l = 1; l < L; l++) {
                                 const uint32_t w = q == 0 ? cur[l][k].x : q == 1 ? cur[l][k].y : q == 2 ? cur[l][k].z : cur[l][k].w;
-                                const uint32_t qlo = w & 0xFFFFu, qhi = w >> 16;
-                                const uint32_t elo = opinion_dist(qlo), ehi = opinion_dist(qhi);
-                                if (elo > dlo) { plo = qlo; dlo = elo; }   // ties keep the left leaf
-                                if (ehi > dhi) { phi = qhi; dhi = ehi; }
+                                const u16x2 Q = as_u16x2(w), E = pk_opinion_dist(Q);
+                                const i16x2 farther = as_i16x2(D - E) >> (short)15;          // 0xFFFF where E > D
+                                const uint32_t mask = as_u32(farther);
+                                P = as_u16x2((as_u32(Q) & mask) | (as_u32(P) & ~mask));
+                                D = __builtin_elementwise_max(D, E);
                             }
+                            w0 = as_u32(P);
                         }
+                        const uint32_t plo = w0 & 0xFFFFu, phi = w0 >> 16;
                         slot[(2 * q) * 64] = make_uint2(plo << 16, (uint32_t)__builtin_amdgcn_sbfe((int)cb[k], 7 - 2 * q, 1));
                         slot[(2 * q + 1) * 64] = make_uint2(phi << 16, (uint32_t)__builtin_amdgcn_sbfe((int)cb[k], 6 - 2 * q, 1));
                     }
