@@ -583,7 +583,7 @@ __global__ void __launch_bounds__(256) k_achash(HashArgs a) {
     for (int j = 0; j < 8; j++) {
         const uint32_t t = i * 8u + j;
         uint32_t h = 0;
-        if (t != 0u) h = ac_history_hash(hist, t, a.max_bits, a.table) & a.hmask;  // ctx starts at 0 (ordern_entropy.rs:19)
+        if (t != 0u) h = ac_history_hash_fast(hist, t, a.max_bits, a.table) & a.hmask;  // ctx starts at 0 (ordern_entropy.rs:19)
         out[j >> 2] |= (h & 0xFFu) << (8 * (j & 3));
         hist = (hist << 1) | ((c0 >> (7 - j)) & 1u);
     }
