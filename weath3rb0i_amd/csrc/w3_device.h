@@ -226,39 +226,41 @@ __device__ __forceinline__ uint32_t ac_history_hash(uint64_t bits, uint32_t pos,
 // of (x1, x2) are written at once — brev(x1) holds them in write order, the pending parity bits (rev copies of the
 // complement, io.rs:84-87 semantics in EntropyWriter::write_bit, ac_history.rs:63-83) go right after the first one —
 // and the E3 run length is one more clz.  A lane is done once max_bits bits are written (the writer's Err).
-__device__ __forceinline__ uint32_t ac_history_hash_fast(uint64_t bits, uint32_t pos, uint32_t max_bits, const uint16_t *table) {
+// `rot[r]` = the lerp operand (prob << 16, or 1 for prob 0: arithmetic_coder.rs:111) of the r-th coded history bit and
+// of every 8th after it: StationaryModel::predict walks the bit positions backwards from `pos & 7` (stationary.rs:54-57),
+// so the caller rotates the 8-entry table once per bit position and no step looks anything up.
+__device__ __forceinline__ uint32_t ac_history_hash_fast(uint64_t bits, uint32_t max_bits, const uint32_t (&rot)[8]) {
     uint32_t x1 = 0u, x2 = 0xFFFFFFFFu, hash = 0u, idx = 0u, rev = 0u;
-    uint32_t al = pos & 7u;
     bool done = max_bits == 0u;
-    for (int i = 0; i < 64; i++) {
+    for (int i0 = 0; i0 < 64; i0 += 8) {
         if (!__ballot(!done)) break;
-        if (!done) {
-            const uint32_t bit = (uint32_t)(bits >> i) & 1u;
-            al = (al + 7u) & 7u;
-            const uint32_t prob = table[al];
-            const uint32_t p32 = prob ? (prob << 16) : 1u;
-            const uint32_t xmid = x1 + __umulhi(x2 - x1, p32);
-            if (bit) x2 = xmid; else x1 = xmid + 1u;
-            const uint32_t a = x1 ^ x2;
-            const uint32_t n = a ? (uint32_t)__builtin_clz(a) : 32u;
-            if (n) {
-                const uint32_t rb = __builtin_bitreverse32(x1) & (n == 32u ? 0xFFFFFFFFu : ((1u << n) - 1u));   // the n bits, first written at bit 0
-                const uint32_t r = rev < 40u ? rev : 40u;                                                       // (bits past 32 never matter)
-                const uint64_t par = (rb & 1u) ? 0ull : ((1ull << r) - 1ull);                                   // r copies of the complement
-                const uint64_t seq = (uint64_t)(rb & 1u) | (par << 1) | ((uint64_t)(rb >> 1) << (1u + r));
-                hash |= (uint32_t)(seq << idx);
-                idx += n + rev;
-                rev = 0u;
-                x1 = n == 32u ? 0u : x1 << n;
-                x2 = n == 32u ? 0xFFFFFFFFu : ((x2 << n) | ((1u << n) - 1u));
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            if (!done) {
+                const uint32_t bit = (uint32_t)(bits >> (i0 + r)) & 1u;
+                const uint32_t xmid = x1 + __umulhi(x2 - x1, rot[r]);
+                if (bit) x2 = xmid; else x1 = xmid + 1u;
+                const uint32_t a = x1 ^ x2;
+                const uint32_t n = a ? (uint32_t)__builtin_clz(a) : 32u;
+                if (n) {
+                    const uint32_t rb = __builtin_bitreverse32(x1) & (n == 32u ? 0xFFFFFFFFu : ((1u << n) - 1u));   // the n bits, first written at bit 0
+                    const uint32_t rr = rev < 40u ? rev : 40u;                                                      // (bits past 32 never matter)
+                    const uint64_t par = (rb & 1u) ? 0ull : ((1ull << rr) - 1ull);                                  // rr copies of the complement
+                    const uint64_t seq = (uint64_t)(rb & 1u) | (par << 1) | ((uint64_t)(rb >> 1) << (1u + rr));
+                    hash |= (uint32_t)(seq << idx);
+                    idx += n + rev;
+                    rev = 0u;
+                    x1 = n == 32u ? 0u : x1 << n;
+                    x2 = n == 32u ? 0xFFFFFFFFu : ((x2 << n) | ((1u << n) - 1u));
+                }
+                if (idx >= max_bits) done = true;
+                // E3 run: positions below the top bit where x1 has 1 and x2 has 0 (arithmetic_coder.rs:57-62)
+                const uint32_t e3 = (x1 & ~x2) << 1;
+                const uint32_t m = (~e3) ? (uint32_t)__builtin_clz(~e3) : 32u;   // <= 31: bit 0 of e3 is 0
+                rev += m;
+                x1 = (x1 << m) & 0x7FFFFFFFu;
+                x2 = (x2 << m) | 0x80000000u | ((1u << m) - 1u);
             }
-            if (idx >= max_bits) done = true;
-            // E3 run: positions below the top bit where x1 has 1 and x2 has 0 (arithmetic_coder.rs:57-62)
-            const uint32_t e3 = (x1 & ~x2) << 1;
-            const uint32_t m = (~e3) ? (uint32_t)__builtin_clz(~e3) : 32u;   // <= 31: bit 0 of e3 is 0
-            rev += m;
-            x1 = (x1 << m) & 0x7FFFFFFFu;
-            x2 = (x2 << m) | 0x80000000u | ((1u << m) - 1u);
         }
     }
     return max_bits >= 32u ? hash : (hash & ((1u << max_bits) - 1u));

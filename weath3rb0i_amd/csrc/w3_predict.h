@@ -568,6 +568,10 @@ struct HashArgs {
     const uint8_t *in; uint64_t n; uint32_t block_size; uint32_t max_bits; uint32_t hmask; uint16_t table[8]; uint2 *keys;
 };
 
+__device__ __forceinline__ uint32_t sel8(const uint32_t (&v)[8], uint32_t k) {   // k is wave-uniform: scalar selects, no indexing
+    return k == 0 ? v[0] : k == 1 ? v[1] : k == 2 ? v[2] : k == 3 ? v[3] : k == 4 ? v[4] : k == 5 ? v[5] : k == 6 ? v[6] : v[7];
+}
+
 __global__ void __launch_bounds__(256) k_achash(HashArgs a) {
     const uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= a.n) return;
@@ -578,12 +582,19 @@ __global__ void __launch_bounds__(256) k_achash(HashArgs a) {
     uint64_t hist = 0;
     for (uint32_t k = 1; k <= 8 && k <= i; k++) hist |= (uint64_t)blk[i - k] << (8 * (k - 1));
     const uint32_t c0 = blk[i];
+    uint32_t p32t[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) p32t[k] = a.table[k] ? ((uint32_t)a.table[k] << 16) : 1u;   // lerp operand, arithmetic_coder.rs:111
     uint32_t out[2] = {0, 0};
 #pragma unroll 1
     for (int j = 0; j < 8; j++) {
         const uint32_t t = i * 8u + j;
+        // every lane of the wave is at bit position j: the r-th coded history bit uses table[(j - 1 - r) & 7]
+        uint32_t rot[8];
+#pragma unroll
+        for (int r = 0; r < 8; r++) rot[r] = sel8(p32t, (uint32_t)(j + 7 - r) & 7u);
         uint32_t h = 0;
-        if (t != 0u) h = ac_history_hash_fast(hist, t, a.max_bits, a.table) & a.hmask;  // ctx starts at 0 (ordern_entropy.rs:19)
+        if (t != 0u) h = ac_history_hash_fast(hist, a.max_bits, rot) & a.hmask;  // ctx starts at 0 (ordern_entropy.rs:19)
         out[j >> 2] |= (h & 0xFFu) << (8 * (j & 3));
         hist = (hist << 1) | ((c0 >> (7 - j)) & 1u);
     }
