@@ -229,10 +229,21 @@ __device__ __forceinline__ uint32_t ac_history_hash(uint64_t bits, uint32_t pos,
 // `rot[r]` = the lerp operand (prob << 16, or 1 for prob 0: arithmetic_coder.rs:111) of the r-th coded history bit and
 // of every 8th after it: StationaryModel::predict walks the bit positions backwards from `pos & 7` (stationary.rs:54-57),
 // so the caller rotates the 8-entry table once per bit position and no step looks anything up.
-__device__ __forceinline__ uint32_t ac_history_hash_fast(uint64_t bits, uint32_t max_bits, const uint32_t (&rot)[8]) {
-    uint32_t x1 = 0u, x2 = 0xFFFFFFFFu, hash = 0u, idx = 0u, rev = 0u;
-    bool done = max_bits == 0u;
-    for (int i0 = 0; i0 < 64; i0 += 8) {
+// State of the nested coder after some history bits (also the entry type of the 8-bit prefix table of k_achash).
+struct ACHashState {
+    uint32_t x1, x2, hash, meta;   // meta = idx | rev << 8 | done << 31   (idx <= 32 + 31 + 8*31, rev <= 8*31 inside a table entry)
+};
+__device__ __forceinline__ ACHashState ac_hash_state_init(uint32_t max_bits) {
+    ACHashState s; s.x1 = 0u; s.x2 = 0xFFFFFFFFu; s.hash = 0u; s.meta = max_bits == 0u ? 0x80000000u : 0u;
+    return s;
+}
+
+// Steps [i_begin, i_end) (multiples of 8) of the hash from state `st`; returns the state after them.
+__device__ __forceinline__ ACHashState ac_history_hash_steps(uint64_t bits, uint32_t max_bits, const uint32_t (&rot)[8], ACHashState st,
+                                                            int i_begin, int i_end) {
+    uint32_t x1 = st.x1, x2 = st.x2, hash = st.hash, idx = st.meta & 0xFFu, rev = (st.meta >> 8) & 0x7FFFFFu;
+    bool done = (st.meta >> 31) != 0u;
+    for (int i0 = i_begin; i0 < i_end; i0 += 8) {
         if (!__ballot(!done)) break;
 #pragma unroll
         for (int r = 0; r < 8; r++) {
@@ -263,7 +274,16 @@ __device__ __forceinline__ uint32_t ac_history_hash_fast(uint64_t bits, uint32_t
             }
         }
     }
-    return max_bits >= 32u ? hash : (hash & ((1u << max_bits) - 1u));
+    ACHashState o;
+    o.x1 = x1; o.x2 = x2; o.hash = hash;
+    o.meta = (idx < 255u ? idx : 255u) | (rev << 8) | (done ? 0x80000000u : 0u);   // idx >= max_bits (<= 32) only ever means "done"
+    return o;
+}
+__device__ __forceinline__ uint32_t ac_hash_finish(const ACHashState &s, uint32_t max_bits) {
+    return max_bits >= 32u ? s.hash : (s.hash & ((1u << max_bits) - 1u));
+}
+__device__ __forceinline__ uint32_t ac_history_hash_fast(uint64_t bits, uint32_t max_bits, const uint32_t (&rot)[8]) {
+    return ac_hash_finish(ac_history_hash_steps(bits, max_bits, rot, ac_hash_state_init(max_bits), 0, 64), max_bits);
 }
 
 }  // namespace w3

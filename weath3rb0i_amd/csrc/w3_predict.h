@@ -566,10 +566,32 @@ __global__ void __launch_bounds__(256) k_mix(MixArgs a) {
 // ---------------------------------------------------------------------------
 struct HashArgs {
     const uint8_t *in; uint64_t n; uint32_t block_size; uint32_t max_bits; uint32_t hmask; uint16_t table[8]; uint2 *keys;
+    uint4 *lut;   // [65536][8] coder state after the 16 most recent history bits, per bit position (k_achash_lut)
 };
 
 __device__ __forceinline__ uint32_t sel8(const uint32_t (&v)[8], uint32_t k) {   // k is wave-uniform: scalar selects, no indexing
     return k == 0 ? v[0] : k == 1 ? v[1] : k == 2 ? v[2] : k == 3 ? v[3] : k == 4 ? v[4] : k == 5 ? v[5] : k == 6 ? v[6] : v[7];
+}
+
+// The first 16 coded history bits are the previous two bytes (for bit position 0) or their tail plus the partial byte:
+// 65536 x 8 possible prefixes.  Their coder states are tabulated once per call (the idea of the reference's
+// ACHistoryCached memo, history/ac_history_cached.rs:31-76, as a dense 8 MiB table that stays in L2 / Infinity Cache);
+// every hash starts from its entry at step 16 — with max_bits = 8 most are already complete there.
+#define W3_ACHASH_LUT_BITS 16
+__global__ void __launch_bounds__(256) k_achash_lut(HashArgs a) {
+    const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;   // e = v * 8 + j
+    if (e >= (8u << W3_ACHASH_LUT_BITS)) return;
+    const uint32_t v = e >> 3, j = e & 7u;
+    uint32_t p32t[8], rot[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) p32t[k] = a.table[k] ? ((uint32_t)a.table[k] << 16) : 1u;
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+        const uint32_t k = (j + 7u - (uint32_t)r) & 7u;
+        rot[r] = k == 0 ? p32t[0] : k == 1 ? p32t[1] : k == 2 ? p32t[2] : k == 3 ? p32t[3] : k == 4 ? p32t[4] : k == 5 ? p32t[5] : k == 6 ? p32t[6] : p32t[7];
+    }
+    const ACHashState s = ac_history_hash_steps((uint64_t)v, a.max_bits, rot, ac_hash_state_init(a.max_bits), 0, W3_ACHASH_LUT_BITS);
+    a.lut[e] = make_uint4(s.x1, s.x2, s.hash, s.meta);
 }
 
 __global__ void __launch_bounds__(256) k_achash(HashArgs a) {
@@ -594,7 +616,11 @@ __global__ void __launch_bounds__(256) k_achash(HashArgs a) {
 #pragma unroll
         for (int r = 0; r < 8; r++) rot[r] = sel8(p32t, (uint32_t)(j + 7 - r) & 7u);
         uint32_t h = 0;
-        if (t != 0u) h = ac_history_hash_fast(hist, a.max_bits, rot) & a.hmask;  // ctx starts at 0 (ordern_entropy.rs:19)
+        if (t != 0u) {   // ctx starts at 0 (ordern_entropy.rs:19)
+            const uint4 le = a.lut[((uint32_t)hist & ((1u << W3_ACHASH_LUT_BITS) - 1u)) * 8u + (uint32_t)j];
+            ACHashState st; st.x1 = le.x; st.x2 = le.y; st.hash = le.z; st.meta = le.w;
+            h = ac_hash_finish(ac_history_hash_steps(hist, a.max_bits, rot, st, W3_ACHASH_LUT_BITS, 64), a.max_bits) & a.hmask;
+        }
         out[j >> 2] |= (h & 0xFFu) << (8 * (j & 3));
         hist = (hist << 1) | ((c0 >> (7 - j)) & 1u);
     }

@@ -27,6 +27,8 @@ struct TwoPhaseWs {
     const int16_t *stretch = nullptr;   // APM LUTs (device; owned by the ctx)
     const uint16_t *squash = nullptr;
     const uint2 *st = nullptr;          // NaiveStateTable rows for the slot-state leaves (device; owned by the ctx)
+    void *achash_lut = nullptr;         // k_achash_lut: [65536][8] coder states (8 MiB)
+    size_t achash_lut_cap = 0;
     void *dummy = nullptr;              // 256-byte sink for predicated-off stores (w3_apm.h)
     size_t dummy_cap = 0;
     void *slot_tables = nullptr;        // per-lane HashMaps of the slot-state leaves
@@ -38,6 +40,8 @@ struct TwoPhaseWs {
         if (keys) (void)hipFree(keys);
         if (perm) (void)hipFree(perm);
         if (redo) (void)hipFree(redo);
+        if (achash_lut) (void)hipFree(achash_lut);
+        achash_lut = nullptr; achash_lut_cap = 0;
         if (dummy) (void)hipFree(dummy);
         dummy = nullptr; dummy_cap = 0;
         if (slot_tables) (void)hipFree(slot_tables);
@@ -176,6 +180,9 @@ static inline int twophase_predict(TwoPhaseWs &ws, hipStream_t s, const ParsedSp
             ha.in = d_in; ha.n = n; ha.block_size = (uint32_t)block_size; ha.max_bits = nd.max_bits;
             ha.hmask = (1u << (nd.bits - 3)) - 1u; ha.keys = (uint2 *)ws.keys;
             memcpy(ha.table, nd.table, sizeof ha.table);
+            if ((rc = tp_ensure(ws.achash_lut, ws.achash_lut_cap, (size_t)(8u << W3_ACHASH_LUT_BITS) * 16, err))) return rc;
+            ha.lut = (uint4 *)ws.achash_lut;
+            hipLaunchKernelGGL(w3::k_achash_lut, dim3((8u << W3_ACHASH_LUT_BITS) / 256), dim3(256), 0, s, ha);
             hipLaunchKernelGGL(w3::k_achash, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, ha);
             pa.keys = (const uint2 *)ws.keys;
             launch_small<true>(nd.bits - 3, dim3(grid_small), s, pa);
