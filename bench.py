@@ -164,7 +164,7 @@ def main():
     for _ in range(args.warmup):
         step()
     ctx.set_timing(True)
-    kern_ms = {"predict_ms": 0.0, "slot_ms": 0.0, "apm_ms": 0.0, "coder_ms": 0.0, "pack_ms": 0.0, "generic_ms": 0.0}
+    kern_ms = {"predict_ms": 0.0, "achash_ms": 0.0, "slot_ms": 0.0, "apm_ms": 0.0, "coder_ms": 0.0, "pack_ms": 0.0, "generic_ms": 0.0}
     coder_bytes = 0
     launches = 0
     sync()
@@ -204,6 +204,8 @@ def main():
             if nslot:
                 cands.append(("k_slot (slot-state leaves: lane per block, hash map in HBM; all batches of a step)",
                               kern_ms["slot_ms"] / args.steps, nslot * n * (1 + 16 + 2 * 192)))
+            if kern_ms["achash_ms"] > 0:   # ACHistory leaves: one byte read + 8 key bytes written per input byte (+ the 8 MiB prefix table)
+                cands.append(("k_achash (ACHistory keys of every step, 16-bit prefix table)", kern_ms["achash_ms"] / args.steps, n * 9 + (8 << 20)))
             dom_name, dom_ms, dom_bytes = max(cands, key=lambda c: c[1])
             try:  # PMC-measured HBM bytes of this kernel for this exact config (profiles/, separate rocprofv3 --pmc passes)
                 for tj in json.load(open(os.path.join(ROOT, "profiles", "r1_traffic.json")))["entries"]:

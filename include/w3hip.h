@@ -197,6 +197,8 @@ typedef struct w3_timing {
     float    apm_ms;       /* APM stage kernels of the two-phase path (k_apm0 / k_apm1, + k_mix / k_partition they need) */
     float    slot_ms;      /* slot-state leaves: table zero-fill + k_slot launches (also inside predict_ms) */
     uint32_t n_slot_launches; /* k_slot launches (block batches sized to the device memory budget) */
+    float    achash_ms;    /* ACHistory key kernels (k_achash_lut + k_achash; also inside predict_ms) */
+    uint32_t reserved;
 } w3_timing;
 int w3_get_timing(const w3_ctx *ctx, w3_timing *out);
 

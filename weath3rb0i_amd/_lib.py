@@ -29,7 +29,7 @@ class Timing(C.Structure):
     _fields_ = [("predict_ms", C.c_float), ("coder_ms", C.c_float), ("pack_ms", C.c_float), ("generic_ms", C.c_float),
                 ("total_ms", C.c_float), ("path", C.c_uint32), ("n_coder_launches", C.c_uint32),
                 ("coder_bytes", C.c_uint64), ("predict_bytes", C.c_uint64), ("n_recoded_blocks", C.c_uint32), ("apm_ms", C.c_float),
-                ("slot_ms", C.c_float), ("n_slot_launches", C.c_uint32)]
+                ("slot_ms", C.c_float), ("n_slot_launches", C.c_uint32), ("achash_ms", C.c_float), ("reserved", C.c_uint32)]
 
 
 EXPORTS = [

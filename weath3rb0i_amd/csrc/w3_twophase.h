@@ -152,6 +152,7 @@ static inline int twophase_predict(TwoPhaseWs &ws, hipStream_t s, const ParsedSp
     w3::SlotArgs sa;
     memset(&sa, 0, sizeof sa);
     uint64_t slot_stride = 0;
+    bool achash_timed = false;
     if (n_live == 0) {
         hipLaunchKernelGGL(w3::k_fill_half, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (uint4 *)ws.P, (uint64_t)n);
         bytes += n * 16;
@@ -182,8 +183,10 @@ static inline int twophase_predict(TwoPhaseWs &ws, hipStream_t s, const ParsedSp
             memcpy(ha.table, nd.table, sizeof ha.table);
             if ((rc = tp_ensure(ws.achash_lut, ws.achash_lut_cap, (size_t)(8u << W3_ACHASH_LUT_BITS) * 16, err))) return rc;
             ha.lut = (uint4 *)ws.achash_lut;
+            if (ev && !achash_timed) (void)hipEventRecord(ev[12], s);   // (timed for the first ACHistory leaf)
             hipLaunchKernelGGL(w3::k_achash_lut, dim3((8u << W3_ACHASH_LUT_BITS) / 256), dim3(256), 0, s, ha);
             hipLaunchKernelGGL(w3::k_achash, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, ha);
+            if (ev && !achash_timed) { (void)hipEventRecord(ev[13], s); achash_timed = true; if (tm) tm->reserved = 1u; }
             pa.keys = (const uint2 *)ws.keys;
             launch_small<true>(nd.bits - 3, dim3(grid_small), s, pa);
             bytes += n * 17;

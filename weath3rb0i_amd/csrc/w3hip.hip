@@ -35,7 +35,7 @@ struct w3_ctx {
     int opt_path = W3_PATH_AUTO;
     int opt_timing = 0;
     w3_timing timing{};
-    hipEvent_t ev[12]{};
+    hipEvent_t ev[14]{};
     // workspace
     DevBuf tables, stripes, lens, offs, total, flag, io_in, io_out, coffs, misc, cm_luts;
     TwoPhaseWs tp;
@@ -511,6 +511,8 @@ extern "C" int w3_encode_blocks_device(w3_ctx *ctx, const w3_model_spec *spec, c
             ctx->timing.predict_ms = elapsed(ctx, 0); ctx->timing.coder_ms = elapsed(ctx, 1); ctx->timing.coder_bytes += total;
             ctx->timing.apm_ms = ps.n_apm ? elapsed(ctx, 4) : 0.f;
             ctx->timing.slot_ms = ps.has_slot ? elapsed(ctx, 5) : 0.f;
+            ctx->timing.achash_ms = ctx->timing.reserved ? elapsed(ctx, 6) : 0.f;
+            ctx->timing.reserved = 0u;
         }
         ctx->timing.pack_ms = elapsed(ctx, 2);
         ctx->timing.total_ms = elapsed(ctx, 3);
