@@ -202,7 +202,9 @@ static inline int twophase_predict(TwoPhaseWs &ws, hipStream_t s, const ParsedSp
             pa.job_counter = (uint32_t *)ws.splits + (size_t)nb * (W3_SLICES + 1);   // lives behind the split table
             (void)hipMemsetAsync(pa.job_counter, 0, 4, s);
             if (getenv("W3_DEBUG_NOSTORE")) pa.dbg_flags = 1u;   // timing experiment: results are wrong
-            uint32_t rank_waves = 2048u;   // ~128 blocks live: P regions stay in the Infinity Cache
+            // ~128 (order 1) / ~192 (order 2) blocks live: their P regions stay in the Infinity Cache.  Measured at 1e9 B
+            // (grid 1024 / 2048 / 3072 / 4096): order 1 26.8 / 19.0 / 23.7 / 27.6 ms, order 2 28.0 / 18.6 / 17.1 / 20.7 ms.
+            uint32_t rank_waves = c == LEAF_WIDE2 ? 3072u : 2048u;
             if (const char *ev_ = getenv("W3_RANK_GRID")) rank_waves = (uint32_t)std::max(64, atoi(ev_));   // tuning hook
             const uint32_t grid_rank = std::min<uint32_t>(nb * W3_SLICES, rank_waves);
             if (c == LEAF_WIDE1) {
