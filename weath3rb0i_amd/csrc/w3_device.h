@@ -145,14 +145,23 @@ struct Encoder {
 // ACReader + decoder side (io.rs:7-49, arithmetic_coder.rs:74-106)
 // ---------------------------------------------------------------------------
 struct BitSource {
-    const uint8_t *p; uint32_t len, pos; uint64_t win; uint32_t navail;
-    __device__ __forceinline__ void init(const uint8_t *s, uint32_t l) { p = s; len = l; pos = 0; win = 0; navail = 0; }
-    __device__ __forceinline__ uint32_t get(uint32_t k) {  // k in 0..32; zeros past EOF (io.rs:23-26)
-        while (navail <= 32u) {
-            uint32_t b = pos < len ? p[pos] : 0u;
-            pos++;
-            win = (win << 8) | b;
-            navail += 8u;
+    // ACReader (entropy_coding/io.rs:7-49): MSB-first bits, zeros past EOF (:23-26).  The stream is read four bytes at a
+    // time and ONE WORD AHEAD of its use (a byte-at-a-time read on demand put a dependent global load — ~1 us for a
+    // lone lane — into every few bit-steps of the decoder).
+    const uint8_t *p; uint32_t len, pos; uint64_t win; uint32_t navail, nxt;
+    __device__ __forceinline__ uint32_t load_word(uint32_t at) const {   // bytes [at, at+4) big-endian, zeros past len
+        uint32_t v = 0u;
+        if (at + 4u <= len) { uint32_t raw; __builtin_memcpy(&raw, p + at, 4); v = __builtin_bswap32(raw); }
+        else { for (uint32_t k = 0; k < 4u; k++) v = (v << 8) | (at + k < len ? p[at + k] : 0u); }
+        return v;
+    }
+    __device__ __forceinline__ void init(const uint8_t *s, uint32_t l) { p = s; len = l; pos = 4u; win = 0; navail = 0; nxt = load_word(0u); }
+    __device__ __forceinline__ uint32_t get(uint32_t k) {  // k in 0..32
+        if (navail < k) {            // refill: at most 31 bits are pending, so 32 more fit
+            win = (win << 32) | nxt;
+            navail += 32u;
+            nxt = load_word(pos);    // consumed one refill later
+            pos += 4u;
         }
         uint32_t v = (uint32_t)(win >> (navail - k));
         if (k < 32u) v &= (1u << k) - 1u;
