@@ -172,6 +172,22 @@ def test_apm_robust_coder_handback(ctx, oracle):
     assert lens.tolist() == wlens.tolist() and out.tobytes() == want.tobytes()
 
 
+def test_slot_tables_in_batches(ctx, oracle, monkeypatch):
+    """When the hash maps of all blocks do not fit the device budget, k_slot runs in equal batches of blocks
+    (tables zero-filled per batch); forced here with the tuning hook."""
+    data = markov_text(130 * 512 + 77, seed=14)
+    monkeypatch.setenv("W3_SLOT_BUDGET_MB", "40")     # slot2: 2^12 cells x 128 B = 512 KiB per block -> 64 blocks per batch
+    check(ctx, oracle, "slot2", data, 512, decode=False)
+    assert ctx.timing()["path"] == 1                   # (check() ends on its k_cm cross-check)
+    dev, _ = pair(oracle, "slot2")
+    ctx.set_timing(True)
+    try:
+        ctx.encode_blocks(dev(), data, 512)
+        assert ctx.timing()["n_slot_launches"] == 3
+    finally:
+        ctx.set_timing(False)
+
+
 def test_cm_reference_container(ctx, oracle):
     """w30i + length + ONE stream (main.rs:89-144) with a CM model."""
     d = markov_text(20000, seed=3)
