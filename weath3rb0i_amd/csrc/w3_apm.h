@@ -69,10 +69,10 @@ __device__ __forceinline__ void apm_table_init(lds_u16 *tab, const lds_u16 *s_ro
 
 // lane i receives the value of lane i - 8 / i + 8 of its 16-lane DPP row (lanes without a source get 0)
 __device__ __forceinline__ uint32_t dpp_from_lane_minus8(uint32_t v) {
-    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118 /* row_shr:8 */, 0xF, 0xF, false);
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118 /* row_shr:8 */, 0xF, 0xF, true);
 }
 __device__ __forceinline__ uint32_t dpp_from_lane_plus8(uint32_t v) {
-    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x108 /* row_shl:8 */, 0xF, 0xF, false);
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x108 /* row_shl:8 */, 0xF, 0xF, true);
 }
 
 // One round: 64 steps = 8 positions (k) x 8 bit positions (j), lane = 8 k + j.  Returns the refined probability of this
@@ -95,17 +95,24 @@ __device__ __forceinline__ uint32_t apm_round(lds_u16 *tab, const lds_i16 *s_str
     const bool fwd0 = odd && w_prev == er, fwd1 = odd && w_prev == er + 1u;   // the earlier position writes an entry I read
     const uint32_t ewr = (!odd && w_next == ew) ? dummy : ew;                  // the later position rewrites my entry: it stores
     uint32_t t0 = 0u, t1 = 0u;
+    // LDS byte addresses formed once, outside the sub-steps (hipcc re-derives `tab + index` per access otherwise)
+    lds_u16 *rd = tab + er;
+    const uint32_t wr_mine = (uint32_t)(uintptr_t)(tab + ewr), wr_idle = (uint32_t)(uintptr_t)(tab + dummy);
 #pragma unroll
     for (int kk = 0; kk < 8; kk += 2) {
         const bool mine = (k >> 1) == (kk >> 1);
-        uint32_t a0 = tab[er], a1 = tab[er + 1u];   // (one unaligned ds_read_b32 instead: 44 -> 113 ms, measured)
+        uint32_t a0 = rd[0], a1 = rd[1];   // (one unaligned ds_read_b32 instead: 44 -> 113 ms, measured)
         const int tvp = (int)(hi ? a1 : a0);
-        const uint32_t nvp = (uint32_t)(tvp + ((target - tvp) >> rate));       // arithmetic shift = floor; final on the earlier position
-        const uint32_t f = dpp_from_lane_minus8(nvp) & 0xFFFFu;
+        const uint32_t nvp = (uint32_t)(tvp + ((target - tvp) >> rate));       // arithmetic shift = floor; final on the earlier position; stays in [0, 65535]
+        const uint32_t f = dpp_from_lane_minus8(nvp);
         a0 = fwd0 ? f : a0; a1 = fwd1 ? f : a1;
         t0 = mine ? a0 : t0; t1 = mine ? a1 : t1;
         const int tv = (int)(hi ? a1 : a0);
-        tab[mine ? ewr : dummy] = (uint16_t)(tv + ((target - tv) >> rate));
+        {
+            uint32_t wa, wv = (uint32_t)(tv + ((target - tv) >> rate));
+            asm volatile("v_cndmask_b32 %0, %1, %2, %3" : "=v"(wa) : "v"(wr_idle), "v"(wr_mine), "s"(__ballot(mine)));
+            asm volatile("ds_write_b16 %0, %1" : : "v"(wa), "v"(wv) : "memory");
+        }
         W3_LDS_FENCE();
     }
     const uint32_t pa = (t0 * (4096u - w) + t1 * w) >> 12;
