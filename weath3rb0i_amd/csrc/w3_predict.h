@@ -103,14 +103,17 @@ __device__ __forceinline__ void match_keys(uint2 k8, uint64_t M[8]) {
 #pragma unroll
     for (int j = 0; j < 8; j++) {
         const uint32_t key = ((j < 4 ? k8.x : k8.y) >> (8 * (j & 3))) & 0xFFu;
-        uint64_t m = ~0ull;
+        // lanes whose key bit k equals mine: mybit ? B : ~B  ==  ~(B ^ sign-extended bit); folded into the running AND as one
+        // 3-input bit operation per 32-bit half (v_bitop3_b32) instead of two selects and two ANDs
+        uint32_t mlo = 0xFFFFFFFFu, mhi = 0xFFFFFFFFu;
 #pragma unroll
         for (int k = 0; k < H; k++) {
-            const bool mybit = (key >> k) & 1u;
-            const uint64_t B = __ballot(mybit);
-            m &= mybit ? B : ~B;
+            const uint32_t sm = (uint32_t)__builtin_amdgcn_sbfe((int)key, k, 1);
+            const uint64_t B = __ballot(sm != 0u);
+            mlo &= ~((uint32_t)B ^ sm);
+            mhi &= ~((uint32_t)(B >> 32) ^ sm);
         }
-        M[j] = m;
+        M[j] = ((uint64_t)mhi << 32) | mlo;
     }
 }
 
