@@ -140,4 +140,86 @@ __global__ void __launch_bounds__(64) k_generic(GenericArgs a) {
     }
 }
 
+// ---------------------------------------------------------------------------
+// The same loop for 1..4 leaves with the leaf count a template parameter: the leaves' Counter loads of a step are
+// independent, but the run-time leaf loop above waits for each before it starts the next (one memory round trip per
+// leaf and step, ~1 us each for a lone lane).  Here all addresses are formed first and the loads issued together;
+// an exact-map leaf issues its FIRST probe with them and only walks further (serially) on a collision.
+// ---------------------------------------------------------------------------
+template <bool DECODE, int NL>
+__global__ void __launch_bounds__(64) k_generic_nl(GenericArgs a) {
+    __shared__ LeafParam s_leaf[W3_MAX_LEAVES];
+    stage_leaves(s_leaf, a);
+    const uint32_t lane = blockIdx.x * blockDim.x + threadIdx.x;
+    if (lane >= a.n_lanes) return;
+    const uint32_t b = a.first_block + lane;
+    const uint64_t off = (uint64_t)b * a.block_size;
+    const uint32_t len = (uint32_t)((a.n - off) < a.block_size ? (a.n - off) : a.block_size);
+    uint8_t *lane_tbl = a.tables + (uint64_t)lane * a.lane_stride;
+    const LeafParam *lp = s_leaf;   // (a register copy goes to scratch: ACHistory indexes lp.table dynamically)
+
+    Encoder enc; Decoder dec;
+    if (DECODE) dec.init(a.cin + a.coffs[b], a.clens[b]);
+    else enc.init(a.stripes + (uint64_t)lane * a.stripe_cap, a.stripe_cap);
+
+    uint64_t hist64 = 0; uint32_t t = 0;
+    for (uint32_t i = 0; i < len; i++) {
+        uint32_t byte = DECODE ? 0u : a.in[off + i];
+        for (int s = 7; s >= 0; s--) {
+            uint32_t *slot[NL]; uint32_t val[NL], key[NL], ctx[NL];
+            // 1. every leaf's address, then every leaf's load
+#pragma unroll
+            for (int l = 0; l < NL; l++) {
+                slot[l] = nullptr; val[l] = 0u; key[l] = 0u; ctx[l] = 0u;
+                if (!lp[l].frozen) {
+                    ctx[l] = leaf_ctx(lp[l], hist64, t);
+                    uint32_t *tbl = reinterpret_cast<uint32_t *>(lane_tbl + lp[l].tbl_off);
+                    if (!lp[l].use_hash) slot[l] = tbl + ctx[l];
+                    else slot[l] = tbl + 2u * (((ctx[l] * 2654435761u) ^ (ctx[l] >> 15)) & lp[l].hash_mask);   // first probe (leaf_slot)
+                }
+            }
+#pragma unroll
+            for (int l = 0; l < NL; l++) {
+                if (slot[l]) {
+                    if (!lp[l].use_hash) val[l] = *slot[l];
+                    else { const uint2 kv = *reinterpret_cast<const uint2 *>(slot[l]); key[l] = kv.x; val[l] = kv.y; }
+                }
+            }
+            // 2. exact-map leaves: hit, claim an empty slot, or keep probing (leaf_slot semantics)
+#pragma unroll
+            for (int l = 0; l < NL; l++) {
+                if (slot[l] && lp[l].use_hash) {
+                    if (key[l] == ctx[l] + 1u) slot[l] += 1;
+                    else if (key[l] == 0u) { slot[l][0] = ctx[l] + 1u; slot[l] += 1; val[l] = 0u; }
+                    else { slot[l] = leaf_slot(lp[l], lane_tbl, ctx[l]); val[l] = *slot[l]; }
+                }
+            }
+            // 3. predict: leftmost leaf of maximal |p - 1/2| (BestOfTwo tree, models/mod.rs:67-69)
+            uint32_t p = 32768u, best = 0u;
+#pragma unroll
+            for (int l = 0; l < NL; l++) {
+                const uint32_t pl = slot[l] ? counter_p_packed(val[l]) : 32768u;
+                const uint32_t d = opinion_dist(pl);
+                if (l == 0 || d > best) { p = pl; best = d; }
+            }
+            uint32_t bit;
+            if (DECODE) { bit = dec.decode(p); byte = (byte << 1) | bit; }
+            else bit = (byte >> s) & 1u;
+            // Model::update = adapt (train current ctx) then update (advance)  models/mod.rs:28-31
+#pragma unroll
+            for (int l = 0; l < NL; l++)
+                if (slot[l]) *slot[l] = counter_update_packed(val[l], bit);
+            hist64 = (hist64 << 1) | bit;
+            t++;
+            if (!DECODE) enc.encode(bit, p);
+        }
+        if (DECODE) a.dout[off + i] = (uint8_t)byte;
+    }
+    if (!DECODE) {
+        uint32_t produced = enc.flush();
+        a.out_len[b] = produced;
+        if (produced > a.stripe_cap) atomicOr(a.overflow, 1u);
+    }
+}
+
 }  // namespace w3

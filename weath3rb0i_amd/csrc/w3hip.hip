@@ -294,7 +294,13 @@ static int generic_encode(w3_ctx *ctx, hipStream_t s, const ParsedSpec &ps, cons
         ga.first_block = first; ga.n_lanes = cnt;
         ga.stripes = (uint8_t *)ctx->stripes.p + (uint64_t)first * stripe_cap;
         HIPCHK(ctx, hipMemsetAsync(ctx->tables.p, 0, (size_t)cnt * lane_stride, s));
-        hipLaunchKernelGGL(k_generic<false>, dim3((cnt + 63) / 64), dim3(64), 0, s, ga);
+        switch (ga.n_leaves) {   // 1-4 leaves: all Counter loads of a step in flight together
+        case 1: hipLaunchKernelGGL((k_generic_nl<false, 1>), dim3((cnt + 63) / 64), dim3(64), 0, s, ga); break;
+        case 2: hipLaunchKernelGGL((k_generic_nl<false, 2>), dim3((cnt + 63) / 64), dim3(64), 0, s, ga); break;
+        case 3: hipLaunchKernelGGL((k_generic_nl<false, 3>), dim3((cnt + 63) / 64), dim3(64), 0, s, ga); break;
+        case 4: hipLaunchKernelGGL((k_generic_nl<false, 4>), dim3((cnt + 63) / 64), dim3(64), 0, s, ga); break;
+        default: hipLaunchKernelGGL(k_generic<false>, dim3((cnt + 63) / 64), dim3(64), 0, s, ga); break;
+        }
         HIPCHK(ctx, hipGetLastError());
     }
     return W3_OK;
@@ -319,7 +325,13 @@ static int generic_decode(w3_ctx *ctx, hipStream_t s, const ParsedSpec &ps, cons
         uint32_t cnt = std::min(lanes, nb - first);
         ga.first_block = first; ga.n_lanes = cnt;
         HIPCHK(ctx, hipMemsetAsync(ctx->tables.p, 0, (size_t)cnt * lane_stride, s));
-        hipLaunchKernelGGL(k_generic<true>, dim3((cnt + 63) / 64), dim3(64), 0, s, ga);
+        switch (ga.n_leaves) {
+        case 1: hipLaunchKernelGGL((k_generic_nl<true, 1>), dim3((cnt + 63) / 64), dim3(64), 0, s, ga); break;
+        case 2: hipLaunchKernelGGL((k_generic_nl<true, 2>), dim3((cnt + 63) / 64), dim3(64), 0, s, ga); break;
+        case 3: hipLaunchKernelGGL((k_generic_nl<true, 3>), dim3((cnt + 63) / 64), dim3(64), 0, s, ga); break;
+        case 4: hipLaunchKernelGGL((k_generic_nl<true, 4>), dim3((cnt + 63) / 64), dim3(64), 0, s, ga); break;
+        default: hipLaunchKernelGGL(k_generic<true>, dim3((cnt + 63) / 64), dim3(64), 0, s, ga); break;
+        }
         HIPCHK(ctx, hipGetLastError());
     }
     return W3_OK;
