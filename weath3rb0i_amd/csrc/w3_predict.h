@@ -570,6 +570,7 @@ __global__ void __launch_bounds__(256) k_mix(MixArgs a) {
 struct HashArgs {
     const uint8_t *in; uint64_t n; uint32_t block_size; uint32_t max_bits; uint32_t hmask; uint16_t table[8]; uint2 *keys;
     uint4 *lut;   // [65536][8] coder state after the 16 most recent history bits, per bit position (k_achash_lut)
+    uint16_t *lut_key;   // [65536][8] the finished key (low 8 bits) | 0x8000 when the hash is complete after those 16 bits
 };
 
 __device__ __forceinline__ uint32_t sel8(const uint32_t (&v)[8], uint32_t k) {   // k is wave-uniform: scalar selects, no indexing
@@ -595,39 +596,76 @@ __global__ void __launch_bounds__(256) k_achash_lut(HashArgs a) {
     }
     const ACHashState s = ac_history_hash_steps((uint64_t)v, a.max_bits, rot, ac_hash_state_init(a.max_bits), 0, W3_ACHASH_LUT_BITS);
     a.lut[e] = make_uint4(s.x1, s.x2, s.hash, s.meta);
+    a.lut_key[e] = (uint16_t)((s.meta >> 31) ? (0x8000u | ((ac_hash_finish(s, a.max_bits) & a.hmask) & 0xFFu)) : 0u);
 }
 
 __global__ void __launch_bounds__(256) k_achash(HashArgs a) {
+    // Phase 1, per byte position and bit position: the 16-bit prefix table.  Most hashes are complete there (max_bits
+    // output bits written); the rest are QUEUED per wavefront (their ids, in LDS).  Phase 2 runs the queue 64 hashes at a
+    // time, every lane busy, until the slowest is done — instead of eight loops per wave that each run as long as their
+    // slowest lane.  A queued hash is rebuilt from its owner lane's registers (history, byte) and its table entry.
+    __shared__ uint16_t q_id[4][512];      // lane << 3 | bit position
+    __shared__ uint8_t q_key[4][64][8];    // results of the queued hashes, by (lane, bit position)
     const uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (g >= a.n) return;
-    const uint64_t b = g / a.block_size;
-    const uint32_t i = (uint32_t)(g - b * a.block_size);
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    const bool live = g < a.n;
+    const uint64_t gc = live ? g : a.n - 1u;
+    const uint64_t b = gc / a.block_size;
+    const uint32_t i = (uint32_t)(gc - b * a.block_size);
     const uint8_t *blk = a.in + b * a.block_size;
     // the last 64 bits before bit 0 of byte i, newest at bit 0
-    uint64_t hist = 0;
-    for (uint32_t k = 1; k <= 8 && k <= i; k++) hist |= (uint64_t)blk[i - k] << (8 * (k - 1));
+    uint64_t hist0 = 0;
+    for (uint32_t k = 1; k <= 8 && k <= i; k++) hist0 |= (uint64_t)blk[i - k] << (8 * (k - 1));
     const uint32_t c0 = blk[i];
     uint32_t p32t[8];
 #pragma unroll
     for (int k = 0; k < 8; k++) p32t[k] = a.table[k] ? ((uint32_t)a.table[k] << 16) : 1u;   // lerp operand, arithmetic_coder.rs:111
     uint32_t out[2] = {0, 0};
+    uint32_t qn = 0, pend = 0;   // wave-uniform queue length; this lane's pending bit positions
+    uint64_t hist = hist0;
 #pragma unroll 1
     for (int j = 0; j < 8; j++) {
         const uint32_t t = i * 8u + j;
-        // every lane of the wave is at bit position j: the r-th coded history bit uses table[(j - 1 - r) & 7]
-        uint32_t rot[8];
-#pragma unroll
-        for (int r = 0; r < 8; r++) rot[r] = sel8(p32t, (uint32_t)(j + 7 - r) & 7u);
-        uint32_t h = 0;
-        if (t != 0u) {   // ctx starts at 0 (ordern_entropy.rs:19)
-            const uint4 le = a.lut[((uint32_t)hist & ((1u << W3_ACHASH_LUT_BITS) - 1u)) * 8u + (uint32_t)j];
-            ACHashState st; st.x1 = le.x; st.x2 = le.y; st.hash = le.z; st.meta = le.w;
-            h = ac_hash_finish(ac_history_hash_steps(hist, a.max_bits, rot, st, W3_ACHASH_LUT_BITS, 64), a.max_bits) & a.hmask;
+        bool pending = false;
+        if (live && t != 0u) {   // ctx starts at 0 (ordern_entropy.rs:19)
+            const uint32_t le = a.lut_key[((uint32_t)hist & ((1u << W3_ACHASH_LUT_BITS) - 1u)) * 8u + (uint32_t)j];   // 2-byte entry: 1 MiB table
+            if (le & 0x8000u) out[j >> 2] |= (le & 0xFFu) << (8 * (j & 3));
+            else pending = true;
         }
-        out[j >> 2] |= (h & 0xFFu) << (8 * (j & 3));
+        const uint64_t pm = __ballot(pending);
+        if (pending) { q_id[wave][qn + mbcnt64(pm)] = (uint16_t)((lane << 3) | (uint32_t)j); pend |= 1u << j; }
+        qn += (uint32_t)__popcll(pm);
         hist = (hist << 1) | ((c0 >> (7 - j)) & 1u);
     }
-    a.keys[g] = make_uint2(out[0], out[1]);
+    __asm__ volatile("" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    for (uint32_t base = 0; base < qn; base += 64u) {
+        const uint32_t e = base + lane;
+        const uint32_t id = q_id[wave][min(e, qn - 1u)], j = id & 7u, owner = id >> 3;
+        // the owner's history at bit position j: its byte-aligned history shifted by the first j bits of its byte
+        const uint32_t olo = (uint32_t)__shfl((int)(uint32_t)hist0, (int)owner, 64), ohi = (uint32_t)__shfl((int)(uint32_t)(hist0 >> 32), (int)owner, 64);
+        const uint32_t oc0 = (uint32_t)__shfl((int)c0, (int)owner, 64);
+        if (e < qn) {
+            const uint64_t h = (((((uint64_t)ohi << 32) | olo)) << j) | (uint64_t)(oc0 >> (8u - j));
+            const uint4 sv = a.lut[((uint32_t)h & ((1u << W3_ACHASH_LUT_BITS) - 1u)) * 8u + j];
+            // StationaryModel::predict walks the bit positions backwards from j: the r-th coded history bit uses table[(j - 1 - r) & 7]
+            uint32_t rot[8];
+#pragma unroll
+            for (int r = 0; r < 8; r++) {
+                const uint32_t k = (j + 7u - (uint32_t)r) & 7u;
+                rot[r] = k == 0 ? p32t[0] : k == 1 ? p32t[1] : k == 2 ? p32t[2] : k == 3 ? p32t[3] : k == 4 ? p32t[4] : k == 5 ? p32t[5] : k == 6 ? p32t[6] : p32t[7];
+            }
+            ACHashState st; st.x1 = sv.x; st.x2 = sv.y; st.hash = sv.z; st.meta = sv.w;
+            st = ac_history_hash_steps(h, a.max_bits, rot, st, W3_ACHASH_LUT_BITS, 64);
+            q_key[wave][owner][j] = (uint8_t)(ac_hash_finish(st, a.max_bits) & a.hmask);
+        }
+    }
+    __asm__ volatile("" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int j = 0; j < 8; j++)
+        if ((pend >> j) & 1u) out[j >> 2] |= (uint32_t)q_key[wave][lane][j] << (8 * (j & 3));
+    if (live) a.keys[g] = make_uint2(out[0], out[1]);
 }
 
 // FrozenModel as the leftmost leaf: every p is Counter::new().p() = 32768

@@ -181,8 +181,9 @@ static inline int twophase_predict(TwoPhaseWs &ws, hipStream_t s, const ParsedSp
             ha.in = d_in; ha.n = n; ha.block_size = (uint32_t)block_size; ha.max_bits = nd.max_bits;
             ha.hmask = (1u << (nd.bits - 3)) - 1u; ha.keys = (uint2 *)ws.keys;
             memcpy(ha.table, nd.table, sizeof ha.table);
-            if ((rc = tp_ensure(ws.achash_lut, ws.achash_lut_cap, (size_t)(8u << W3_ACHASH_LUT_BITS) * 16, err))) return rc;
+            if ((rc = tp_ensure(ws.achash_lut, ws.achash_lut_cap, (size_t)(8u << W3_ACHASH_LUT_BITS) * 18, err))) return rc;
             ha.lut = (uint4 *)ws.achash_lut;
+            ha.lut_key = (uint16_t *)((uint8_t *)ws.achash_lut + (size_t)(8u << W3_ACHASH_LUT_BITS) * 16);
             if (ev && !achash_timed) (void)hipEventRecord(ev[12], s);   // (timed for the first ACHistory leaf)
             hipLaunchKernelGGL(w3::k_achash_lut, dim3((8u << W3_ACHASH_LUT_BITS) / 256), dim3(256), 0, s, ha);
             hipLaunchKernelGGL(w3::k_achash, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, ha);
