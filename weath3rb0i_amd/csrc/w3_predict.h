@@ -581,7 +581,7 @@ __device__ __forceinline__ uint32_t sel8(const uint32_t (&v)[8], uint32_t k) {  
 // 65536 x 8 possible prefixes.  Their coder states are tabulated once per call (the idea of the reference's
 // ACHistoryCached memo, history/ac_history_cached.rs:31-76, as a dense 8 MiB table that stays in L2 / Infinity Cache);
 // every hash starts from its entry at step 16 — with max_bits = 8 most are already complete there.
-#define W3_ACHASH_LUT_BITS 16
+#define W3_ACHASH_LUT_BITS 16   // (a multiple of 8: ac_history_hash_steps advances 8 history bits at a time)
 __global__ void __launch_bounds__(256) k_achash_lut(HashArgs a) {
     const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;   // e = v * 8 + j
     if (e >= (8u << W3_ACHASH_LUT_BITS)) return;
