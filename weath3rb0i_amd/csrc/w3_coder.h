@@ -494,7 +494,7 @@ __global__ void __launch_bounds__(192) k_coder_x3(Coder3Args a) {
 
     if (wave == 1) {
         // ------------------------------ X-wave ------------------------------
-        // The recurrence (arithmetic_coder.rs:41-65) as a 9-deep dependency chain of 18 VALU instructions per step.
+        // The recurrence (arithmetic_coder.rs:41-65) as a 9-deep dependency chain of 15 VALU instructions per step.
         // (Measured: the shorter chain bought nothing — 30.2 -> 29.8 ms — because ONE wave issues a VALU instruction only
         // every ~7-8 cycles whether it is dependent or not; the step costs its instruction COUNT, ~20 with the LDS ops.)
         //   m    = mulhi(d, p32)                                  d = x2 - x1, carried from the previous step
@@ -516,28 +516,42 @@ __global__ void __launch_bounds__(192) k_coder_x3(Coder3Args a) {
             for (uint32_t k = 0; k < 8u; k++) {
                 if (i + k < len) {
                     const size_t ring = ((size_t)((i + k) & (W3_X2_RING - 1u)) * 8u) * 64u + lane;
+                    // token slot base as an LDS byte address in a register: the ring sits above 64 KiB, beyond the reach of the
+                    // 16-bit ds offset field, and hipcc re-forms base + constant with an extra VALU instruction per store otherwise
+                    typedef __attribute__((address_space(3))) uint64_t lds_tok_t;
+                    lds_tok_t *tokp = (lds_tok_t *)&tok[ring];
+                    asm volatile("" : "+v"(tokp));
                     uint2 op[8];
 #pragma unroll
                     for (int j = 0; j < 8; j++) op[j] = opq[ring + j * 64];
 #pragma unroll
                     for (int j = 0; j < 8; j++) {
                         const uint32_t p32 = op[j].x, bitmask = op[j].y;   // ~0 when the coded bit is 1
-                        const uint32_t m = __umulhi(d, p32);
-                        const uint32_t xmid = x1 + m;
-                        uint32_t x1n, x2n, e, t, nb1;
-                        // v_bfi_b32: (mask & a) | (~mask & b).  hipcc turns the C form into v_cmp + 2 v_cndmask + s_nop.
-                        asm("v_bfi_b32 %0, %1, 0, %2" : "=v"(t) : "v"(bitmask), "v"(m));          // bit ? 0 : m
-                        asm("v_bfi_b32 %0, %1, 0, 1" : "=v"(nb1) : "v"(bitmask));                // bit ? 0 : 1
-                        asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(x2n) : "v"(bitmask), "v"(xmid), "v"(x2));
-                        asm("v_add3_u32 %0, %1, %2, %3" : "=v"(x1n) : "v"(x1), "v"(t), "v"(nb1));
-                        asm("v_bfi_b32 %0, %1, %2, -1" : "=v"(e) : "v"(x1n), "v"(x2n));          // ~x1n | x2n
-                        const uint32_t u = (x1n ^ x2n) & ((e << 1) | 1u);
-                        const uint32_t sft = (uint32_t)__builtin_clz(u);
-                        tok[ring + j * 64] = make_uint2(x1n, sft);
-                        const uint32_t X1 = x1n << sft, X2 = ((x2n + 1u) << sft) - 1u;
-                        d = X2 - X1;
-                        x1 = X1 & 0x7FFFFFFFu;
-                        x2 = X2 | 0x80000000u;
+                        // The whole step as ONE asm statement (15 VALU): hipcc pads every separate inline-asm VALU statement with an
+                        // s_nop (an issue slot of the lone wave each), and its own rendering of the C form takes 22 instructions.
+                        //   m = mulhi(d, p32); xmid = x1 + m; xmid1 = xmid + 1
+                        //   x2n = bit ? xmid : x2;  x1n = bit ? x1 : xmid1                      (v_bfi: (mask & a) | (~mask & b))
+                        //   u = (x1n ^ x2n) & ((~x1n | x2n) << 1 | 1);  s = clz(u)
+                        //   X1 = x1n << s;  X2 = ((x2n + 1) << s) - 1;  d = X2 - X1;  x1 = X1 & 0x7FFFFFFF;  x2 = X2 | 0x80000000
+                        uint32_t x1n, sft, t0, t1;
+                        asm("v_mul_hi_u32 %4, %2, %7\n\t"          // t0 = m
+                            "v_add_u32 %5, %0, %4\n\t"             // t1 = xmid
+                            "v_add3_u32 %4, %0, %4, 1\n\t"         // t0 = xmid1
+                            "v_bfi_b32 %1, %8, %5, %1\n\t"         // x2 = x2n
+                            "v_bfi_b32 %3, %8, %0, %4\n\t"         // x1n
+                            "v_bfi_b32 %4, %3, %1, -1\n\t"         // t0 = ~x1n | x2n
+                            "v_lshl_or_b32 %4, %4, 1, 1\n\t"       // t0 = g
+                            "v_bitop3_b32 %5, %4, %3, %1 bitop3:0x60\n\t"   // t1 = u = g & (x1n ^ x2n)
+                            "v_ffbh_u32 %6, %5\n\t"                // s
+                            "v_add_u32 %4, 1, %1\n\t"              // t0 = x2n + 1
+                            "v_lshlrev_b32 %0, %6, %3\n\t"         // x1 = X1 (raw)
+                            "v_lshl_add_u32 %1, %4, %6, -1\n\t"    // x2 = X2 (raw)
+                            "v_sub_u32 %2, %1, %0\n\t"             // d
+                            "v_and_b32 %0, 0x7fffffff, %0\n\t"
+                            "v_or_b32 %1, 0x80000000, %1"
+                            : "+v"(x1), "+v"(x2), "+v"(d), "=&v"(x1n), "=&v"(t0), "=&v"(t1), "=&v"(sft)
+                            : "v"(p32), "v"(bitmask));
+                        tokp[j * 64] = ((uint64_t)sft << 32) | x1n;
                     }
                     if (i + k + 1u == len) fin_x2[lane] = x2;
                 }
