@@ -23,7 +23,7 @@ __device__ __forceinline__ uint32_t counter_p(uint32_t c0, uint32_t c1) {
     int32_t rem = (int32_t)((a << 17) - q * d);  // true remainder is tiny: mod-2^32 arithmetic is exact
     if (rem < 0) q -= 1u;
     else if (rem >= (int32_t)d) q += 1u;
-    return (q >> 1) + (q & 1u);
+    return (q + 1u) >> 1;   // (q >> 1) + (q & 1), counter.rs:17
 }
 
 // packed counter: low 16 = data[0], high 16 = data[1]
