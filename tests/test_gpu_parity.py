@@ -21,6 +21,7 @@ def pair(oracle, name):
     """(device model, oracle model factory) for a named configuration."""
     book1 = [1, 50188, 62497, 15819, 22545, 31499, 22988, 29616]
     enwik7 = [752, 50314, 58928, 21421, 24680, 30788, 24297, 32530]
+    edge = [0, 65535, 1, 32768, 0, 65535, 12345, 1]
     table = {
         "order0": (lambda: w3.Order0(), lambda: oracle.Order0()),
         "order1": (lambda: w3.Order1(), lambda: oracle.Order1()),
@@ -45,6 +46,11 @@ def pair(oracle, name):
                        lambda: oracle.OrderNEntropy(7, 3, oracle.ACHistory(4, oracle.StationaryModel.from_table(enwik7)))),
         "ac_11_3_mb16": (lambda: w3.OrderNEntropy(11, 3, w3.ACHistory(16, w3.StationaryModel.for_book1())),
                          lambda: oracle.OrderNEntropy(11, 3, oracle.ACHistory(16, oracle.StationaryModel.from_table(book1)))),
+        # extreme StationaryModel tables: prob 0 (lerp operand 1: up to 32 bits per coded history bit), 65535, 1, one half
+        "ac_edge_table_mb8": (lambda: w3.OrderNEntropy(11, 3, w3.ACHistory(8, w3.StationaryModel.from_table(edge))),
+                              lambda: oracle.OrderNEntropy(11, 3, oracle.ACHistory(8, oracle.StationaryModel.from_table(edge)))),
+        "ac_edge_table_mb32": (lambda: w3.OrderNEntropy(11, 3, w3.ACHistory(32, w3.StationaryModel.from_table(edge))),
+                               lambda: oracle.OrderNEntropy(11, 3, oracle.ACHistory(32, oracle.StationaryModel.from_table(edge)))),
         "best_frozen_first": (lambda: w3.BestOfTwoModel(w3.FrozenModel(w3.Order1()), w3.Order0()),
                               lambda: oracle.BestOfTwoModel(oracle.FrozenModel(oracle.Order1()), oracle.Order0())),
         "best_ac_wide": (lambda: w3.BestOfTwoModel(w3.init_model(), w3.BestOfTwoModel(w3.OrderN(27, 3), w3.Order1())),
@@ -78,7 +84,8 @@ ALL = ["order0", "order1", "order2", "ordern_12_0", "ordern_14_4", "ordern_9_1",
 
 
 TWOPHASE = ["order0", "order1", "order2", "ordern_8_3", "ordern_5_3", "ordern_3_3", "ordern_10_3", "main_default", "ac_7_3_mb4",
-            "ac_11_3_mb16", "frozen0", "best01", "best012", "best_right", "best_frozen_first", "best_ac_wide"]
+            "ac_11_3_mb16", "ac_edge_table_mb8", "ac_edge_table_mb32", "frozen0", "best01", "best012", "best_right", "best_frozen_first",
+            "best_ac_wide"]
 NOT_TWOPHASE = ["ordern_12_0", "ordern_14_4", "ordern_22_2", "ordern_30_3", "raw_16_3", "ac_19_3_enwik7"]
 
 
