@@ -27,6 +27,11 @@ struct TwoPhaseWs {
     const int16_t *stretch = nullptr;   // APM LUTs (device; owned by the ctx)
     const uint16_t *squash = nullptr;
     const uint2 *st = nullptr;          // NaiveStateTable rows for the slot-state leaves (device; owned by the ctx)
+    // wide Counter leaves: their k_partition passes run on a side stream beside the time-ordered leaves' kernels
+    void *rec_w[4] = {nullptr, nullptr, nullptr, nullptr}, *perm_w[4] = {nullptr, nullptr, nullptr, nullptr}, *splits_w[4] = {nullptr, nullptr, nullptr, nullptr};
+    size_t rec_w_cap[4] = {0, 0, 0, 0}, perm_w_cap[4] = {0, 0, 0, 0}, splits_w_cap[4] = {0, 0, 0, 0};
+    hipStream_t side = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join[4] = {nullptr, nullptr, nullptr, nullptr};
     void *achash_lut = nullptr;         // k_achash_lut: [65536][8] coder states (8 MiB)
     size_t achash_lut_cap = 0;
     void *dummy = nullptr;              // 256-byte sink for predicated-off stores (w3_apm.h)
@@ -40,6 +45,16 @@ struct TwoPhaseWs {
         if (keys) (void)hipFree(keys);
         if (perm) (void)hipFree(perm);
         if (redo) (void)hipFree(redo);
+        for (int w = 0; w < 4; w++) {
+            if (rec_w[w]) (void)hipFree(rec_w[w]);
+            if (perm_w[w]) (void)hipFree(perm_w[w]);
+            if (splits_w[w]) (void)hipFree(splits_w[w]);
+            rec_w[w] = perm_w[w] = splits_w[w] = nullptr; rec_w_cap[w] = perm_w_cap[w] = splits_w_cap[w] = 0;
+        }
+        if (side) (void)hipStreamDestroy(side);
+        if (ev_fork) (void)hipEventDestroy(ev_fork);
+        for (int w = 0; w < 4; w++) { if (ev_join[w]) (void)hipEventDestroy(ev_join[w]); ev_join[w] = nullptr; }
+        side = nullptr; ev_fork = nullptr;
         if (achash_lut) (void)hipFree(achash_lut);
         achash_lut = nullptr; achash_lut_cap = 0;
         if (dummy) (void)hipFree(dummy);
@@ -133,9 +148,21 @@ static inline int twophase_predict(TwoPhaseWs &ws, hipStream_t s, const ParsedSp
         need_perm |= c == LEAF_WIDE1 || c == LEAF_WIDE2;
     }
     if (need_keys && (rc = tp_ensure(ws.keys, ws.keys_cap, n * 8, err))) return rc;
-    if (need_perm && (rc = tp_ensure(ws.perm, ws.perm_cap, (size_t)grid_wide * 2 * block_size * 8, err))) return rc;
-    if (need_perm && (rc = tp_ensure(ws.rec, ws.rec_cap, n * 8, err))) return rc;
-    if (need_perm && (rc = tp_ensure(ws.splits, ws.splits_cap, (size_t)nb * (W3_SLICES + 1) * 4 + 64, err))) return rc;
+    if (need_perm) {
+        int nw = 0;
+        for (int l = 0; l < ps.n_leaves; l++) { const int c = leaf_class(ps.leaf[l]); nw += c == LEAF_WIDE1 || c == LEAF_WIDE2; }
+        if (nw > 4) { err = "more than 4 wide Counter leaves"; return W3_E_UNSUPPORTED; }
+        for (int w = 0; w < nw; w++) {
+            if ((rc = tp_ensure(ws.perm_w[w], ws.perm_w_cap[w], (size_t)grid_wide * 2 * block_size * 8, err))) return rc;
+            if ((rc = tp_ensure(ws.rec_w[w], ws.rec_w_cap[w], n * 8, err))) return rc;
+            if ((rc = tp_ensure(ws.splits_w[w], ws.splits_w_cap[w], (size_t)nb * (W3_SLICES + 1) * 4 + 64, err))) return rc;
+        }
+        if (!ws.side) {
+            bool ok = hipStreamCreateWithFlags(&ws.side, hipStreamNonBlocking) == hipSuccess && hipEventCreateWithFlags(&ws.ev_fork, hipEventDisableTiming) == hipSuccess;
+            for (int w = 0; w < 4 && ok; w++) ok = hipEventCreateWithFlags(&ws.ev_join[w], hipEventDisableTiming) == hipSuccess;
+            if (!ok) { (void)hipGetLastError(); err = "side stream creation failed"; return W3_E_HIP; }
+        }
+    }
 
     // FrozenModel leaves never adapt: p == 32768, distance 0.  They can never beat a trained leaf and tie
     // only when every leaf says 32768, so they matter only if ALL leaves are frozen.
@@ -146,6 +173,13 @@ static inline int twophase_predict(TwoPhaseWs &ws, hipStream_t s, const ParsedSp
     if (n_live <= 1 && (rc = tp_ensure(ws.P, ws.P_cap, n * 16, err))) return rc;
 
     if (ev) (void)hipEventRecord(ev[0], s);
+    // fork: the partition passes of the wide leaves go to the side stream (they are bound by scattered line requests, the
+    // time-ordered kernels by VALU issue); the rank kernels follow on the main stream after the join
+    const bool forked = need_perm && !getenv("W3_NO_SIDE_STREAM");
+    hipStream_t sp = forked ? ws.side : s;
+    if (forked) { (void)hipEventRecord(ws.ev_fork, s); (void)hipStreamWaitEvent(ws.side, ws.ev_fork, 0); }
+    struct Deferred { w3::PredictArgs pa; int cls; uint32_t grid_rank; } deferred[4];
+    int n_def = 0;
     uint64_t bytes = 0;
     w3::MixArgs &ma = ws.mix;
     memset(&ma, 0, sizeof ma);
@@ -194,31 +228,37 @@ static inline int twophase_predict(TwoPhaseWs &ws, hipStream_t s, const ParsedSp
         } else if (c == LEAF_SMALL) {
             launch_small<false>(nd.bits - 3, dim3(grid_small), s, pa);
         } else {
-            pa.perm = (uint32_t *)ws.perm;
+            const int w = n_def;
+            pa.perm = (uint32_t *)ws.perm_w[w];
             if (ws.debug_stamps) {
                 if (!ws.dbg && hipMalloc(&ws.dbg, 64) != hipSuccess) ws.dbg = nullptr;
                 if (ws.dbg) { (void)hipMemsetAsync(ws.dbg, 0, 64, s); pa.dbg = (unsigned long long *)ws.dbg; }
             }
-            pa.rec = (uint2 *)ws.rec; pa.splits = (uint32_t *)ws.splits;
-            pa.job_counter = (uint32_t *)ws.splits + (size_t)nb * (W3_SLICES + 1);   // lives behind the split table
-            (void)hipMemsetAsync(pa.job_counter, 0, 4, s);
+            pa.rec = (uint2 *)ws.rec_w[w]; pa.splits = (uint32_t *)ws.splits_w[w];
+            pa.job_counter = (uint32_t *)ws.splits_w[w] + (size_t)nb * (W3_SLICES + 1);   // lives behind the split table
+            (void)hipMemsetAsync(pa.job_counter, 0, 4, sp);
             if (getenv("W3_DEBUG_NOSTORE")) pa.dbg_flags = 1u;   // timing experiment: results are wrong
             // ~128 (order 1) / ~192 (order 2) blocks live: their P regions stay in the Infinity Cache.  Measured at 1e9 B
             // (grid 1024 / 2048 / 3072 / 4096): order 1 26.8 / 19.0 / 23.7 / 27.6 ms, order 2 28.0 / 18.6 / 17.1 / 20.7 ms.
             uint32_t rank_waves = c == LEAF_WIDE2 ? 3072u : 2048u;
             if (const char *ev_ = getenv("W3_RANK_GRID")) rank_waves = (uint32_t)std::max(64, atoi(ev_));   // tuning hook
             const uint32_t grid_rank = std::min<uint32_t>(nb * W3_SLICES, rank_waves);
-            if (c == LEAF_WIDE1) {
-                hipLaunchKernelGGL(w3::k_partition<1>, dim3(grid_wide), dim3(64), 0, s, pa);
-                hipLaunchKernelGGL(w3::k_rank_sorted<1>, dim3(grid_rank), dim3(64), 0, s, pa);
-            } else {
-                hipLaunchKernelGGL(w3::k_partition<2>, dim3(grid_wide), dim3(64), 0, s, pa);
-                hipLaunchKernelGGL(w3::k_rank_sorted<2>, dim3(grid_rank), dim3(64), 0, s, pa);
-            }
+            if (c == LEAF_WIDE1) hipLaunchKernelGGL(w3::k_partition<1>, dim3(grid_wide), dim3(64), 0, sp, pa);
+            else hipLaunchKernelGGL(w3::k_partition<2>, dim3(grid_wide), dim3(64), 0, sp, pa);
+            if (forked) (void)hipEventRecord(ws.ev_join[n_def], ws.side);
+            deferred[n_def].pa = pa; deferred[n_def].cls = c; deferred[n_def].grid_rank = grid_rank; n_def++;
             bytes += n * 16 * (c == LEAF_WIDE1 ? 2 : 4);  // record passes: 8 B written + 8 B read each
         }
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) { err = std::string("predict launch: ") + hipGetErrorString(e); return W3_E_HIP; }
+    }
+    // join, then rank inside the sorted groups (main stream: these kernels want the Infinity Cache to themselves)
+    for (int w = 0; w < n_def; w++) {
+        if (forked) (void)hipStreamWaitEvent(s, ws.ev_join[w], 0);   // this leaf's records are sorted (later leaves may still be partitioning)
+        if (deferred[w].cls == LEAF_WIDE1) hipLaunchKernelGGL(w3::k_rank_sorted<1>, dim3(deferred[w].grid_rank), dim3(64), 0, s, deferred[w].pa);
+        else hipLaunchKernelGGL(w3::k_rank_sorted<2>, dim3(deferred[w].grid_rank), dim3(64), 0, s, deferred[w].pa);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) { err = std::string("rank launch: ") + hipGetErrorString(e); return W3_E_HIP; }
     }
     if (sa.n_leaves) {
         // HashMaps in HBM, one per (block, leaf), zeroed per batch of blocks; as many blocks at once as the budget allows
