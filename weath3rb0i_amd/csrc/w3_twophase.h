@@ -30,6 +30,7 @@ struct TwoPhaseWs {
     // wide Counter leaves: their k_partition passes run on a side stream beside the time-ordered leaves' kernels
     void *rec_w[4] = {nullptr, nullptr, nullptr, nullptr}, *perm_w[4] = {nullptr, nullptr, nullptr, nullptr}, *splits_w[4] = {nullptr, nullptr, nullptr, nullptr};
     size_t rec_w_cap[4] = {0, 0, 0, 0}, perm_w_cap[4] = {0, 0, 0, 0}, splits_w_cap[4] = {0, 0, 0, 0};
+    int wide1_slot = -1;                // rec_w / splits_w index of an Order1-shaped leaf of the last predict (records sorted by c1)
     hipStream_t side = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join[4] = {nullptr, nullptr, nullptr, nullptr};
     void *achash_lut = nullptr;         // k_achash_lut: [65536][8] coder states (8 MiB)
@@ -178,6 +179,7 @@ static inline int twophase_predict(TwoPhaseWs &ws, hipStream_t s, const ParsedSp
     const bool forked = need_perm && !getenv("W3_NO_SIDE_STREAM");
     hipStream_t sp = forked ? ws.side : s;
     if (forked) { (void)hipEventRecord(ws.ev_fork, s); (void)hipStreamWaitEvent(ws.side, ws.ev_fork, 0); }
+    ws.wide1_slot = -1;
     struct Deferred { w3::PredictArgs pa; int cls; uint32_t grid_rank; } deferred[4];
     int n_def = 0;
     uint64_t bytes = 0;
@@ -246,6 +248,7 @@ static inline int twophase_predict(TwoPhaseWs &ws, hipStream_t s, const ParsedSp
             if (c == LEAF_WIDE1) hipLaunchKernelGGL(w3::k_partition<1>, dim3(grid_wide), dim3(64), 0, sp, pa);
             else hipLaunchKernelGGL(w3::k_partition<2>, dim3(grid_wide), dim3(64), 0, sp, pa);
             if (forked) (void)hipEventRecord(ws.ev_join[n_def], ws.side);
+            if (c == LEAF_WIDE1) ws.wide1_slot = n_def;
             deferred[n_def].pa = pa; deferred[n_def].cls = c; deferred[n_def].grid_rank = grid_rank; n_def++;
             bytes += n * 16 * (c == LEAF_WIDE1 ? 2 : 4);  // record passes: 8 B written + 8 B read each
         }
@@ -353,9 +356,12 @@ static inline int twophase_apm(TwoPhaseWs &ws, hipStream_t s, const ParsedSpec &
             bytes += n * (16 * (uint64_t)L + 1 + 16);
         } else {
             if (!ws.P_valid) { if ((rc = twophase_mix(ws, s, n, err))) return rc; bytes += n * 16 * (ws.mix.n_src + 1); }
-            if ((rc = tp_ensure(ws.splits, ws.splits_cap, (size_t)nb * (W3_SLICES + 1) * 4 + 64, err))) return rc;
-            uint32_t *job_counter = (uint32_t *)ws.splits + (size_t)nb * (W3_SLICES + 1);
-            if (!partitioned) {   // records sorted by the previous byte (the leaves' own partitions may have reused ws.rec since)
+            // the records sorted by the previous byte: an Order1-shaped leaf of this call has already produced them
+            const bool reuse = ws.wide1_slot >= 0;
+            if (!reuse && (rc = tp_ensure(ws.splits, ws.splits_cap, (size_t)nb * (W3_SLICES + 1) * 4 + 64, err))) return rc;
+            void *rec_p = reuse ? ws.rec_w[ws.wide1_slot] : nullptr, *splits_p = reuse ? ws.splits_w[ws.wide1_slot] : ws.splits;
+            uint32_t *job_counter = (uint32_t *)splits_p + (size_t)nb * (W3_SLICES + 1);
+            if (!partitioned && !reuse) {   // records sorted by the previous byte (the leaves' own partitions may have reused ws.rec since)
                 const uint32_t grid_wide = std::min<uint32_t>(nb, 256 * 16);
                 if ((rc = tp_ensure(ws.perm, ws.perm_cap, (size_t)grid_wide * 2 * block_size * 8, err))) return rc;
                 if ((rc = tp_ensure(ws.rec, ws.rec_cap, n * 8, err))) return rc;
@@ -368,7 +374,7 @@ static inline int twophase_apm(TwoPhaseWs &ws, hipStream_t s, const ParsedSpec &
                 bytes += n * (4 + 32);
             }
             (void)hipMemsetAsync(job_counter, 0, 4, s);
-            aa.rec = (const uint2 *)ws.rec; aa.splits = (const uint32_t *)ws.splits; aa.job_counter = job_counter;
+            aa.rec = (const uint2 *)(reuse ? rec_p : ws.rec); aa.splits = (const uint32_t *)splits_p; aa.job_counter = job_counter;
             const uint32_t grid = std::min<uint32_t>((nb * W3_SLICES + W3_APM_WAVES - 1) / W3_APM_WAVES, 512u);   // 2 workgroups per CU: ~128 blocks live
             hipLaunchKernelGGL(w3::k_apm1, dim3(grid), dim3(64 * W3_APM_WAVES), 0, s, aa);
             bytes += n * (8 + 16 + 16);
