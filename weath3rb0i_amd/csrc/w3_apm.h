@@ -136,7 +136,8 @@ __global__ void __launch_bounds__(64 * W3_APM_WAVES) k_apm0(ApmArgs a) {
     lds_u16 *tab = (lds_u16 *)&s_tab[wave][0];
     const lds_i16 *l_str = (const lds_i16 *)&s_str[0];
     const lds_u16 *l_row = (const lds_u16 *)&s_row[0];
-    const uint32_t b = blockIdx.x * W3_APM_WAVES + wave;
+    // wave-uniform block id in an SGPR: the per-leaf base addresses become scalar and every access is base + 32-bit lane offset
+    const uint32_t b = (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * W3_APM_WAVES + (uint32_t)wave));
     if (b >= a.nblocks) return;   // (no barrier below)
     apm_table_init(tab, l_row, lane);
     const uint64_t off = (uint64_t)b * a.block_size;
@@ -154,7 +155,8 @@ __global__ void __launch_bounds__(64 * W3_APM_WAVES) k_apm0(ApmArgs a) {
             const uint32_t ic = min(base + (uint32_t)(r * 8 + k), last);
             bb[r] = blk[ic];
 #pragma unroll
-            for (int l = 0; l < L; l++) pp[r][l] = a.src[l][(off + ic) * 8u + (uint32_t)j];
+            for (int l = 0; l < L; l++)   // scalar base + 32-bit byte offset (global_load ... v_off, s[base])
+                pp[r][l] = *reinterpret_cast<const uint16_t *>(reinterpret_cast<const uint8_t *>(a.src[l] + off * 8u) + (ic * 16u + 2u * (uint32_t)j));
         }
     };
     auto process = [&](const uint32_t (&pc)[W3_APM_PF][L], const uint32_t (&bc)[W3_APM_PF], uint32_t base) {
@@ -178,7 +180,7 @@ __global__ void __launch_bounds__(64 * W3_APM_WAVES) k_apm0(ApmArgs a) {
             const uint32_t o = apm_round(tab, l_str, p, c0, bit, valid, a.rate, k);
             // unconditional store (a branch around it makes hipcc wait vmcnt(0) — store latency included — before it
             // touches the prefetched operands of the next batch)
-            uint16_t *dst = valid ? out + ((uint64_t)i * 8u + (uint32_t)j) : a.dummy + lane;
+            uint16_t *dst = valid ? reinterpret_cast<uint16_t *>(reinterpret_cast<uint8_t *>(out) + (i * 16u + 2u * (uint32_t)j)) : a.dummy + lane;
             *dst = (uint16_t)o;
         }
     };
