@@ -17,6 +17,7 @@ struct LeafParam {
     uint64_t tbl_off;        // byte offset of this leaf's table inside the lane's region
     uint32_t hash_mask;      // slots-1 when use_hash
     uint32_t hist_mask;      // (1<<(bits-align))-1
+    const uint4 *lut;        // ACHistory leaves: [65536][8] coder states after the 16 most recent history bits (k_achash_lut), or null
 };
 
 struct GenericArgs {
@@ -52,8 +53,22 @@ struct GenericArgs {
 __device__ __forceinline__ uint32_t leaf_ctx(const LeafParam &lp, uint64_t hist64, uint32_t t) {
     if (t == 0u) return 0u;
     uint32_t h;
-    if (lp.hist == 2) h = ac_history_hash(hist64, t, lp.max_bits, lp.table);
-    else h = (uint32_t)hist64;
+    if (lp.hist == 2) {
+        if (lp.lut) {
+            // the 16-bit prefix table of k_achash (w3_predict.h): most hashes are complete there; the rest resume at step 16.
+            // (The literal one-bit-at-a-time form made the reference's default model decode at 12 MiB/s.)
+            const uint32_t j = t & 7u;
+            const uint4 e = lp.lut[((uint32_t)hist64 & 0xFFFFu) * 8u + j];
+            ACHashState st; st.x1 = e.x; st.x2 = e.y; st.hash = e.z; st.meta = e.w;
+            if (!(e.w >> 31)) {
+                uint32_t rot[8];
+#pragma unroll
+                for (int r = 0; r < 8; r++) { const uint32_t p = lp.table[(j + 7u - (uint32_t)r) & 7u]; rot[r] = p ? (p << 16) : 1u; }
+                st = ac_history_hash_steps(hist64, lp.max_bits, rot, st, 16, 64);
+            }
+            h = ac_hash_finish(st, lp.max_bits);
+        } else h = ac_history_hash(hist64, t, lp.max_bits, lp.table);
+    } else h = (uint32_t)hist64;
     h &= lp.hist_mask;
     return (h << lp.align) | (t & ((1u << lp.align) - 1u));
 }

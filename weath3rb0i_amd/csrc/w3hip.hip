@@ -37,7 +37,7 @@ struct w3_ctx {
     w3_timing timing{};
     hipEvent_t ev[14]{};
     // workspace
-    DevBuf tables, stripes, lens, offs, total, flag, io_in, io_out, coffs, misc, cm_luts;
+    DevBuf tables, stripes, lens, offs, total, flag, io_in, io_out, coffs, misc, cm_luts, achash_luts;
     TwoPhaseWs tp;
 };
 
@@ -103,7 +103,7 @@ extern "C" void w3_ctx_destroy(w3_ctx *ctx) {
     (void)hipSetDevice(ctx->device);
     (void)hipDeviceSynchronize();
     DevBuf *bufs[] = {&ctx->tables, &ctx->stripes, &ctx->lens, &ctx->offs, &ctx->total, &ctx->flag,
-                      &ctx->io_in, &ctx->io_out, &ctx->coffs, &ctx->misc, &ctx->cm_luts};
+                      &ctx->io_in, &ctx->io_out, &ctx->coffs, &ctx->misc, &ctx->cm_luts, &ctx->achash_luts};
     for (DevBuf *b : bufs)
         if (b->p) (void)hipFree(b->p);
     ctx->tp.release();
@@ -231,6 +231,10 @@ static uint64_t layout_generic(const ParsedSpec &ps, size_t block_size, GenericA
     return std::max<uint64_t>(off, 16);
 }
 
+// ACHistory leaves of the lane-per-block kernels: tabulate the coder states of every 16-bit history prefix once per call
+// (k_achash_lut, w3_predict.h) so that leaf_ctx looks the hash up instead of running the nested coder bit by bit.
+static int prepare_achash_luts(w3_ctx *ctx, hipStream_t s, GenericArgs &ga);
+
 // ---------------------------------------------------------------------------
 // timing helpers
 // ---------------------------------------------------------------------------
@@ -277,6 +281,29 @@ static int table_budget(w3_ctx *ctx, uint64_t lane_stride, uint32_t want_lanes, 
     return W3_OK;
 }
 
+static int prepare_achash_luts(w3_ctx *ctx, hipStream_t s, GenericArgs &ga) {
+    int n_ac = 0;
+    for (int l = 0; l < ga.n_leaves; l++) n_ac += ga.leaf[l].kind == 0 && ga.leaf[l].hist == W3_HIST_AC && !ga.leaf[l].frozen;
+    if (!n_ac) return W3_OK;
+    const size_t entries = (size_t)8u << W3_ACHASH_LUT_BITS, per_leaf = entries * 18;
+    ENSURE(ctx, ctx->achash_luts, per_leaf * (size_t)n_ac);
+    int k = 0;
+    for (int l = 0; l < ga.n_leaves; l++) {
+        LeafParam &lp = ga.leaf[l];
+        if (!(lp.kind == 0 && lp.hist == W3_HIST_AC && !lp.frozen)) continue;
+        uint8_t *base = (uint8_t *)ctx->achash_luts.p + per_leaf * (size_t)k++;
+        HashArgs ha;
+        memset(&ha, 0, sizeof ha);
+        ha.max_bits = lp.max_bits; ha.hmask = 0xFFu;
+        memcpy(ha.table, lp.table, sizeof ha.table);
+        ha.lut = (uint4 *)base; ha.lut_key = (uint16_t *)(base + entries * 16);
+        hipLaunchKernelGGL(k_achash_lut, dim3((unsigned)(entries / 256)), dim3(256), 0, s, ha);
+        lp.lut = (const uint4 *)base;
+    }
+    HIPCHK(ctx, hipGetLastError());
+    return W3_OK;
+}
+
 static int generic_encode(w3_ctx *ctx, hipStream_t s, const ParsedSpec &ps, const uint8_t *d_in, size_t n, size_t block_size,
                           uint32_t nb, uint32_t stripe_cap, uint32_t *d_lens) {
     GenericArgs ga;
@@ -285,6 +312,7 @@ static int generic_encode(w3_ctx *ctx, hipStream_t s, const ParsedSpec &ps, cons
     uint32_t lanes = 0;
     int rc = table_budget(ctx, lane_stride, nb, lanes);
     if (rc) return rc;
+    if ((rc = prepare_achash_luts(ctx, s, ga))) return rc;
     ENSURE(ctx, ctx->tables, (size_t)lanes * lane_stride);
     ga.n = n; ga.block_size = (uint32_t)block_size;
     ga.tables = (uint8_t *)ctx->tables.p; ga.lane_stride = lane_stride;
@@ -314,6 +342,7 @@ static int generic_decode(w3_ctx *ctx, hipStream_t s, const ParsedSpec &ps, cons
     uint32_t lanes = 0;
     int rc = table_budget(ctx, lane_stride, nb, lanes);
     if (rc) return rc;
+    if ((rc = prepare_achash_luts(ctx, s, ga))) return rc;
     ENSURE(ctx, ctx->tables, (size_t)lanes * lane_stride);
     ENSURE(ctx, ctx->coffs, (size_t)nb * 8);
     ENSURE(ctx, ctx->total, 8);
@@ -406,6 +435,7 @@ static int cm_encode(w3_ctx *ctx, hipStream_t s, const ParsedSpec &ps, const uin
     CmArgs ca;
     memset(&ca, 0, sizeof ca);
     const uint64_t lane_stride = layout_cm(ps, block_size, ca);
+    { int rc_ = prepare_achash_luts(ctx, s, ca.g); if (rc_) return rc_; }
     ca.g.n = n; ca.g.block_size = (uint32_t)block_size;
     ca.g.in = d_in; ca.g.stripe_cap = stripe_cap; ca.g.out_len = d_lens; ca.g.overflow = (uint32_t *)ctx->flag.p;
     return cm_run<false>(ctx, s, ca, lane_stride, nb, stripe_cap);
@@ -416,6 +446,7 @@ static int cm_decode(w3_ctx *ctx, hipStream_t s, const ParsedSpec &ps, const uin
     CmArgs ca;
     memset(&ca, 0, sizeof ca);
     const uint64_t lane_stride = layout_cm(ps, block_size, ca);
+    { int rc_ = prepare_achash_luts(ctx, s, ca.g); if (rc_) return rc_; }
     ENSURE(ctx, ctx->coffs, (size_t)nb * 8);
     ENSURE(ctx, ctx->total, 8);
     hipLaunchKernelGGL(k_scan_lens, dim3(1), dim3(1024), 0, s, d_lens, (uint64_t *)ctx->coffs.p, (uint64_t *)ctx->total.p, nb);
