@@ -212,4 +212,101 @@ __global__ void __launch_bounds__(64) k_cm(CmArgs a) {
     }
 }
 
+// ---------------------------------------------------------------------------
+// Counter leaves (1..4) + APM chain, no slot-state leaves: k_generic_nl (all leaves' Counter loads of a step in flight
+// together, w3_generic.h) followed by the APM stages.  The decoder of the bench's default model.
+// ---------------------------------------------------------------------------
+template <bool DECODE, int NL>
+__global__ void __launch_bounds__(64) k_cm_nl(CmArgs a) {
+    __shared__ int16_t s_str[4096];
+    for (uint32_t i = threadIdx.x; i < 4096u; i += 64u) s_str[i] = a.stretch[i];
+    __shared__ LeafParam s_leaf[W3_MAX_LEAVES];
+    __shared__ ApmParam s_apm[W3_MAX_APM];
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int k = 0; k < W3_MAX_APM; k++) s_apm[k] = a.apm[k];
+    }
+    stage_leaves(s_leaf, a.g);   // (also the barrier for the tables above)
+    const GenericArgs &g = a.g;
+    const uint32_t lane = blockIdx.x * blockDim.x + threadIdx.x;
+    if (lane >= g.n_lanes) return;
+    const uint32_t b = g.first_block + lane;
+    const uint64_t off = (uint64_t)b * g.block_size;
+    const uint32_t len = (uint32_t)((g.n - off) < g.block_size ? (g.n - off) : g.block_size);
+    uint8_t *lane_tbl = g.tables + (uint64_t)lane * g.lane_stride;
+    const LeafParam *lp = s_leaf;
+    Encoder enc; Decoder dec;
+    if (DECODE) dec.init(g.cin + g.coffs[b], g.clens[b]);
+    else enc.init(g.stripes + (uint64_t)lane * g.stripe_cap, g.stripe_cap);
+
+    uint64_t hist64 = 0; uint32_t t = 0, c0 = 1, c1 = 0;
+    for (uint32_t i = 0; i < len; i++) {
+        uint32_t byte = DECODE ? 0u : g.in[off + i];
+        for (int s = 7; s >= 0; s--) {
+            uint32_t *slot[NL]; uint32_t val[NL], key[NL], ctx[NL];
+#pragma unroll
+            for (int l = 0; l < NL; l++) {
+                slot[l] = nullptr; val[l] = 0u; key[l] = 0u; ctx[l] = 0u;
+                if (!lp[l].frozen) {
+                    ctx[l] = leaf_ctx(lp[l], hist64, t);
+                    uint32_t *tbl = reinterpret_cast<uint32_t *>(lane_tbl + lp[l].tbl_off);
+                    slot[l] = lp[l].use_hash ? tbl + 2u * (((ctx[l] * 2654435761u) ^ (ctx[l] >> 15)) & lp[l].hash_mask) : tbl + ctx[l];
+                }
+            }
+#pragma unroll
+            for (int l = 0; l < NL; l++) {
+                if (slot[l]) {
+                    if (!lp[l].use_hash) val[l] = *slot[l];
+                    else { const uint2 kv = *reinterpret_cast<const uint2 *>(slot[l]); key[l] = kv.x; val[l] = kv.y; }
+                }
+            }
+            uint32_t p = 32768u, best = 0u;
+#pragma unroll
+            for (int l = 0; l < NL; l++) {
+                if (slot[l] && lp[l].use_hash) {   // leaf_slot semantics: hit, claim an empty slot, or keep probing
+                    if (key[l] == ctx[l] + 1u) slot[l] += 1;
+                    else if (key[l] == 0u) { slot[l][0] = ctx[l] + 1u; slot[l] += 1; val[l] = 0u; }
+                    else { slot[l] = leaf_slot(lp[l], lane_tbl, ctx[l]); val[l] = *slot[l]; }
+                }
+                const uint32_t pl = slot[l] ? counter_p_packed(val[l]) : 32768u;
+                const uint32_t d = opinion_dist(pl);
+                if (l == 0 || d > best) { p = pl; best = d; }
+            }
+            // APM chain (build-defined)
+            uint16_t *aslot[W3_MAX_APM];
+            for (int k = 0; k < a.n_apm; k++) {
+                const uint32_t row = s_apm[k].ctx_kind ? (c0 | (c1 << 8)) : c0;
+                const uint32_t pos = (uint32_t)((int)s_str[p >> 4] + 2048) * 32u;
+                const uint32_t j = pos >> 12, w = pos & 4095u;
+                uint16_t *tr = reinterpret_cast<uint16_t *>(lane_tbl + s_apm[k].off) + row * 33u + j;
+                const uint32_t pa = ((uint32_t)tr[0] * (4096u - w) + (uint32_t)tr[1] * w) >> 12;
+                aslot[k] = tr + (w >> 11);
+                uint32_t o = (p + 3u * pa + 2u) >> 2;
+                p = o < 1u ? 1u : o > 65535u ? 65535u : o;
+            }
+            uint32_t bit;
+            if (DECODE) { bit = dec.decode(p); byte = (byte << 1) | bit; }
+            else bit = (byte >> s) & 1u;
+            for (int k = 0; k < a.n_apm; k++) {
+                const int tv = (int)*aslot[k];
+                *aslot[k] = (uint16_t)(tv + (((bit ? 65535 : 0) - tv) >> s_apm[k].rate));   // arithmetic shift = floor
+            }
+#pragma unroll
+            for (int l = 0; l < NL; l++)
+                if (slot[l]) *slot[l] = counter_update_packed(val[l], bit);
+            hist64 = (hist64 << 1) | bit;
+            t++;
+            c0 = (c0 << 1) | bit;
+            if (c0 >= 256u) { c1 = c0 & 0xFFu; c0 = 1u; }
+            if (!DECODE) enc.encode(bit, p);
+        }
+        if (DECODE) g.dout[off + i] = (uint8_t)byte;
+    }
+    if (!DECODE) {
+        const uint32_t produced = enc.flush();
+        g.out_len[b] = produced;
+        if (produced > g.stripe_cap) atomicOr(g.overflow, 1u);
+    }
+}
+
 }  // namespace w3

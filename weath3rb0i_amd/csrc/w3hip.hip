@@ -424,7 +424,17 @@ static int cm_run(w3_ctx *ctx, hipStream_t s, CmArgs &ca, uint64_t lane_stride, 
         for (int k = 0; k < ca.n_apm; k++)
             hipLaunchKernelGGL(k_cm_init_apm, dim3(2048), dim3(256), 0, s, ca.g.tables, lane_stride, ca.apm[k].off,
                                ca.apm[k].ctx_kind ? 65536u : 256u, cnt, ca.squash);
-        hipLaunchKernelGGL(k_cm<DECODE>, dim3((cnt + 63) / 64), dim3(64), 0, s, ca);
+        bool has_slot = false;
+        for (int l = 0; l < ca.g.n_leaves; l++) has_slot |= ca.g.leaf[l].kind == 1;
+        const dim3 grid((cnt + 63) / 64), blk(64);
+        if (!has_slot && ca.g.n_leaves <= 4) {   // Counter leaves + APM chain: all Counter loads of a step in flight together
+            switch (ca.g.n_leaves) {
+            case 1: hipLaunchKernelGGL((k_cm_nl<DECODE, 1>), grid, blk, 0, s, ca); break;
+            case 2: hipLaunchKernelGGL((k_cm_nl<DECODE, 2>), grid, blk, 0, s, ca); break;
+            case 3: hipLaunchKernelGGL((k_cm_nl<DECODE, 3>), grid, blk, 0, s, ca); break;
+            default: hipLaunchKernelGGL((k_cm_nl<DECODE, 4>), grid, blk, 0, s, ca); break;
+            }
+        } else hipLaunchKernelGGL(k_cm<DECODE>, grid, blk, 0, s, ca);
         HIPCHK(ctx, hipGetLastError());
     }
     return W3_OK;
