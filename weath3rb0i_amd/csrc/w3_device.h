@@ -174,7 +174,24 @@ struct Decoder {
     uint32_t x1, x2, x;
     BitSource in;
     __device__ __forceinline__ void init(const uint8_t *s, uint32_t l) { in.init(s, l); x1 = 0; x2 = 0xFFFFFFFFu; x = in.get(32u); }
+    // Model probabilities are never 0 (Counter::p, the state table and the APM clamp all give 1..65535): with range >= 2^30
+    // before the step the new range is >= 2^14 - 1, so x1 != x2 afterwards and both renormalisation loops collapse into ONE
+    // shift by s = n + m <= 18 found with a single clz (as in the encoder, w3_coder.h): n equal leading bits, then the m E3
+    // positions where x1 = 1 and x2 = 0.  Of the E3 loop's XORs on x only the last survives the shifts, and there was an
+    // E3 step exactly when the raw shifted x1 has its top bit set.
     __device__ __forceinline__ uint32_t decode(uint32_t prob) {
+        if (__builtin_expect(prob == 0u, 0)) return decode_general(prob);
+        const uint32_t xmid = x1 + __umulhi(x2 - x1, prob << 16);
+        const uint32_t bit = x <= xmid;                                // :82
+        if (bit) x2 = xmid; else x1 = xmid + 1u;
+        const uint32_t s = (uint32_t)__builtin_clz((x1 ^ x2) & (((~x1 | x2) << 1) | 1u));
+        const uint32_t X1 = x1 << s, X2 = ((x2 + 1u) << s) - 1u;
+        x = ((x << s) | in.get(s)) ^ (X1 & 0x80000000u);
+        x1 = X1 & 0x7FFFFFFFu;
+        x2 = X2 | 0x80000000u;
+        return bit;
+    }
+    __device__ __forceinline__ uint32_t decode_general(uint32_t prob) {
         const uint32_t p32 = prob ? (prob << 16) : 1u;
         const uint32_t xmid = x1 + __umulhi(x2 - x1, p32);
         const uint32_t bit = x <= xmid;                                // :82
