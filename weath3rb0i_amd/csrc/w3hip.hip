@@ -434,7 +434,12 @@ static int cm_run(w3_ctx *ctx, hipStream_t s, CmArgs &ca, uint64_t lane_stride, 
             case 3: hipLaunchKernelGGL((k_cm_nl<DECODE, 3>), grid, blk, 0, s, ca); break;
             default: hipLaunchKernelGGL((k_cm_nl<DECODE, 4>), grid, blk, 0, s, ca); break;
             }
-        } else hipLaunchKernelGGL(k_cm<DECODE>, grid, blk, 0, s, ca);
+        } else {
+            int n_slot = 0;
+            for (int l = 0; l < ca.g.n_leaves; l++) n_slot += ca.g.leaf[l].kind == 1;
+            if (n_slot <= W3_CM_STAGED_MAX && !getenv("W3_CM_UNSTAGED")) hipLaunchKernelGGL(k_cm_staged<DECODE>, grid, blk, 0, s, ca);   // slot cells staged in LDS
+            else hipLaunchKernelGGL(k_cm<DECODE>, grid, blk, 0, s, ca);
+        }
         HIPCHK(ctx, hipGetLastError());
     }
     return W3_OK;
