@@ -188,6 +188,14 @@ def test_slot_tables_in_batches(ctx, oracle, monkeypatch):
         ctx.set_timing(False)
 
 
+def test_cm_unstaged_kernel_still_agrees(ctx, oracle, monkeypatch):
+    """k_cm (cells in global memory, used beyond 8 slot leaves) against k_cm_staged and the oracle."""
+    data = markov_text(20000, seed=15) + mixed_bytes(6000, seed=16)
+    monkeypatch.setenv("W3_CM_UNSTAGED", "1")
+    for name in ("slot_mix", "full_cm_small_tables"):
+        check(ctx, oracle, name, data, 4096)
+
+
 def test_cm_reference_container(ctx, oracle):
     """w30i + length + ONE stream (main.rs:89-144) with a CM model."""
     d = markov_text(20000, seed=3)
