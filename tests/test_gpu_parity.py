@@ -117,6 +117,16 @@ def test_twophase_path_models(ctx, oracle, name):
     assert np.array_equal(p, want)
 
 
+def test_order2_partition_chained_and_from_scratch(ctx, oracle, monkeypatch):
+    """An order-2 leaf behind an Order1 leaf refines that leaf's c1-sorted records (k_partition<3>, two passes); alone,
+    ahead of the Order1 leaf, or with the hook set it sorts from scratch (k_partition<2>, four passes).  Same streams."""
+    data = markov_text(150000, seed=21) + bytes(70000) + lcg_text(30001, seed=4)
+    for name in ("best012", "best_ac_wide", "order2"):
+        check_blocks(ctx, oracle, name, data, 65536, "twophase")
+    monkeypatch.setenv("W3_NO_CHAINED_PARTITION", "1")
+    check_blocks(ctx, oracle, "best012", data, 65536, "twophase")
+
+
 @pytest.mark.parametrize("name", NOT_TWOPHASE)
 def test_twophase_rejects_uncovered_specs(ctx, oracle, name):
     from weath3rb0i_amd import _lib as L

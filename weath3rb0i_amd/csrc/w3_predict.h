@@ -41,6 +41,7 @@ struct PredictArgs {
     const uint2 *keys;      // [n] 8 x u8 precomputed keys per byte (k_achash) or null
     uint32_t *perm;         // partition: per-wave scratch, 2 * block_size records
     uint2 *rec;             // [n] sorted records (position, window bytes) of every block
+    const uint2 *rec_src;   // k_partition<3>: [n] records already sorted by c1 (an Order1 leaf's a.rec), else null
     uint32_t *splits;       // [nblocks][W3_SLICES + 1] slice boundaries inside each block's sorted range
     uint32_t *job_counter;  // k_rank_sorted: next job (zeroed before the launch)
     uint32_t hbits;         // H = bits_in_context - 3
@@ -295,7 +296,7 @@ __device__ __forceinline__ uint32_t wave_excl_scan_u32(uint32_t v, uint32_t *tot
 // its own HBM transaction).  hist[pass][16] is filled in ONE time-ordered sweep up front.
 #define W3_PF 8   // rounds whose loads are in flight together in the short-round loops
 
-template <int NPASS>
+template <int NPASS, bool C2ONLY = false>
 __device__ __forceinline__ void partition_hist(const uint8_t *blk, uint32_t len, bool first, uint32_t *hist) {
     const int lane = threadIdx.x & 63;
     const uint64_t gt = lane_gt_mask();
@@ -323,7 +324,9 @@ __device__ __forceinline__ void partition_hist(const uint8_t *blk, uint32_t len,
 #pragma unroll
             for (int ps = 0; ps < NPASS; ps++) {
                 // pass order (LSD): c2 low, c2 high, c1 low, c1 high  /  c1 low, c1 high
-                const uint32_t d = NPASS == 4 ? ((ps < 2 ? (kb >> 8) : kb) >> (4 * (ps & 1))) & 15u : (kb >> (4 * ps)) & 15u;
+                //             C2ONLY: c2 low, c2 high (the records arrive already sorted by c1)
+                const uint32_t d = C2ONLY ? (kb >> (8 + 4 * ps)) & 15u
+                                 : NPASS == 4 ? ((ps < 2 ? (kb >> 8) : kb) >> (4 * (ps & 1))) & 15u : (kb >> (4 * ps)) & 15u;
                 uint64_t m = vm;
 #pragma unroll
                 for (int k = 0; k < 4; k++) {
@@ -401,6 +404,9 @@ __device__ __forceinline__ void partition_pass4(const uint8_t *blk, uint32_t len
 // k_partition<NBYTES>: one wavefront per block sorts the block's records stably by the group key
 // (NBYTES 1: c1 — Order1; 2: (c1,c2) — OrderN(27,3)) into a.rec, and cuts the sorted range into
 // W3_SLICES slices at group boundaries (a.splits) for k_rank_sorted.
+// NBYTES 3: the (c1,c2) grouping built from an Order1 leaf's records (a.rec_src, already sorted by c1): two more
+// passes over c2 instead of four from scratch.  The groups come out c2-major; k_rank_sorted only needs them contiguous
+// and time-ordered inside, which any stable pass order gives.
 template <int NBYTES>
 __global__ void __launch_bounds__(64) k_partition(PredictArgs a) {
     __shared__ uint32_t hist[64];
@@ -414,9 +420,14 @@ __global__ void __launch_bounds__(64) k_partition(PredictArgs a) {
         uint2 *out = a.rec + off;
         unsigned long long t_prev = a.dbg ? __builtin_amdgcn_s_memtime() : 0ull;
         const bool first = off == 0;
-        partition_hist<2 * NBYTES>(blk, len, first, hist);
+        if constexpr (NBYTES == 3) partition_hist<2, true>(blk, len, first, hist); else partition_hist<2 * NBYTES>(blk, len, first, hist);
         W3_STAMP(0);
-        if constexpr (NBYTES == 1) {
+        if constexpr (NBYTES == 3) {
+            partition_pass4<false>(blk, len, first, 2, 0, a.rec_src + off, perm_a, hist);
+            __threadfence_block();
+            W3_STAMP(1);
+            partition_pass4<false>(blk, len, first, 2, 4, perm_a, out, hist + 16);
+        } else if constexpr (NBYTES == 1) {
             partition_pass4<true>(blk, len, first, 1, 0, nullptr, perm_a, hist);
             __threadfence_block();
             W3_STAMP(1);

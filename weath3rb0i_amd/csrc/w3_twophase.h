@@ -245,12 +245,16 @@ static inline int twophase_predict(TwoPhaseWs &ws, hipStream_t s, const ParsedSp
             uint32_t rank_waves = c == LEAF_WIDE2 ? 3072u : 2048u;
             if (const char *ev_ = getenv("W3_RANK_GRID")) rank_waves = (uint32_t)std::max(64, atoi(ev_));   // tuning hook
             const uint32_t grid_rank = std::min<uint32_t>(nb * W3_SLICES, rank_waves);
+            // an order-2 leaf behind an Order1 leaf starts from that leaf's records (sorted by c1; same stream, so they are ready)
+            const bool chained = c == LEAF_WIDE2 && ws.wide1_slot >= 0 && !getenv("W3_NO_CHAINED_PARTITION");
+            if (chained) pa.rec_src = (const uint2 *)ws.rec_w[ws.wide1_slot];
             if (c == LEAF_WIDE1) hipLaunchKernelGGL(w3::k_partition<1>, dim3(grid_wide), dim3(64), 0, sp, pa);
+            else if (chained) hipLaunchKernelGGL(w3::k_partition<3>, dim3(grid_wide), dim3(64), 0, sp, pa);
             else hipLaunchKernelGGL(w3::k_partition<2>, dim3(grid_wide), dim3(64), 0, sp, pa);
             if (forked) (void)hipEventRecord(ws.ev_join[n_def], ws.side);
             if (c == LEAF_WIDE1) ws.wide1_slot = n_def;
             deferred[n_def].pa = pa; deferred[n_def].cls = c; deferred[n_def].grid_rank = grid_rank; n_def++;
-            bytes += n * 16 * (c == LEAF_WIDE1 ? 2 : 4);  // record passes: 8 B written + 8 B read each
+            bytes += n * 16 * (c == LEAF_WIDE1 || chained ? 2 : 4);  // record passes: 8 B written + 8 B read each
         }
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) { err = std::string("predict launch: ") + hipGetErrorString(e); return W3_E_HIP; }
