@@ -45,7 +45,7 @@ struct PredictArgs {
     uint32_t *splits;       // [nblocks][W3_SLICES + 1] slice boundaries inside each block's sorted range
     uint32_t *job_counter;  // k_rank_sorted: next job (zeroed before the launch)
     uint32_t hbits;         // H = bits_in_context - 3
-    uint32_t dbg_flags;      // diagnostic: bit0 = skip the stream stores (timing experiments only)
+    uint32_t dbg_flags;      // bit0 = skip the stream stores (timing experiments only); bit1 = ballot rounds only (no LDS atomics)
     unsigned long long *dbg; // optional: per-phase s_memtime sums (diagnostic builds/runs only; never read by kernels)
 };
 
@@ -190,6 +190,60 @@ __device__ __forceinline__ void rank_round(uint32_t c0, const uint32_t key[8], c
     }
 }
 
+// ---------------------------------------------------------------------------
+// The same round with LDS atomics: ds_add_rtn_u32 serialises the lanes of a wavefront that hit one address in ascending
+// lane order (not in the ISA manual: measured, tools/lds_atomic_order.hip, and checked per device at context creation —
+// k_lds_order_selftest; without it the ballot rounds above run), so ONE returning add per bit position hands every lane
+// the packed Counter (n0 | n1 << 16) exactly as its position sees it, time order = lane order, and leaves the table
+// updated: no match masks, no ranks, no write-back.  What it cannot do is Counter::update's halving at 65535
+// (counter.rs:22-25): a wavefront whose round returns a count >= W3_ATOMIC_LIM drops to the ballot rounds for the rest
+// of the table's life.  Safe: a count grows by at most 64 per round, so a round that starts below LIM + 64 ends below 65535.
+// ---------------------------------------------------------------------------
+#define W3_ATOMIC_LIM 65400u
+#ifndef W3_ATOMIC_MAXSEG
+#define W3_ATOMIC_MAXSEG 4u   // k_rank_sorted: rounds with more groups than this take the ballot path
+#endif
+typedef uint16_t w3_u16x2 __attribute__((ext_vector_type(2)));
+
+// lanes with `on` add their coded bits at key[j]; v[j] = the Counter before this lane's own update
+__device__ __forceinline__ void atomic_round(uint32_t *tbl, uint32_t c0, const uint32_t key[8], bool on, uint32_t v[8]) {
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        const uint32_t inc = on ? (((c0 >> (7 - j)) & 1u) ? 0x10000u : 1u) : 0u;
+        v[j] = __hip_atomic_fetch_add(&tbl[j * 256 + key[j]], inc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+}
+// any returned count at or above the limit (wave-uniform)
+__device__ __forceinline__ bool atomic_round_hot(const uint32_t v[8]) {
+    w3_u16x2 m = __builtin_bit_cast(w3_u16x2, v[0]);
+#pragma unroll
+    for (int j = 1; j < 8; j++) m = __builtin_elementwise_max(m, __builtin_bit_cast(w3_u16x2, v[j]));
+    return __ballot(max((uint32_t)m.x, (uint32_t)m.y) >= W3_ATOMIC_LIM) != 0ull;
+}
+
+// Per-device check of the lane-order property atomic_round relies on: 64 wavefronts x 32 rounds of returning adds on keys
+// from one shared hash (all lanes one address ... 2048 addresses); the host replays them in lane order (twophase_lds_order_ok).
+__host__ __device__ __forceinline__ uint32_t lds_order_hash(uint32_t wave, uint32_t round, uint32_t lane) {
+    uint32_t x = (wave * 64u + round) * 64u + lane + 0x9E3779B9u;
+    x ^= x >> 16; x *= 0x7FEB352Du; x ^= x >> 15; x *= 0x846CA68Bu; x ^= x >> 16;
+    return x;
+}
+__host__ __device__ __forceinline__ uint32_t lds_order_key(uint32_t wave, uint32_t h) {
+    const uint32_t kind = wave & 3u;
+    return kind == 0 ? 77u : kind == 1 ? (h & 7u) * 32u + 1u : kind == 2 ? (h & 255u) : (h & 2047u);
+}
+__global__ void __launch_bounds__(64) k_lds_order_selftest(uint32_t *old) {
+    __shared__ uint32_t tbl[2048];
+    const uint32_t lane = threadIdx.x;
+    for (uint32_t i = lane; i < 2048u; i += 64u) tbl[i] = 0u;
+    __builtin_amdgcn_wave_barrier();
+    for (uint32_t r = 0; r < 32u; r++) {
+        const uint32_t h = lds_order_hash(blockIdx.x, r, lane);
+        old[(blockIdx.x * 32u + r) * 64u + lane] =
+            __hip_atomic_fetch_add(&tbl[lds_order_key(blockIdx.x, h)], (h >> 20) & 1u ? 0x10000u : 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+}
+
 __device__ __forceinline__ uint4 pack_p(const uint32_t p[8]) {
     return make_uint4(p[0] | (p[1] << 16), p[2] | (p[3] << 16), p[4] | (p[5] << 16), p[6] | (p[7] << 16));
 }
@@ -236,6 +290,7 @@ __global__ void __launch_bounds__(64) k_predict_small(PredictArgs a) {
 #pragma unroll
         for (int k = 0; k < 32; k++) tbl[k * 64 + lane] = 0u;
         __builtin_amdgcn_wave_barrier();
+        bool exact = (a.dbg_flags & 2u) != 0u;   // ballot rounds (LDS-atomic order self-test failed, or a count nears 65535)
         // operands of round r+1 are loaded while round r is ranked; every load is unconditional (index clamped)
         const bool first = off == 0;
         const uint32_t last = len - 1u;
@@ -252,24 +307,33 @@ __global__ void __launch_bounds__(64) k_predict_small(PredictArgs a) {
                 const uint32_t ic = min(i + 64u, last);
                 if constexpr (KEYS) { nk = a.keys[off + ic]; nw = blk[ic]; } else nw = load_window(blk, ic, first);
             }
-            uint32_t c0 = 0, key[8];
-            uint64_t M[8];
+            uint32_t c0 = 0, key[8], p[8];
             if constexpr (KEYS) {
                 c0 = valid ? w : 0u;
 #pragma unroll
                 for (int j = 0; j < 8; j++) key[j] = ((j < 4 ? k8.x : k8.y) >> (8 * (j & 3))) & KM;
-                match_keys<H>(valid ? k8 : make_uint2(0, 0), M);
             } else {
                 const uint32_t wv = valid ? w : 0u;
                 c0 = wv & 0xFFu;
-                const uint32_t w16 = wv & 0xFFFFu;
 #pragma unroll
-                for (int j = 0; j < 8; j++) key[j] = (w16 >> (8 - j)) & KM;
-                match_windows<H>(w16, M);
+                for (int j = 0; j < 8; j++) key[j] = ((wv & 0xFFFFu) >> (8 - j)) & KM;
             }
-            const uint64_t seg = __ballot(valid);
-            uint32_t p[8], fin[8], wm;
-            rank_round<false>(c0, key, M, seg, valid, true, tbl, p, fin, wm);
+            if (!exact) {
+                uint32_t v[8];
+                __asm__ volatile("" ::: "memory");
+                atomic_round(tbl, c0, key, valid, v);
+                __asm__ volatile("" ::: "memory");
+#pragma unroll
+                for (int j = 0; j < 8; j++) p[j] = counter_p_packed(v[j]);
+                exact = atomic_round_hot(v);
+            } else {
+                uint64_t M[8];
+                if constexpr (KEYS) match_keys<H>(valid ? k8 : make_uint2(0, 0), M);
+                else match_windows<H>((valid ? w : 0u) & 0xFFFFu, M);
+                const uint64_t seg = __ballot(valid);
+                uint32_t fin[8], wm;
+                rank_round<false>(c0, key, M, seg, valid, true, tbl, p, fin, wm);
+            }
             if (valid) a.P[off + i] = pack_p(p);
         }
     }
@@ -498,6 +562,7 @@ __global__ void __launch_bounds__(64) k_rank_sorted(PredictArgs a) {
 #pragma unroll
         for (int k = 0; k < 32; k++) tbl[k * 64 + lane] = 0u;
         __builtin_amdgcn_wave_barrier();
+        bool exact = (a.dbg_flags & 2u) != 0u;   // ballot rounds only (see atomic_round)
         bool dirty = false;              // table holds states of group open_g
         uint32_t open_g = 0xFFFFFFFFu;   // group the table describes (also: group of the previous round's last element)
         // software pipeline: the record of round r+1 is loaded while round r is ranked
@@ -524,29 +589,70 @@ __global__ void __launch_bounds__(64) k_rank_sorted(PredictArgs a) {
             const uint64_t hgt = heads & lane_gt_mask();
             const uint64_t below_end = hgt ? ((1ull << (__ffsll((long long)hgt) - 1)) - 1ull) : ~0ull;
             const uint64_t seg = below_end & ~((1ull << start) - 1ull) & vm;
-            uint32_t key[8], p[8], fin[8], wm;
-            uint64_t M[8];
+            uint32_t key[8], p[8];
 #pragma unroll
             for (int j = 0; j < 8; j++) key[j] = (w16 >> (8 - j)) & 0xFFu;
-            match_windows<8>(w16, M);
             uint32_t *vt = tbl;
-            rank_round<true>(c0, key, M, seg, valid, g == open_g, vt, p, fin, wm);
-            // the group of the round's last valid element stays open into the next round: its states go to the table
+            // the group of the round's last valid element stays open into the next round: its states stay in the table
             const int lastlane = 63 - __clzll((long long)vm);
             const uint32_t g_last = readlane_u32(g, lastlane);
-            if (g_last != open_g && dirty) {
+            uint64_t hm = heads & vm;   // segment starts
+            if (!exact && (uint32_t)__popcll(hm) <= W3_ATOMIC_MAXSEG) {
+                // LDS-atomic rounds (atomic_round), one segment (= group) after the other; a group that ends inside the
+                // round leaves the table empty again: its own lanes zero what they touched, or, when it came in from
+                // earlier rounds, the whole table is cleared
+                uint32_t v[8];
 #pragma unroll
-                for (int k = 0; k < 32; k++) vt[k * 64 + lane] = 0u;
-                dirty = false;
-            }
-            __builtin_amdgcn_wave_barrier();
-            if (valid && g == g_last) {
+                for (int j = 0; j < 8; j++) v[j] = 0u;
+                __asm__ volatile("" ::: "memory");
+                if (dirty && readlane_u32(g, 0) != open_g) {
 #pragma unroll
-                for (int j = 0; j < 8; j++)
-                    if ((wm >> j) & 1u) vt[j * 256 + key[j]] = fin[j];
+                    for (int k = 0; k < 32; k++) vt[k * 64 + lane] = 0u;
+                    dirty = false;
+                }
+                bool carried = dirty;
+                while (hm) {
+                    const int st = __ffsll((long long)hm) - 1;
+                    hm &= hm - 1ull;
+                    const int en = hm ? __ffsll((long long)hm) - 1 : 64;
+                    const bool in = valid && lane >= st && lane < en;
+                    __asm__ volatile("" ::: "memory");
+                    if (in) atomic_round(vt, c0, key, true, v);
+                    __asm__ volatile("" ::: "memory");
+                    if (hm) {
+                        if (carried) {
+#pragma unroll
+                            for (int k = 0; k < 32; k++) vt[k * 64 + lane] = 0u;
+                        } else if (in) {
+#pragma unroll
+                            for (int j = 0; j < 8; j++) vt[j * 256 + key[j]] = 0u;
+                        }
+                    }
+                    carried = false;
+                }
+                __asm__ volatile("" ::: "memory");
+#pragma unroll
+                for (int j = 0; j < 8; j++) p[j] = counter_p_packed(v[j]);
+                exact = atomic_round_hot(v);
+            } else {
+                uint32_t fin[8], wm;
+                uint64_t M[8];
+                match_windows<8>(w16, M);
+                rank_round<true>(c0, key, M, seg, valid, g == open_g, vt, p, fin, wm);
+                if (g_last != open_g && dirty) {
+#pragma unroll
+                    for (int k = 0; k < 32; k++) vt[k * 64 + lane] = 0u;
+                    dirty = false;
+                }
+                __builtin_amdgcn_wave_barrier();
+                if (valid && g == g_last) {
+#pragma unroll
+                    for (int j = 0; j < 8; j++)
+                        if ((wm >> j) & 1u) vt[j * 256 + key[j]] = fin[j];
+                }
+                __asm__ volatile("" ::: "memory");
+                __builtin_amdgcn_wave_barrier();
             }
-            __asm__ volatile("" ::: "memory");
-            __builtin_amdgcn_wave_barrier();
             dirty = true;
             open_g = g_last;
             if (valid && !(a.dbg_flags & 1u)) a.P[off + i] = pack_p(p);  // 16-byte scatter, write-only

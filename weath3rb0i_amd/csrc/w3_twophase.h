@@ -10,6 +10,7 @@
 #include <algorithm>
 #include <cstdlib>
 #include <string>
+#include <vector>
 
 #include "w3_apm.h"
 #include "w3_coder.h"
@@ -24,6 +25,7 @@ struct TwoPhaseWs {
     bool P_valid = false;      // ws.P holds the merged stream of the last predict
     void *dbg = nullptr;       // 8 x u64 phase stamps of the last wide predict kernel (W3_OPT_DEBUG_STAMPS)
     int debug_stamps = 0;
+    int lds_order = -1;        // k_lds_order_selftest: -1 not run yet, 1 = returning LDS adds are lane-ordered (atomic rounds allowed), 0 = not
     const int16_t *stretch = nullptr;   // APM LUTs (device; owned by the ctx)
     const uint16_t *squash = nullptr;
     const uint2 *st = nullptr;          // NaiveStateTable rows for the slot-state leaves (device; owned by the ctx)
@@ -134,12 +136,40 @@ static inline int twophase_mix(TwoPhaseWs &ws, hipStream_t s, size_t n, std::str
     return W3_OK;
 }
 
+// Runs k_lds_order_selftest once per context and replays it on the host (see atomic_round in w3_predict.h).
+static inline bool twophase_lds_order_ok(TwoPhaseWs &ws, hipStream_t s) {
+    if (ws.lds_order >= 0) return ws.lds_order == 1;
+    ws.lds_order = 0;
+    if (getenv("W3_NO_LDS_ATOMICS")) return false;
+    const uint32_t waves = 64, rounds = 32, n = waves * rounds * 64;
+    uint32_t *d_old = nullptr;
+    if (hipMalloc(&d_old, (size_t)n * 4) != hipSuccess) { (void)hipGetLastError(); return false; }
+    std::vector<uint32_t> old(n), t(2048);
+    hipLaunchKernelGGL(w3::k_lds_order_selftest, dim3(waves), dim3(64), 0, s, d_old);
+    bool ok = hipGetLastError() == hipSuccess && hipMemcpyAsync(old.data(), d_old, (size_t)n * 4, hipMemcpyDeviceToHost, s) == hipSuccess &&
+              hipStreamSynchronize(s) == hipSuccess;
+    (void)hipFree(d_old);
+    if (!ok) { (void)hipGetLastError(); return false; }
+    for (uint32_t w = 0; w < waves && ok; w++) {
+        std::fill(t.begin(), t.end(), 0u);
+        for (uint32_t r = 0; r < rounds && ok; r++)
+            for (uint32_t l = 0; l < 64; l++) {
+                const uint32_t h = w3::lds_order_hash(w, r, l), k = w3::lds_order_key(w, h);
+                if (old[(w * rounds + r) * 64 + l] != t[k]) { ok = false; break; }
+                t[k] += (h >> 20) & 1u ? 0x10000u : 1u;
+            }
+    }
+    ws.lds_order = ok ? 1 : 0;
+    return ok;
+}
+
 // need_P: also merge the leaves' streams into ws.P (k_mix).  The default coder (k_coder_x3) mixes on the fly
 // and needs no P for up to 4 live leaves.
 static inline int twophase_predict(TwoPhaseWs &ws, hipStream_t s, const ParsedSpec &ps, const uint8_t *d_in, size_t n, size_t block_size,
                                    uint32_t nb, bool need_P, const uint16_t **d_P, hipEvent_t *ev, w3_timing *tm, std::string &err) {
     int rc = W3_OK;
     ws.P_valid = false;
+    const bool lds_atomics = twophase_lds_order_ok(ws, s);
     const uint32_t grid_small = std::min<uint32_t>(nb, 256 * 20);
     const uint32_t grid_wide = std::min<uint32_t>(nb, 256 * 16);
     bool need_keys = false, need_perm = false;
@@ -210,6 +240,7 @@ static inline int twophase_predict(TwoPhaseWs &ws, hipStream_t s, const ParsedSp
             continue;
         }
         pa.hbits = nd.bits - 3;
+        if (!lds_atomics) pa.dbg_flags |= 2u;
         bytes += n * 17;
         if (c == LEAF_SMALL_AC) {
             w3::HashArgs ha;
@@ -240,6 +271,7 @@ static inline int twophase_predict(TwoPhaseWs &ws, hipStream_t s, const ParsedSp
             pa.job_counter = (uint32_t *)ws.splits_w[w] + (size_t)nb * (W3_SLICES + 1);   // lives behind the split table
             (void)hipMemsetAsync(pa.job_counter, 0, 4, sp);
             if (getenv("W3_DEBUG_NOSTORE")) pa.dbg_flags = 1u;   // timing experiment: results are wrong
+            if (!lds_atomics) pa.dbg_flags |= 2u;
             // ~128 (order 1) / ~192 (order 2) blocks live: their P regions stay in the Infinity Cache.  Measured at 1e9 B
             // (grid 1024 / 2048 / 3072 / 4096): order 1 26.8 / 19.0 / 23.7 / 27.6 ms, order 2 28.0 / 18.6 / 17.1 / 20.7 ms.
             uint32_t rank_waves = c == LEAF_WIDE2 ? 3072u : 2048u;
@@ -260,13 +292,16 @@ static inline int twophase_predict(TwoPhaseWs &ws, hipStream_t s, const ParsedSp
         if (e != hipSuccess) { err = std::string("predict launch: ") + hipGetErrorString(e); return W3_E_HIP; }
     }
     // join, then rank inside the sorted groups (main stream: these kernels want the Infinity Cache to themselves)
+    const bool rank_side = forked && getenv("W3_RANK_SIDE");   // experiment: later leaves' rank kernels stay on the side stream
     for (int w = 0; w < n_def; w++) {
-        if (forked) (void)hipStreamWaitEvent(s, ws.ev_join[w], 0);   // this leaf's records are sorted (later leaves may still be partitioning)
-        if (deferred[w].cls == LEAF_WIDE1) hipLaunchKernelGGL(w3::k_rank_sorted<1>, dim3(deferred[w].grid_rank), dim3(64), 0, s, deferred[w].pa);
-        else hipLaunchKernelGGL(w3::k_rank_sorted<2>, dim3(deferred[w].grid_rank), dim3(64), 0, s, deferred[w].pa);
+        hipStream_t sr = rank_side && w > 0 ? ws.side : s;
+        if (forked && sr == s) (void)hipStreamWaitEvent(s, ws.ev_join[w], 0);   // this leaf's records are sorted (later leaves may still be partitioning)
+        if (deferred[w].cls == LEAF_WIDE1) hipLaunchKernelGGL(w3::k_rank_sorted<1>, dim3(deferred[w].grid_rank), dim3(64), 0, sr, deferred[w].pa);
+        else hipLaunchKernelGGL(w3::k_rank_sorted<2>, dim3(deferred[w].grid_rank), dim3(64), 0, sr, deferred[w].pa);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) { err = std::string("rank launch: ") + hipGetErrorString(e); return W3_E_HIP; }
     }
+    if (rank_side && n_def > 1) { (void)hipEventRecord(ws.ev_join[0], ws.side); (void)hipStreamWaitEvent(s, ws.ev_join[0], 0); }
     if (sa.n_leaves) {
         // HashMaps in HBM, one per (block, leaf), zeroed per batch of blocks; as many blocks at once as the budget allows
         if (!ws.st) { err = "state table not staged"; return W3_E_HIP; }
