@@ -93,6 +93,7 @@ def main():
     ap.add_argument("--size", type=int, default=1_000_000_000, help="input bytes PER GPU (enwik9-class = 1e9)")
     ap.add_argument("--block-size", type=int, default=65536)
     ap.add_argument("--path", default="auto", help="auto | generic | twophase")
+    ap.add_argument("--parts", type=int, default=0, help="block ranges pipelined inside one encode call (W3_OPT_PARTS): 0 = auto, 1..4")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--force-exchange", action="store_true", help="run the RCCL exchange step even with 1 rank (rehearsal)")
@@ -125,6 +126,7 @@ def main():
     model, model_name = make_model(w3, args.model)
     ctx = w3.Context(local_rank)
     ctx.set_path(args.path)
+    ctx.set_parts(args.parts)
 
     # rank r owns chunks [r*chunks, (r+1)*chunks) of one global seeded stream (weak scaling: n bytes per GPU)
     chunks_per_rank = (n + (1 << 20) - 1) >> 20
@@ -167,6 +169,7 @@ def main():
     kern_ms = {"predict_ms": 0.0, "achash_ms": 0.0, "slot_ms": 0.0, "apm_ms": 0.0, "coder_ms": 0.0, "pack_ms": 0.0, "generic_ms": 0.0}
     coder_bytes = 0
     launches = 0
+    parts = 1
     sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -177,6 +180,7 @@ def main():
         coder_bytes += tm["coder_bytes"]
         launches += max(1, tm["n_coder_launches"])
         path = tm["path"]
+        parts = max(1, tm["n_parts"])
     sync()
     dt = time.perf_counter() - t0
     ctx.set_timing(False)
@@ -199,18 +203,19 @@ def main():
             # input + its output stream; k_slot = per leaf and input byte 2 nibbles x (96 B read + 96 B written) + input + stream
             cands = [("k_coder_x3 (mix + recurrence + output wavefronts)", kern_ms["coder_ms"] / launches, coder_bytes / launches)]
             if napm == 1:
-                cands.append(("k_apm0<%d> (APM stage: wave per block, table in LDS)" % (ncnt + nslot), kern_ms["apm_ms"] / args.steps,
-                              n * (16 * (ncnt + nslot) + 1 + 16)))
+                cands.append(("k_apm0<%d> (APM stage: wave per block, table in LDS)" % (ncnt + nslot), kern_ms["apm_ms"] / (args.steps * parts),
+                              n * (16 * (ncnt + nslot) + 1 + 16) / parts))
             if nslot:
                 cands.append(("k_slot (slot-state leaves: lane per block, hash map in HBM; all batches of a step)",
                               kern_ms["slot_ms"] / args.steps, nslot * n * (1 + 16 + 2 * 192)))
             if kern_ms["achash_ms"] > 0:   # ACHistory leaves: one byte read + 8 key bytes written per input byte (+ the 8 MiB prefix table)
-                cands.append(("k_achash (ACHistory keys of every step, 16-bit prefix table)", kern_ms["achash_ms"] / args.steps, n * 9 + (8 << 20)))
+                cands.append(("k_achash (ACHistory keys of every step, 16-bit prefix table)", kern_ms["achash_ms"] / (args.steps * parts),
+                              n * 9 / parts + (8 << 20)))
             dom_name, dom_ms, dom_bytes = max(cands, key=lambda c: c[1])
             try:  # PMC-measured HBM bytes of this kernel for this exact config (profiles/, separate rocprofv3 --pmc passes)
                 for tj in json.load(open(os.path.join(ROOT, "profiles", "r1_traffic.json")))["entries"]:
                     if tj["config"] == {"model": args.model, "bytes_per_gpu": n, "block_size": bs} and dom_name.startswith(tj["kernel"]):
-                        traffic = tj["traffic_bytes_per_step"]
+                        traffic = int(tj["traffic_bytes_per_step"] / parts)   # per launch, like `achieved`
             except (OSError, KeyError, ValueError):
                 pass
         else:
@@ -228,10 +233,12 @@ def main():
             "config": {"workload": "enwik9-shaped synthetic text (tools/synth.c seed %d), %d bytes per GPU, %d-byte blocks, model %s"
                        % (args.seed, n, bs, model_name), "bytes_per_gpu": n, "block_size": bs, "blocks_per_gpu": nb,
                        "model": model_name, "path": {1: "generic", 2: "twophase"}.get(path, str(path)), "compressed_ratio": round(ratio, 4),
+                       "ranges_per_call": parts,
                        "exchange": "all_gather sizes + grouped send/recv to rank 0 (RCCL), overlapped with the next step's encode" if world > 1 else "none (1 GPU)"},
             "roofline": {"bound": "hbm", "kernel": dom_name, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic,
-                         "avg_launch_ms": round(dom_ms, 4), "algorithmic_bytes_per_launch": int(dom_bytes)},
+                         "avg_launch_ms": round(dom_ms, 4), "algorithmic_bytes_per_launch": int(dom_bytes),
+                         "launches_per_step": parts if path == 2 else 1},
             "kernel_ms_per_step": {k: round(v / args.steps, 3) for k, v in kern_ms.items()},
         }
         if world == 1 and not args.no_cpu_baseline:

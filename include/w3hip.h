@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define W3_ABI_VERSION 3
+#define W3_ABI_VERSION 4
 
 /* ---- error codes --------------------------------------------------------- */
 enum {
@@ -108,7 +108,10 @@ enum {
     W3_OPT_TIMING = 2,  /* 1 = record per-kernel hipEvent timings (w3_get_timing) */
     W3_OPT_CODER  = 3,  /* two-phase coder kernel: 0 = k_coder_x3 (default), 1 = k_coder_fast, 2 = robust k_coder only, 3 = k_coder_x2 */
     W3_OPT_ACC_LIMIT = 4, /* test hook (19..46): accumulator fill at which the fast coder hands a block back */
-    W3_OPT_DEBUG_STAMPS = 5 /* diagnostic: 1 = the partitioned predict kernel sums s_memtime per phase */
+    W3_OPT_DEBUG_STAMPS = 5, /* diagnostic: 1 = the partitioned predict kernel sums s_memtime per phase */
+    W3_OPT_PARTS = 6    /* two-phase encode: block ranges pipelined on separate streams inside one call (the coder and APM
+                           kernels of one range beside the predict kernels of the next); 0/1 = one range (default), 2..4.
+                           Output is identical; measured no faster on MI355X */
 };
 enum { W3_PATH_AUTO = 0, W3_PATH_GENERIC = 1, W3_PATH_TWOPHASE = 2 };
 int         w3_ctx_set_option(w3_ctx *ctx, int opt, int64_t value);
@@ -198,7 +201,8 @@ typedef struct w3_timing {
     float    slot_ms;      /* slot-state leaves: table zero-fill + k_slot launches (also inside predict_ms) */
     uint32_t n_slot_launches; /* k_slot launches (block batches sized to the device memory budget) */
     float    achash_ms;    /* ACHistory key kernels (k_achash_lut + k_achash; also inside predict_ms) */
-    uint32_t reserved;
+    uint32_t n_parts;      /* block ranges the call was pipelined in (W3_OPT_PARTS); the *_ms fields above are sums over
+                              the ranges' kernels, which overlap in time: their sum can exceed total_ms */
 } w3_timing;
 int w3_get_timing(const w3_ctx *ctx, w3_timing *out);
 

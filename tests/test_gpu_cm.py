@@ -188,6 +188,20 @@ def test_slot_tables_in_batches(ctx, oracle, monkeypatch):
         ctx.set_timing(False)
 
 
+def test_apm_models_in_block_ranges(ctx, oracle):
+    """Range pipelining with APM chains (ORDER0 and ORDER1 stages); slot-state specs stay in one range."""
+    data = markov_text(500 * 1024 + 17, seed=33)
+    ctx.set_parts(3)
+    try:
+        for name in ("o012_apm", "apm_chain4"):
+            check(ctx, oracle, name, data, 512, decode=False)
+        dev, _ = pair(oracle, "slot2")
+        ctx.encode_blocks(dev(), data[:300 * 512], 512)
+        assert ctx.timing()["n_parts"] == 1
+    finally:
+        ctx.set_parts(0)
+
+
 def test_cm_unstaged_kernel_still_agrees(ctx, oracle, monkeypatch):
     """k_cm (cells in global memory, used beyond 8 slot leaves) against k_cm_staged and the oracle."""
     data = markov_text(20000, seed=15) + mixed_bytes(6000, seed=16)

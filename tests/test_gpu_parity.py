@@ -127,6 +127,29 @@ def test_order2_partition_chained_and_from_scratch(ctx, oracle, monkeypatch):
     check_blocks(ctx, oracle, "best012", data, 65536, "twophase")
 
 
+@pytest.mark.parametrize("parts", [2, 3, 4])
+def test_block_ranges_pipelined_on_streams(ctx, oracle, parts):
+    """W3_OPT_PARTS: the call's blocks as 2..4 ranges on separate streams (range r's APM / coder kernels beside range
+    r+1's predict kernels), own workspace each; same streams, lengths and hand-backs as one range."""
+    data = markov_text(300 * 1024 + 333, seed=31) + bytes(40 * 1024) + lcg_text(200 * 1024, seed=6)
+    bs = 512                                                     # 1081 blocks -> ranges of >= 256 blocks
+    ctx.set_parts(parts)
+    ctx.set_timing(True)
+    try:
+        for name in ("best012", "main_default", "order0"):
+            check_blocks(ctx, oracle, name, data, bs, "twophase")
+            assert ctx.timing()["n_parts"] == parts
+        ctx.set_acc_limit(19)                                   # hand-backs in every range (robust coder per range)
+        check_blocks(ctx, oracle, "best012", data, bs, "twophase")
+        assert ctx.timing()["n_recoded_blocks"] > 0
+    finally:
+        ctx.set_acc_limit(46)
+        ctx.set_parts(0)
+        ctx.set_timing(False)
+    out, lens = ctx.encode_blocks(pair(oracle, "best012")[0](), data[:100 * 512], bs)   # too few blocks: one range
+    assert ctx.timing()["n_parts"] == 1
+
+
 @pytest.mark.parametrize("name", NOT_TWOPHASE)
 def test_twophase_rejects_uncovered_specs(ctx, oracle, name):
     from weath3rb0i_amd import _lib as L

@@ -28,7 +28,7 @@ def test_exports_match_header(lib):
     for name in sorted(declared):
         assert hasattr(lib, name), "libw3hip.so does not export %s" % name
     assert declared == set(L.EXPORTS)
-    assert lib.w3_abi_version() == 3
+    assert lib.w3_abi_version() == 4
 
 
 def test_struct_layout(lib):

@@ -12,7 +12,7 @@ W3_APM_ORDER0, W3_APM_ORDER1 = 0, 1
 W3_MAX_APM = 4
 W3_HIST_NONE, W3_HIST_RAW, W3_HIST_AC = 0, 1, 2
 W3_OK, W3_E_INVALID, W3_E_NOSPACE, W3_E_HIP, W3_E_UNSUPPORTED, W3_E_NOMEM, W3_E_FORMAT = 0, -1, -2, -3, -4, -5, -6
-W3_OPT_PATH, W3_OPT_TIMING, W3_OPT_CODER, W3_OPT_ACC_LIMIT, W3_OPT_DEBUG_STAMPS = 1, 2, 3, 4, 5
+W3_OPT_PATH, W3_OPT_TIMING, W3_OPT_CODER, W3_OPT_ACC_LIMIT, W3_OPT_DEBUG_STAMPS, W3_OPT_PARTS = 1, 2, 3, 4, 5, 6
 W3_PATH_AUTO, W3_PATH_GENERIC, W3_PATH_TWOPHASE = 0, 1, 2
 
 
@@ -29,7 +29,7 @@ class Timing(C.Structure):
     _fields_ = [("predict_ms", C.c_float), ("coder_ms", C.c_float), ("pack_ms", C.c_float), ("generic_ms", C.c_float),
                 ("total_ms", C.c_float), ("path", C.c_uint32), ("n_coder_launches", C.c_uint32),
                 ("coder_bytes", C.c_uint64), ("predict_bytes", C.c_uint64), ("n_recoded_blocks", C.c_uint32), ("apm_ms", C.c_float),
-                ("slot_ms", C.c_float), ("n_slot_launches", C.c_uint32), ("achash_ms", C.c_float), ("reserved", C.c_uint32)]
+                ("slot_ms", C.c_float), ("n_slot_launches", C.c_uint32), ("achash_ms", C.c_float), ("n_parts", C.c_uint32)]
 
 
 EXPORTS = [

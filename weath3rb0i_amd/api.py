@@ -49,6 +49,10 @@ class Context:
     def set_acc_limit(self, bits):
         self._chk(self.lib.w3_ctx_set_option(self.h, L.W3_OPT_ACC_LIMIT, bits))
 
+    def set_parts(self, parts=0):
+        """Block ranges a two-phase encode is pipelined in on separate streams (0 = auto, 1 = one range)."""
+        self._chk(self.lib.w3_ctx_set_option(self.h, L.W3_OPT_PARTS, int(parts)))
+
     def set_timing(self, on=True):
         self._chk(self.lib.w3_ctx_set_option(self.h, L.W3_OPT_TIMING, int(on)))
 

@@ -45,6 +45,7 @@ struct PredictArgs {
     uint32_t *splits;       // [nblocks][W3_SLICES + 1] slice boundaries inside each block's sorted range
     uint32_t *job_counter;  // k_rank_sorted: next job (zeroed before the launch)
     uint32_t hbits;         // H = bits_in_context - 3
+    uint32_t maxseg;        // k_rank_sorted: rounds with more groups than this take the ballot path (W3_ATOMIC_MAXSEG)
     uint32_t dbg_flags;      // bit0 = skip the stream stores (timing experiments only); bit1 = ballot rounds only (no LDS atomics)
     unsigned long long *dbg; // optional: per-phase s_memtime sums (diagnostic builds/runs only; never read by kernels)
 };
@@ -463,7 +464,7 @@ __device__ __forceinline__ void partition_pass4(const uint8_t *blk, uint32_t len
     }
 }
 
-#define W3_SLICES 16u   // rank jobs per block (sorted range cut at group boundaries)
+#define W3_SLICES 64u   // rank jobs per block (sorted range cut at group boundaries)
 
 // k_partition<NBYTES>: one wavefront per block sorts the block's records stably by the group key
 // (NBYTES 1: c1 — Order1; 2: (c1,c2) — OrderN(27,3)) into a.rec, and cuts the sorted range into
@@ -597,7 +598,7 @@ __global__ void __launch_bounds__(64) k_rank_sorted(PredictArgs a) {
             const int lastlane = 63 - __clzll((long long)vm);
             const uint32_t g_last = readlane_u32(g, lastlane);
             uint64_t hm = heads & vm;   // segment starts
-            if (!exact && (uint32_t)__popcll(hm) <= W3_ATOMIC_MAXSEG) {
+            if (!exact && (uint32_t)__popcll(hm) <= a.maxseg) {
                 // LDS-atomic rounds (atomic_round), one segment (= group) after the other; a group that ends inside the
                 // round leaves the table empty again: its own lanes zero what they touched, or, when it came in from
                 // earlier rounds, the whole table is cleared
@@ -655,7 +656,7 @@ __global__ void __launch_bounds__(64) k_rank_sorted(PredictArgs a) {
             }
             dirty = true;
             open_g = g_last;
-            if (valid && !(a.dbg_flags & 1u)) a.P[off + i] = pack_p(p);  // 16-byte scatter, write-only
+            if (valid && !(a.dbg_flags & 1u)) a.P[off + ((a.dbg_flags & 4u) ? (i & 0xFFFu) : i)] = pack_p(p);  // 16-byte scatter, write-only
         }
         W3_STAMP(3);
         if (a.dbg && lane == 0 && sl == 0) atomicAdd(&a.dbg[7], 1ull);

@@ -25,6 +25,8 @@ struct TwoPhaseWs {
     bool P_valid = false;      // ws.P holds the merged stream of the last predict
     void *dbg = nullptr;       // 8 x u64 phase stamps of the last wide predict kernel (W3_OPT_DEBUG_STAMPS)
     int debug_stamps = 0;
+    bool achash_timed = false; // the last predict call recorded ev[12]/ev[13]
+    hipEvent_t ev_pred_done = nullptr;   // recorded by twophase_encode when the predict phase has been enqueued (range pipelining)
     int lds_order = -1;        // k_lds_order_selftest: -1 not run yet, 1 = returning LDS adds are lane-ordered (atomic rounds allowed), 0 = not
     const int16_t *stretch = nullptr;   // APM LUTs (device; owned by the ctx)
     const uint16_t *squash = nullptr;
@@ -34,6 +36,11 @@ struct TwoPhaseWs {
     size_t rec_w_cap[4] = {0, 0, 0, 0}, perm_w_cap[4] = {0, 0, 0, 0}, splits_w_cap[4] = {0, 0, 0, 0};
     int wide1_slot = -1;                // rec_w / splits_w index of an Order1-shaped leaf of the last predict (records sorted by c1)
     hipStream_t side = nullptr;
+    // range pipelining: the APM and coder kernels go to a high-priority stream, so that their workgroups are placed ahead
+    // of the next range's predict kernels (which otherwise take every slot that frees up)
+    bool use_hi = false;
+    hipStream_t hi = nullptr;
+    hipEvent_t ev_hi_start = nullptr, ev_hi_done = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join[4] = {nullptr, nullptr, nullptr, nullptr};
     void *achash_lut = nullptr;         // k_achash_lut: [65536][8] coder states (8 MiB)
     size_t achash_lut_cap = 0;
@@ -58,6 +65,10 @@ struct TwoPhaseWs {
         if (ev_fork) (void)hipEventDestroy(ev_fork);
         for (int w = 0; w < 4; w++) { if (ev_join[w]) (void)hipEventDestroy(ev_join[w]); ev_join[w] = nullptr; }
         side = nullptr; ev_fork = nullptr;
+        if (hi) (void)hipStreamDestroy(hi);
+        if (ev_hi_start) (void)hipEventDestroy(ev_hi_start);
+        if (ev_hi_done) (void)hipEventDestroy(ev_hi_done);
+        hi = nullptr; ev_hi_start = ev_hi_done = nullptr;
         if (achash_lut) (void)hipFree(achash_lut);
         achash_lut = nullptr; achash_lut_cap = 0;
         if (dummy) (void)hipFree(dummy);
@@ -169,6 +180,7 @@ static inline int twophase_predict(TwoPhaseWs &ws, hipStream_t s, const ParsedSp
                                    uint32_t nb, bool need_P, const uint16_t **d_P, hipEvent_t *ev, w3_timing *tm, std::string &err) {
     int rc = W3_OK;
     ws.P_valid = false;
+    ws.achash_timed = false;
     const bool lds_atomics = twophase_lds_order_ok(ws, s);
     const uint32_t grid_small = std::min<uint32_t>(nb, 256 * 20);
     const uint32_t grid_wide = std::min<uint32_t>(nb, 256 * 16);
@@ -240,6 +252,8 @@ static inline int twophase_predict(TwoPhaseWs &ws, hipStream_t s, const ParsedSp
             continue;
         }
         pa.hbits = nd.bits - 3;
+        pa.maxseg = W3_ATOMIC_MAXSEG;
+        if (const char *ev_ = getenv("W3_ATOMIC_MAXSEG")) pa.maxseg = (uint32_t)std::max(0, atoi(ev_));   // tuning hook
         if (!lds_atomics) pa.dbg_flags |= 2u;
         bytes += n * 17;
         if (c == LEAF_SMALL_AC) {
@@ -254,7 +268,7 @@ static inline int twophase_predict(TwoPhaseWs &ws, hipStream_t s, const ParsedSp
             if (ev && !achash_timed) (void)hipEventRecord(ev[12], s);   // (timed for the first ACHistory leaf)
             hipLaunchKernelGGL(w3::k_achash_lut, dim3((8u << W3_ACHASH_LUT_BITS) / 256), dim3(256), 0, s, ha);
             hipLaunchKernelGGL(w3::k_achash, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, ha);
-            if (ev && !achash_timed) { (void)hipEventRecord(ev[13], s); achash_timed = true; if (tm) tm->reserved = 1u; }
+            if (ev && !achash_timed) { (void)hipEventRecord(ev[13], s); achash_timed = true; ws.achash_timed = true; }
             pa.keys = (const uint2 *)ws.keys;
             launch_small<true>(nd.bits - 3, dim3(grid_small), s, pa);
             bytes += n * 17;
@@ -270,7 +284,7 @@ static inline int twophase_predict(TwoPhaseWs &ws, hipStream_t s, const ParsedSp
             pa.rec = (uint2 *)ws.rec_w[w]; pa.splits = (uint32_t *)ws.splits_w[w];
             pa.job_counter = (uint32_t *)ws.splits_w[w] + (size_t)nb * (W3_SLICES + 1);   // lives behind the split table
             (void)hipMemsetAsync(pa.job_counter, 0, 4, sp);
-            if (getenv("W3_DEBUG_NOSTORE")) pa.dbg_flags = 1u;   // timing experiment: results are wrong
+            if (const char *ev_ = getenv("W3_DEBUG_NOSTORE")) pa.dbg_flags = (uint32_t)atoi(ev_) & 5u;   // timing experiments: results are wrong
             if (!lds_atomics) pa.dbg_flags |= 2u;
             // ~128 (order 1) / ~192 (order 2) blocks live: their P regions stay in the Infinity Cache.  Measured at 1e9 B
             // (grid 1024 / 2048 / 3072 / 4096): order 1 26.8 / 19.0 / 23.7 / 27.6 ms, order 2 28.0 / 18.6 / 17.1 / 20.7 ms.
@@ -437,6 +451,19 @@ static inline int twophase_encode(TwoPhaseWs &ws, hipStream_t s, const ParsedSpe
     const bool x3 = ws.coder_mode == 0 && (n_live <= 4 || ps.n_apm > 0);   // more leaves: merge with k_mix first, then k_coder_x2
     int rc = twophase_predict(ws, s, ps, d_in, n, block_size, nb, !x3 && ps.n_apm == 0, nullptr, ev, tm, err);
     if (rc) return rc;
+    if (ws.ev_pred_done) (void)hipEventRecord(ws.ev_pred_done, s);   // the next block range may start its predict kernels
+    hipStream_t s_lo = s;
+    if (ws.use_hi) {
+        if (!ws.hi) {
+            int lo_p = 0, hi_p = 0;
+            bool ok = hipDeviceGetStreamPriorityRange(&lo_p, &hi_p) == hipSuccess && hipStreamCreateWithPriority(&ws.hi, hipStreamNonBlocking, hi_p) == hipSuccess &&
+                      hipEventCreateWithFlags(&ws.ev_hi_start, hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&ws.ev_hi_done, hipEventDisableTiming) == hipSuccess;
+            if (!ok) { (void)hipGetLastError(); err = "high-priority stream creation failed"; return W3_E_HIP; }
+        }
+        (void)hipEventRecord(ws.ev_hi_start, s);
+        (void)hipStreamWaitEvent(ws.hi, ws.ev_hi_start, 0);
+        s = ws.hi;
+    }
     if ((rc = twophase_apm(ws, s, ps, d_in, n, block_size, nb, ev, tm, err))) return rc;   // leaves ws.P as the one source stream
     if (getenv("W3_DEBUG_NOSTORE")) { err = "W3_DEBUG_NOSTORE: predict-only timing experiment"; return W3_E_UNSUPPORTED; }
     if ((rc = tp_ensure(ws.redo, ws.redo_cap, (size_t)nb * 4, err))) return rc;
@@ -477,6 +504,7 @@ static inline int twophase_encode(TwoPhaseWs &ws, hipStream_t s, const ParsedSpe
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { err = std::string("coder launch: ") + hipGetErrorString(e); return W3_E_HIP; }
     if (tm) tm->n_coder_launches = 1;
+    if (s != s_lo) { (void)hipEventRecord(ws.ev_hi_done, s); (void)hipStreamWaitEvent(s_lo, ws.ev_hi_done, 0); }
     return W3_OK;
 }
 

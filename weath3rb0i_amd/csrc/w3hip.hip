@@ -28,6 +28,8 @@ struct DevBuf {
     size_t cap = 0;
 };
 
+#define W3_MAX_PARTS 4
+
 struct w3_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -39,6 +41,11 @@ struct w3_ctx {
     // workspace
     DevBuf tables, stripes, lens, offs, total, flag, io_in, io_out, coffs, misc, cm_luts, achash_luts;
     TwoPhaseWs tp;
+    // block ranges 1..3 of a pipelined two-phase encode (range 0 uses tp, ev and the caller's stream)
+    struct Range { TwoPhaseWs ws; hipStream_t stream = nullptr; hipEvent_t ev[14]{}; hipEvent_t ev_done = nullptr; };
+    Range ranges[W3_MAX_PARTS - 1];
+    hipEvent_t ev_fork = nullptr, ev_pred[W3_MAX_PARTS]{};
+    int opt_parts = 0;   // 0 = auto
 };
 
 #define HIPCHK(ctx, expr)                                                                       \
@@ -107,6 +114,14 @@ extern "C" void w3_ctx_destroy(w3_ctx *ctx) {
     for (DevBuf *b : bufs)
         if (b->p) (void)hipFree(b->p);
     ctx->tp.release();
+    for (auto &r : ctx->ranges) {
+        r.ws.release();
+        for (auto &e : r.ev) if (e) (void)hipEventDestroy(e);
+        if (r.ev_done) (void)hipEventDestroy(r.ev_done);
+        if (r.stream) (void)hipStreamDestroy(r.stream);
+    }
+    if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
+    for (auto &e : ctx->ev_pred) if (e) (void)hipEventDestroy(e);
     for (auto &e : ctx->ev)
         if (e) (void)hipEventDestroy(e);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -126,6 +141,10 @@ extern "C" int w3_ctx_set_option(w3_ctx *ctx, int opt, int64_t value) {
         ctx->tp.coder_mode = (int)value;
         return W3_OK;
     case W3_OPT_DEBUG_STAMPS: ctx->tp.debug_stamps = value ? 1 : 0; return W3_OK;
+    case W3_OPT_PARTS:
+        if (value < 0 || value > W3_MAX_PARTS) return W3_E_INVALID;
+        ctx->opt_parts = (int)value;
+        return W3_OK;
     case W3_OPT_ACC_LIMIT:
         if (value < 19 || value > 46) return W3_E_INVALID;
         ctx->tp.acc_limit = (uint32_t)value;
@@ -490,6 +509,46 @@ static int check_args(w3_ctx *ctx, size_t n, size_t block_size) {
     return W3_OK;
 }
 
+static float elapsed_ev(hipEvent_t *ev, int slot) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, ev[2 * slot], ev[2 * slot + 1]) != hipSuccess) { (void)hipGetLastError(); return 0.f; }
+    return ms;
+}
+
+// How many block ranges a two-phase encode is pipelined in (W3_OPT_PARTS; default ONE).  The idea: the coder (lane per
+// block: fewer wavefronts than SIMDs) and the APM kernels (two wavefronts per SIMD, LDS-bound) leave most issue slots idle,
+// so range r's APM and coder kernels could execute beside range r+1's predict kernels.  Measured on MI355X (1e9 B,
+// order012apm): 2 ranges 115 -> 115 ms, 4 ranges 185 ms.  The APM workgroups (77 KB of LDS) are starved while predict
+// kernels are resident: 8 KB workgroups refill every hole that opens, the LDS never has a contiguous free region, and a
+// high-priority stream (tried: use_hi) does not reserve one.  Kept as a tested option; not the default.
+// Slot-state leaves size their hash-map batches from the free device memory, so specs with them stay in one range.
+static int choose_parts(const w3_ctx *ctx, const ParsedSpec &ps, uint32_t nb) {
+    if (ps.has_slot) return 1;
+    int k = ctx->opt_parts;
+    if (const char *e = getenv("W3_PARTS")) k = atoi(e);   // tuning hook
+    if (k <= 0) k = 1;
+    k = std::min(k, W3_MAX_PARTS);
+    while (k > 1 && nb / (uint32_t)k < 256u) k--;
+    return k;
+}
+
+static int ensure_ranges(w3_ctx *ctx, int parts, bool timing) {
+    if (!ctx->ev_fork) HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
+    for (int p = 0; p < parts; p++)
+        if (!ctx->ev_pred[p]) HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_pred[p], hipEventDisableTiming));
+    for (int p = 1; p < parts; p++) {
+        w3_ctx::Range &r = ctx->ranges[p - 1];
+        if (!r.stream) HIPCHK(ctx, hipStreamCreateWithFlags(&r.stream, hipStreamNonBlocking));
+        if (!r.ev_done) HIPCHK(ctx, hipEventCreateWithFlags(&r.ev_done, hipEventDisableTiming));
+        if (timing)
+            for (auto &e : r.ev)
+                if (!e) HIPCHK(ctx, hipEventCreate(&e));
+        r.ws.coder_mode = ctx->tp.coder_mode; r.ws.acc_limit = ctx->tp.acc_limit; r.ws.debug_stamps = 0;
+        r.ws.stretch = ctx->tp.stretch; r.ws.squash = ctx->tp.squash; r.ws.st = ctx->tp.st;
+    }
+    return W3_OK;
+}
+
 extern "C" int w3_encode_blocks_device(w3_ctx *ctx, const w3_model_spec *spec, const uint8_t *d_in, size_t n, size_t block_size,
                                        uint8_t *d_out, size_t out_cap, uint32_t *d_block_lens, uint64_t *d_total, void *stream) {
     int rc = check_args(ctx, n, block_size);
@@ -521,13 +580,42 @@ extern "C" int w3_encode_blocks_device(w3_ctx *ctx, const w3_model_spec *spec, c
 
     Timer tm{ctx, s, 0};
     uint32_t cap = default_stripe_cap(block_size);
+    const int parts = two ? choose_parts(ctx, ps, nb) : 1;
+    uint32_t pb[W3_MAX_PARTS + 1];   // range p = blocks [pb[p], pb[p+1]); boundaries on multiples of 64 blocks
+    for (int p = 0; p <= parts; p++) pb[p] = p == parts ? nb : (uint32_t)((uint64_t)nb * p / parts) / 64u * 64u;
+    w3_timing ptm[W3_MAX_PARTS];
+    memset(ptm, 0, sizeof ptm);
+    if (parts > 1 && (rc = ensure_ranges(ctx, parts, ctx->opt_timing != 0))) return rc;
+    ENSURE(ctx, ctx->flag, 16 * W3_MAX_PARTS);
     for (int attempt = 0; attempt < 2; attempt++) {
         ENSURE(ctx, ctx->stripes, (size_t)nb * cap);
-        HIPCHK(ctx, hipMemsetAsync(ctx->flag.p, 0, 16, s));
+        HIPCHK(ctx, hipMemsetAsync(ctx->flag.p, 0, 16 * W3_MAX_PARTS, s));
         tm.start(3);
+        uint32_t fl[4 * W3_MAX_PARTS];
+        memset(fl, 0, sizeof fl);
         if (two) {
-            rc = twophase_encode(ctx->tp, s, ps, d_in, n, block_size, nb, (uint8_t *)ctx->stripes.p, cap, d_block_lens,
-                                 (uint32_t *)ctx->flag.p, ctx->opt_timing ? ctx->ev : nullptr, &ctx->timing, ctx->err);
+            if (parts > 1) HIPCHK(ctx, hipEventRecord(ctx->ev_fork, s));
+            for (int p = 0; p < parts && !rc; p++) {
+                TwoPhaseWs &ws = p ? ctx->ranges[p - 1].ws : ctx->tp;
+                hipStream_t sp = p ? ctx->ranges[p - 1].stream : s;
+                hipEvent_t *evp = !ctx->opt_timing ? nullptr : p ? ctx->ranges[p - 1].ev : ctx->ev;
+                const size_t o = (size_t)pb[p] * block_size, np = std::min<size_t>(n, (size_t)pb[p + 1] * block_size) - o;
+                if (p) {   // after the call's earlier work on s, and once the previous range's predict kernels are through
+                    HIPCHK(ctx, hipStreamWaitEvent(sp, ctx->ev_fork, 0));
+                    HIPCHK(ctx, hipStreamWaitEvent(sp, ctx->ev_pred[p - 1], 0));
+                }
+                ws.use_hi = parts > 1 && !getenv("W3_NO_HI_STREAM");
+                ws.ev_pred_done = parts > 1 ? ctx->ev_pred[p] : nullptr;
+                if (p && ctx->tp.lds_order >= 0) ws.lds_order = ctx->tp.lds_order;   // (range 0 has run the self-test)
+                rc = twophase_encode(ws, sp, ps, d_in + o, np, block_size, pb[p + 1] - pb[p], (uint8_t *)ctx->stripes.p + (size_t)pb[p] * cap, cap,
+                                     d_block_lens + pb[p], (uint32_t *)ctx->flag.p + 4 * p, evp, &ptm[p], ctx->err);
+                ws.ev_pred_done = nullptr;
+                if (p && !rc) { HIPCHK(ctx, hipEventRecord(ctx->ranges[p - 1].ev_done, sp)); HIPCHK(ctx, hipStreamWaitEvent(s, ctx->ranges[p - 1].ev_done, 0)); }
+            }
+            if (rc) {   // leave no range running behind an error return
+                if (parts > 1) (void)hipDeviceSynchronize();
+                return rc;
+            }
             ctx->timing.path = W3_PATH_TWOPHASE;
         } else {
             tm.start(0);
@@ -535,24 +623,33 @@ extern "C" int w3_encode_blocks_device(w3_ctx *ctx, const w3_model_spec *spec, c
                             : generic_encode(ctx, s, ps, d_in, n, block_size, nb, cap, d_block_lens);
             tm.stop();
             ctx->timing.path = W3_PATH_GENERIC;
-        }
-        if (rc) return rc;
-        uint32_t fl[2] = {0, 0};
-        HIPCHK(ctx, hipMemcpyAsync(fl, ctx->flag.p, 8, hipMemcpyDeviceToHost, s));
-        HIPCHK(ctx, hipStreamSynchronize(s));
-        if (two && fl[1]) {  // blocks the fast coder handed back (pending-bit run longer than its accumulator)
-            ctx->timing.n_recoded_blocks = fl[1];
-            rc = twophase_recode(ctx->tp, s, d_in, n, block_size, nb, (uint8_t *)ctx->stripes.p, cap, d_block_lens,
-                                 (uint32_t *)ctx->flag.p, fl[1], ctx->err);
             if (rc) return rc;
-            HIPCHK(ctx, hipMemcpyAsync(fl, ctx->flag.p, 8, hipMemcpyDeviceToHost, s));
+        }
+        HIPCHK(ctx, hipMemcpyAsync(fl, ctx->flag.p, sizeof fl, hipMemcpyDeviceToHost, s));
+        HIPCHK(ctx, hipStreamSynchronize(s));
+        bool recoded = false;
+        for (int p = 0; p < parts && two; p++) {
+            if (!fl[4 * p + 1]) continue;   // blocks the fast coder handed back (pending-bit run longer than its accumulator)
+            TwoPhaseWs &ws = p ? ctx->ranges[p - 1].ws : ctx->tp;
+            const size_t o = (size_t)pb[p] * block_size, np = std::min<size_t>(n, (size_t)pb[p + 1] * block_size) - o;
+            ctx->timing.n_recoded_blocks += fl[4 * p + 1];
+            rc = twophase_recode(ws, s, d_in + o, np, block_size, pb[p + 1] - pb[p], (uint8_t *)ctx->stripes.p + (size_t)pb[p] * cap, cap,
+                                 d_block_lens + pb[p], (uint32_t *)ctx->flag.p + 4 * p, fl[4 * p + 1], ctx->err);
+            if (rc) return rc;
+            recoded = true;
+        }
+        if (recoded) {
+            HIPCHK(ctx, hipMemcpyAsync(fl, ctx->flag.p, sizeof fl, hipMemcpyDeviceToHost, s));
             HIPCHK(ctx, hipStreamSynchronize(s));
         }
-        if (fl[0] & 2u) { ctx->err = "coder pipeline timeout (internal error)"; return W3_E_HIP; }
-        const uint32_t ovf = fl[0] & 1u;
+        uint32_t f0 = 0;
+        for (int p = 0; p < parts; p++) f0 |= fl[4 * p];
+        if (f0 & 2u) { ctx->err = "coder pipeline timeout (internal error)"; return W3_E_HIP; }
+        const uint32_t ovf = f0 & 1u;
         if (!ovf) break;
         if (attempt == 1) { ctx->err = "stripe overflow at the worst-case bound (internal error)"; return W3_E_HIP; }
         cap = worst_stripe_cap(block_size);  // rare: a block expanded past 2N+64
+        ctx->timing.n_recoded_blocks = 0;
     }
     Timer tp{ctx, s, 0};
     tp.start(2);
@@ -563,18 +660,29 @@ extern "C" int w3_encode_blocks_device(w3_ctx *ctx, const w3_model_spec *spec, c
     uint64_t total = 0;
     HIPCHK(ctx, hipMemcpyAsync(&total, total_p, 8, hipMemcpyDeviceToHost, s));
     HIPCHK(ctx, hipStreamSynchronize(s));
+    if (two) {
+        for (int p = 0; p < parts; p++) {
+            ctx->timing.coder_bytes += ptm[p].coder_bytes; ctx->timing.predict_bytes += ptm[p].predict_bytes;
+            ctx->timing.n_coder_launches += ptm[p].n_coder_launches; ctx->timing.n_slot_launches += ptm[p].n_slot_launches;
+        }
+        ctx->timing.coder_bytes += total;
+    }
     if (ctx->opt_timing) {
         if (!two) ctx->timing.generic_ms = elapsed(ctx, 0);
         else {
-            ctx->timing.predict_ms = elapsed(ctx, 0); ctx->timing.coder_ms = elapsed(ctx, 1); ctx->timing.coder_bytes += total;
-            ctx->timing.apm_ms = ps.n_apm ? elapsed(ctx, 4) : 0.f;
-            ctx->timing.slot_ms = ps.has_slot ? elapsed(ctx, 5) : 0.f;
-            ctx->timing.achash_ms = ctx->timing.reserved ? elapsed(ctx, 6) : 0.f;
-            ctx->timing.reserved = 0u;
+            for (int p = 0; p < parts; p++) {   // sums over the ranges (their kernels overlap in time)
+                hipEvent_t *evp = p ? ctx->ranges[p - 1].ev : ctx->ev;
+                const TwoPhaseWs &ws = p ? ctx->ranges[p - 1].ws : ctx->tp;
+                ctx->timing.predict_ms += elapsed_ev(evp, 0); ctx->timing.coder_ms += elapsed_ev(evp, 1);
+                if (ps.n_apm) ctx->timing.apm_ms += elapsed_ev(evp, 4);
+                if (ps.has_slot) ctx->timing.slot_ms += elapsed_ev(evp, 5);
+                if (ws.achash_timed) ctx->timing.achash_ms += elapsed_ev(evp, 6);
+            }
         }
         ctx->timing.pack_ms = elapsed(ctx, 2);
         ctx->timing.total_ms = elapsed(ctx, 3);
     }
+    ctx->timing.n_parts = (uint32_t)parts;
     if (total > out_cap) { ctx->err = "out_cap too small"; return W3_E_NOSPACE; }
     return W3_OK;
 }
