@@ -12,18 +12,20 @@ namespace w3 {
 // Counter  (models/counter.rs:4-26)
 // ---------------------------------------------------------------------------
 // p = round_half_up( 2^17*(c1+1) / (c0+c1+2) ) without a 64-bit divide:
-// f32 reciprocal estimate (|err| < 0.1) + one exact integer correction step.
-// Exact for every reachable Counter state (c0,c1 <= 65535); verified
-// exhaustively on device by tests/test_gpu_primitives.py.
+// p = ((q >> 1) + (q & 1)) with q = floor(2^17 a / d) (counter.rs:10-18)  ==  floor(2^16 a / d + 1/2)  ==  floor((2^17 a + d) / 2d),
+// a = c1 + 1, d = c0 + c1 + 2.  f32 estimate biased low (x + 0.47 with |error| < 0.02: never above the true value, at most
+// one below), then ONE exact integer correction: R = 2^17 a + d - p * 2d lies in [0, 4d); p += R >= 2d.  R is tiny, so
+// mod-2^32 arithmetic is exact, and p < 2^17, 2d < 2^19 keep the product in the full-rate 24-bit multiplier.
+// Exact for every reachable Counter state (c0, c1 <= 65535): verified exhaustively on the device (w3_selftest_counter_p,
+// tests/test_gpu_parity.py::test_counter_p_exhaustive).
 __device__ __forceinline__ uint32_t counter_p(uint32_t c0, uint32_t c1) {
     const uint32_t d = c0 + c1 + 2u;
     const uint32_t a = c1 + 1u;
-    float est = (float)a * 131072.0f * __builtin_amdgcn_rcpf((float)d);
-    uint32_t q = (uint32_t)est;
-    int32_t rem = (int32_t)((a << 17) - q * d);  // true remainder is tiny: mod-2^32 arithmetic is exact
-    if (rem < 0) q -= 1u;
-    else if (rem >= (int32_t)d) q += 1u;
-    return (q + 1u) >> 1;   // (q >> 1) + (q & 1), counter.rs:17
+    const float t = (float)a * __builtin_amdgcn_rcpf((float)d);
+    uint32_t p = (uint32_t)__builtin_fmaf(t, 65536.0f, 0.47f);
+    const uint32_t d2 = d + d;
+    const uint32_t R = ((a << 17) + d) - __umul24(p, d2);
+    return p + (R >= d2 ? 1u : 0u);
 }
 
 // packed counter: low 16 = data[0], high 16 = data[1]

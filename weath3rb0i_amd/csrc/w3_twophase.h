@@ -286,9 +286,11 @@ static inline int twophase_predict(TwoPhaseWs &ws, hipStream_t s, const ParsedSp
             (void)hipMemsetAsync(pa.job_counter, 0, 4, sp);
             if (const char *ev_ = getenv("W3_DEBUG_NOSTORE")) pa.dbg_flags = (uint32_t)atoi(ev_) & 5u;   // timing experiments: results are wrong
             if (!lds_atomics) pa.dbg_flags |= 2u;
-            // ~128 (order 1) / ~192 (order 2) blocks live: their P regions stay in the Infinity Cache.  Measured at 1e9 B
-            // (grid 1024 / 2048 / 3072 / 4096): order 1 26.8 / 19.0 / 23.7 / 27.6 ms, order 2 28.0 / 18.6 / 17.1 / 20.7 ms.
-            uint32_t rank_waves = c == LEAF_WIDE2 ? 3072u : 2048u;
+            // A persistent grid of 2048 wavefronts walks the (block, slice) jobs in block order, so only the blocks in flight
+            // (~32 with 64 slices each, more while a block's largest group is still running) are being scattered into and their
+            // P regions stay in the Infinity Cache.  Measured at 1e9 B, whole predict phase (grid 1024 / 1536 / 2048 / 2560 / 3072 /
+            // 4096): 64.0 / 59.1 / 54.6 / 55.1 / 58.7 / 58.7 ms.
+            uint32_t rank_waves = 2048u;
             if (const char *ev_ = getenv("W3_RANK_GRID")) rank_waves = (uint32_t)std::max(64, atoi(ev_));   // tuning hook
             const uint32_t grid_rank = std::min<uint32_t>(nb * W3_SLICES, rank_waves);
             // an order-2 leaf behind an Order1 leaf starts from that leaf's records (sorted by c1; same stream, so they are ready)
