@@ -308,16 +308,15 @@ static inline int twophase_predict(TwoPhaseWs &ws, hipStream_t s, const ParsedSp
         if (e != hipSuccess) { err = std::string("predict launch: ") + hipGetErrorString(e); return W3_E_HIP; }
     }
     // join, then rank inside the sorted groups (main stream: these kernels want the Infinity Cache to themselves)
-    const bool rank_side = forked && getenv("W3_RANK_SIDE");   // experiment: later leaves' rank kernels stay on the side stream
+    // (measured, no gain: the later leaves' rank kernels on the side stream beside the first one — 35 + 28 ms together against
+    // 17.7 + 15.8 ms one after the other: they saturate the same scattered-store path — and the time-ordered leaves last)
     for (int w = 0; w < n_def; w++) {
-        hipStream_t sr = rank_side && w > 0 ? ws.side : s;
-        if (forked && sr == s) (void)hipStreamWaitEvent(s, ws.ev_join[w], 0);   // this leaf's records are sorted (later leaves may still be partitioning)
-        if (deferred[w].cls == LEAF_WIDE1) hipLaunchKernelGGL(w3::k_rank_sorted<1>, dim3(deferred[w].grid_rank), dim3(64), 0, sr, deferred[w].pa);
-        else hipLaunchKernelGGL(w3::k_rank_sorted<2>, dim3(deferred[w].grid_rank), dim3(64), 0, sr, deferred[w].pa);
+        if (forked) (void)hipStreamWaitEvent(s, ws.ev_join[w], 0);   // this leaf's records are sorted (later leaves may still be partitioning)
+        if (deferred[w].cls == LEAF_WIDE1) hipLaunchKernelGGL(w3::k_rank_sorted<1>, dim3(deferred[w].grid_rank), dim3(64), 0, s, deferred[w].pa);
+        else hipLaunchKernelGGL(w3::k_rank_sorted<2>, dim3(deferred[w].grid_rank), dim3(64), 0, s, deferred[w].pa);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) { err = std::string("rank launch: ") + hipGetErrorString(e); return W3_E_HIP; }
     }
-    if (rank_side && n_def > 1) { (void)hipEventRecord(ws.ev_join[0], ws.side); (void)hipStreamWaitEvent(s, ws.ev_join[0], 0); }
     if (sa.n_leaves) {
         // HashMaps in HBM, one per (block, leaf), zeroed per batch of blocks; as many blocks at once as the budget allows
         if (!ws.st) { err = "state table not staged"; return W3_E_HIP; }
