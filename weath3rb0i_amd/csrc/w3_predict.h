@@ -533,6 +533,137 @@ __global__ void __launch_bounds__(64) k_partition(PredictArgs a) {
     }
 }
 
+// ---------------------------------------------------------------------------
+// k_partition8<MODE>: the same stable partition in ONE 8-bit pass per key byte.  256 open output runs per wave would turn
+// every 8-byte record store into its own memory transaction (the reason for the 4-bit passes above), so records go through
+// LDS tiles: a tile of 2048 records is counting-sorted by the digit inside LDS — the slot of a record is ONE returning LDS add
+// on its bin's cursor, stable because the adds are lane-ordered (atomic_round's property, same self-test) and the rounds are
+// issued in time order — and then copied out bin run by bin run, consecutive lanes to consecutive addresses.
+//   MODE 1: records from the input, key c1 (Order1).   MODE 3: records from a.rec_src (sorted by c1), key c2 (order 2 refined).
+// ---------------------------------------------------------------------------
+#define W3_P8_TILE 2048u
+#define W3_P8_ROUNDS (W3_P8_TILE / 64u)
+
+__device__ __forceinline__ void wave_excl_scan_256(uint32_t *cnt, uint32_t *excl, uint32_t *excl2) {
+    // 256 counts, 4 consecutive bins per lane
+    const int lane = threadIdx.x & 63;
+    const uint32_t c0 = cnt[4 * lane], c1 = cnt[4 * lane + 1], c2 = cnt[4 * lane + 2], c3 = cnt[4 * lane + 3];
+    uint32_t tot;
+    const uint32_t base = wave_excl_scan_u32(c0 + c1 + c2 + c3, &tot);
+    excl[4 * lane] = base; excl[4 * lane + 1] = base + c0; excl[4 * lane + 2] = base + c0 + c1; excl[4 * lane + 3] = base + c0 + c1 + c2;
+    if (excl2) { excl2[4 * lane] = base; excl2[4 * lane + 1] = base + c0; excl2[4 * lane + 2] = base + c0 + c1; excl2[4 * lane + 3] = base + c0 + c1 + c2; }
+}
+
+template <int MODE>
+__global__ void __launch_bounds__(64) k_partition8(PredictArgs a) {
+    __shared__ uint2 tile[W3_P8_TILE];
+    __shared__ uint32_t gcur[256], tcnt[256], tstart[256], tcur[256];
+    const int lane = threadIdx.x;
+    constexpr uint32_t KSH = MODE == 1 ? 8u : 16u;   // digit = window byte c1 / c2
+    for (uint32_t b = blockIdx.x; b < a.nblocks; b += gridDim.x) {
+        const uint64_t off = (uint64_t)b * a.block_size;
+        const uint32_t len = (uint32_t)((a.n - off) < a.block_size ? (a.n - off) : a.block_size);
+        const uint8_t *blk = a.in + off;
+        const uint2 *src = MODE == 3 ? a.rec_src + off : nullptr;
+        uint2 *out = a.rec + off;
+        const bool first = off == 0;
+        const uint32_t last = len - 1u;
+        // digit counts of the whole block (order-free: from the input in both modes)
+#pragma unroll
+        for (int k = 0; k < 4; k++) tcnt[k * 64 + lane] = 0u;
+        __builtin_amdgcn_wave_barrier();
+        __asm__ volatile("" ::: "memory");
+        {
+            uint32_t wn[W3_PF];
+#pragma unroll
+            for (int r = 0; r < W3_PF; r++) wn[r] = load_window(blk, min(r * 64u + lane, last), first);
+            for (uint32_t base = 0; base < len; base += 64u * W3_PF) {
+                uint32_t wc[W3_PF];
+#pragma unroll
+                for (int r = 0; r < W3_PF; r++) wc[r] = wn[r];
+#pragma unroll
+                for (int r = 0; r < W3_PF; r++) wn[r] = load_window(blk, min(base + (W3_PF + r) * 64u + lane, last), first);
+#pragma unroll
+                for (int r = 0; r < W3_PF; r++)
+                    if (base + r * 64u + lane < len) __hip_atomic_fetch_add(&tcnt[(wc[r] >> KSH) & 0xFFu], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+        }
+        __asm__ volatile("" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+        wave_excl_scan_256(tcnt, gcur, nullptr);
+        __asm__ volatile("" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+        for (uint32_t t0 = 0; t0 < len; t0 += W3_P8_TILE) {
+            const uint32_t tlen = min(W3_P8_TILE, len - t0);
+            uint2 rec[W3_P8_ROUNDS];
+#pragma unroll
+            for (uint32_t r = 0; r < W3_P8_ROUNDS; r++) {
+                const uint32_t e = min(t0 + r * 64u + lane, last);
+                if constexpr (MODE == 1) rec[r] = make_uint2(e, load_window(blk, e, first)); else rec[r] = src[e];
+            }
+#pragma unroll
+            for (int k = 0; k < 4; k++) tcnt[k * 64 + lane] = 0u;
+            __asm__ volatile("" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (uint32_t r = 0; r < W3_P8_ROUNDS; r++)
+                if (r * 64u + lane < tlen) __hip_atomic_fetch_add(&tcnt[(rec[r].y >> KSH) & 0xFFu], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __asm__ volatile("" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+            wave_excl_scan_256(tcnt, tstart, tcur);
+            __asm__ volatile("" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+            // stable scatter into the tile: rounds in time order, lanes in order inside the returning add
+#pragma unroll
+            for (uint32_t r = 0; r < W3_P8_ROUNDS; r++) {
+                if (r * 64u + lane < tlen) {
+                    const uint32_t slot = __hip_atomic_fetch_add(&tcur[(rec[r].y >> KSH) & 0xFFu], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    tile[slot] = rec[r];
+                }
+            }
+            __asm__ volatile("" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+            // copy out: element k of the sorted tile belongs to bin d at run offset k - tstart[d]
+#pragma unroll
+            for (uint32_t r = 0; r < W3_P8_ROUNDS; r++) {
+                const uint32_t k = r * 64u + lane;
+                if (k < tlen) {
+                    const uint2 rc = tile[k];
+                    const uint32_t d = (rc.y >> KSH) & 0xFFu;
+                    out[gcur[d] + (k - tstart[d])] = rc;
+                }
+            }
+            __asm__ volatile("" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int k = 0; k < 4; k++) gcur[k * 64 + lane] += tcnt[k * 64 + lane];
+            __asm__ volatile("" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+        }
+        __threadfence_block();
+        // slice boundaries: the first group start at or after s*len/W3_SLICES
+        uint32_t *sp = a.splits + (uint64_t)b * (W3_SLICES + 1u);
+        uint32_t prev = 0u;
+        if (lane == 0) { sp[0] = 0u; sp[W3_SLICES] = len; }
+        for (uint32_t sl = 1; sl < W3_SLICES; sl++) {
+            uint32_t start = max((uint32_t)((uint64_t)sl * len / W3_SLICES), prev), found = len;
+            for (uint32_t base = start; base < len; base += 64) {
+                const uint32_t e = base + lane;
+                bool head = false;
+                if (e < len) {
+                    const uint32_t g = MODE == 1 ? ((out[e].y >> 8) & 0xFFu) : ((out[e].y >> 8) & 0xFFFFu);
+                    const uint32_t gp = e ? (MODE == 1 ? ((out[e - 1].y >> 8) & 0xFFu) : ((out[e - 1].y >> 8) & 0xFFFFu)) : 0xFFFFFFFFu;
+                    head = g != gp;
+                }
+                const uint64_t hm = __ballot(head);
+                if (hm) { found = base + (uint32_t)(__ffsll((long long)hm) - 1); break; }
+            }
+            if (lane == 0) sp[sl] = found;
+            prev = found;
+        }
+    }
+}
+
 // k_rank_sorted<NBYTES>: job = (block, slice).  A persistent grid of 2048 wavefronts walks the jobs in
 // block-major order, so only ~2048/W3_SLICES = 128 blocks are being scattered into at any time: their
 // P regions (1 MiB each) then stay in the 256 MiB Infinity Cache, where the eight partial 16-byte

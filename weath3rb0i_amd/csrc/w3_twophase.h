@@ -296,7 +296,11 @@ static inline int twophase_predict(TwoPhaseWs &ws, hipStream_t s, const ParsedSp
             // an order-2 leaf behind an Order1 leaf starts from that leaf's records (sorted by c1; same stream, so they are ready)
             const bool chained = c == LEAF_WIDE2 && ws.wide1_slot >= 0 && !getenv("W3_NO_CHAINED_PARTITION");
             if (chained) pa.rec_src = (const uint2 *)ws.rec_w[ws.wide1_slot];
-            if (c == LEAF_WIDE1) hipLaunchKernelGGL(w3::k_partition<1>, dim3(grid_wide), dim3(64), 0, sp, pa);
+            // one 8-bit pass through LDS tiles (k_partition8) needs the lane-ordered LDS adds; otherwise 4-bit passes
+            const bool p8 = lds_atomics && !getenv("W3_PARTITION4");
+            if (c == LEAF_WIDE1 && p8) hipLaunchKernelGGL(w3::k_partition8<1>, dim3(grid_wide), dim3(64), 0, sp, pa);
+            else if (chained && p8) hipLaunchKernelGGL(w3::k_partition8<3>, dim3(grid_wide), dim3(64), 0, sp, pa);
+            else if (c == LEAF_WIDE1) hipLaunchKernelGGL(w3::k_partition<1>, dim3(grid_wide), dim3(64), 0, sp, pa);
             else if (chained) hipLaunchKernelGGL(w3::k_partition<3>, dim3(grid_wide), dim3(64), 0, sp, pa);
             else hipLaunchKernelGGL(w3::k_partition<2>, dim3(grid_wide), dim3(64), 0, sp, pa);
             if (forked) (void)hipEventRecord(ws.ev_join[n_def], ws.side);
