@@ -33,6 +33,8 @@
 
 namespace w3 {
 
+#define W3_PF 8   // rounds whose loads are in flight together (one batch)
+
 struct PredictArgs {
     const uint8_t *in;      // original bytes (device)
     uint64_t n;
@@ -41,6 +43,8 @@ struct PredictArgs {
     const uint2 *keys;      // [n] 8 x u8 precomputed keys per byte (k_achash) or null
     uint32_t *perm;         // partition: per-wave scratch, 2 * block_size records
     uint2 *rec;             // [n] sorted records (position, window bytes) of every block
+    uint4 *sink;            // 64 x 16 B nobody reads: stores of predicated-off lanes go here, so that every round issues the same
+                            // memory operations and hipcc can count them (a branch around a store costs s_waitcnt vmcnt(0) per round)
     const uint2 *rec_src;   // k_partition<3>: [n] records already sorted by c1 (an Order1 leaf's a.rec), else null
     uint32_t *splits;       // [nblocks][W3_SLICES + 1] slice boundaries inside each block's sorted range
     uint32_t *job_counter;  // k_rank_sorted: next job (zeroed before the launch)
@@ -282,6 +286,8 @@ __device__ __forceinline__ uint32_t load_window(const uint8_t *blk, uint32_t i, 
 template <int H, bool KEYS>
 __global__ void __launch_bounds__(64) k_predict_small(PredictArgs a) {
     __shared__ uint32_t tbl[8 * 256];
+    __shared__ uint32_t st_w[W3_PF * 64];                 // operand staging (one batch of rounds)
+    __shared__ uint2 st_k[KEYS ? W3_PF * 64 : 1];
     const int lane = threadIdx.x;
     constexpr uint32_t KM = (1u << H) - 1u;
     for (uint32_t b = blockIdx.x; b < a.nblocks; b += gridDim.x) {
@@ -292,22 +298,39 @@ __global__ void __launch_bounds__(64) k_predict_small(PredictArgs a) {
         for (int k = 0; k < 32; k++) tbl[k * 64 + lane] = 0u;
         __builtin_amdgcn_wave_barrier();
         bool exact = (a.dbg_flags & 2u) != 0u;   // ballot rounds (LDS-atomic order self-test failed, or a count nears 65535)
-        // operands of round r+1 are loaded while round r is ranked; every load is unconditional (index clamped)
+        // Operands travel in batches of W3_PF rounds: the loads of batch k+1 are issued at the start of batch k (unconditional,
+        // index clamped) and parked in LDS at its end, and the rounds read them from LDS.  That keeps loads and stores from being
+        // in flight together inside a batch: with both pending hipcc waits vmcnt(0)/(1) EVERY round, i.e. for the round's own
+        // 16-byte store to complete (gfx9 counts loads and stores in one counter and LLVM assumes they retire out of order).
         const bool first = off == 0;
         const uint32_t last = len - 1u;
-        uint32_t nw; uint2 nk = make_uint2(0, 0);
-        {
-            const uint32_t ic = min((uint32_t)lane, last);
-            if constexpr (KEYS) { nk = a.keys[off + ic]; nw = blk[ic]; } else nw = load_window(blk, ic, first);
+        uint32_t nw[W3_PF]; uint2 nk[W3_PF];
+#pragma unroll
+        for (int r = 0; r < W3_PF; r++) {
+            const uint32_t ic = min((uint32_t)(r * 64 + lane), last);
+            if constexpr (KEYS) { nk[r] = a.keys[off + ic]; nw[r] = blk[ic]; } else { nw[r] = load_window(blk, ic, first); nk[r] = make_uint2(0, 0); }
         }
-        for (uint32_t base = 0; base < len; base += 64) {
+        for (uint32_t bbase = 0; bbase < len; bbase += 64u * W3_PF) {
+            __asm__ volatile("" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int r = 0; r < W3_PF; r++) { st_w[r * 64 + lane] = nw[r]; if constexpr (KEYS) st_k[r * 64 + lane] = nk[r]; }
+            __asm__ volatile("" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int r = 0; r < W3_PF; r++) {
+                const uint32_t ic = min(bbase + (uint32_t)((W3_PF + r) * 64 + lane), last);
+                if constexpr (KEYS) { nk[r] = a.keys[off + ic]; nw[r] = blk[ic]; } else nw[r] = load_window(blk, ic, first);
+            }
+#pragma unroll 1
+          for (uint32_t rr = 0; rr < W3_PF; rr++) {
+            const uint32_t base = bbase + rr * 64u;
+            if (base >= len) break;
             const uint32_t i = base + lane;
             const bool valid = i < len;
-            const uint32_t w = nw; const uint2 k8 = nk;
-            {
-                const uint32_t ic = min(i + 64u, last);
-                if constexpr (KEYS) { nk = a.keys[off + ic]; nw = blk[ic]; } else nw = load_window(blk, ic, first);
-            }
+            const uint32_t w = st_w[rr * 64u + lane];
+            uint2 k8 = make_uint2(0, 0);
+            if constexpr (KEYS) k8 = st_k[rr * 64u + lane];
             uint32_t c0 = 0, key[8], p[8];
             if constexpr (KEYS) {
                 c0 = valid ? w : 0u;
@@ -335,7 +358,11 @@ __global__ void __launch_bounds__(64) k_predict_small(PredictArgs a) {
                 uint32_t fin[8], wm;
                 rank_round<false>(c0, key, M, seg, valid, true, tbl, p, fin, wm);
             }
-            if (valid) a.P[off + i] = pack_p(p);
+            {
+                uint4 *dst = valid ? a.P + (off + i) : a.sink + lane;   // unconditional store (see PredictArgs::sink)
+                *dst = pack_p(p);
+            }
+          }
         }
     }
 }
@@ -359,7 +386,6 @@ __device__ __forceinline__ uint32_t wave_excl_scan_u32(uint32_t v, uint32_t *tot
 // 16 bins keep only 16 open output lines per wave, so the scattered position writes merge
 // into full lines in L2 (256 bins x 4096 waves overflowed the L2s: every 4-byte store became
 // its own HBM transaction).  hist[pass][16] is filled in ONE time-ordered sweep up front.
-#define W3_PF 8   // rounds whose loads are in flight together in the short-round loops
 
 template <int NPASS, bool C2ONLY = false>
 __device__ __forceinline__ void partition_hist(const uint8_t *blk, uint32_t len, bool first, uint32_t *hist) {
@@ -568,24 +594,45 @@ __global__ void __launch_bounds__(64) k_partition8(PredictArgs a) {
         uint2 *out = a.rec + off;
         const bool first = off == 0;
         const uint32_t last = len - 1u;
-        // digit counts of the whole block (order-free: from the input in both modes)
+        // digit counts of the whole block.  digit(pos) = byte[pos - K] (K = 1: c1, 2: c2; zeros before the block start), so
+        // this is the byte histogram of bytes [0, len - K) plus K zeros: 16 input bytes per lane and load
+        constexpr uint32_t K = MODE == 1 ? 1u : 2u;
 #pragma unroll
         for (int k = 0; k < 4; k++) tcnt[k * 64 + lane] = 0u;
         __builtin_amdgcn_wave_barrier();
         __asm__ volatile("" ::: "memory");
         {
-            uint32_t wn[W3_PF];
+            const uint32_t nbytes = len > K ? len - K : 0u;
+            if (lane == 0) tcnt[0] = min(K, len);
+            __builtin_amdgcn_wave_barrier();
+            __asm__ volatile("" ::: "memory");
+            if (len >= 16u) {
+                const uint32_t cs_max = len - 16u;   // chunks are clamped into the block; bytes before the chunk's own start are skipped
+                constexpr int HP = 4;
+                uint4 qn[HP];
 #pragma unroll
-            for (int r = 0; r < W3_PF; r++) wn[r] = load_window(blk, min(r * 64u + lane, last), first);
-            for (uint32_t base = 0; base < len; base += 64u * W3_PF) {
-                uint32_t wc[W3_PF];
+                for (int r = 0; r < HP; r++) __builtin_memcpy(&qn[r], blk + min((uint32_t)(r * 1024 + lane * 16), cs_max), 16);
+                for (uint32_t base = 0; base < nbytes; base += 1024u * HP) {
+                    uint4 qc[HP];
 #pragma unroll
-                for (int r = 0; r < W3_PF; r++) wc[r] = wn[r];
+                    for (int r = 0; r < HP; r++) qc[r] = qn[r];
 #pragma unroll
-                for (int r = 0; r < W3_PF; r++) wn[r] = load_window(blk, min(base + (W3_PF + r) * 64u + lane, last), first);
+                    for (int r = 0; r < HP; r++) __builtin_memcpy(&qn[r], blk + min(base + (uint32_t)((HP + r) * 1024 + lane * 16), cs_max), 16);
 #pragma unroll
-                for (int r = 0; r < W3_PF; r++)
-                    if (base + r * 64u + lane < len) __hip_atomic_fetch_add(&tcnt[(wc[r] >> KSH) & 0xFFu], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    for (int r = 0; r < HP; r++) {
+                        const uint32_t want = base + (uint32_t)(r * 1024 + lane * 16), cs = min(want, cs_max);
+                        const uint32_t w4[4] = {qc[r].x, qc[r].y, qc[r].z, qc[r].w};
+#pragma unroll
+                        for (int q = 0; q < 16; q++) {
+                            const uint32_t pos = cs + (uint32_t)q;
+                            if (pos >= want && pos < nbytes)
+                                __hip_atomic_fetch_add(&tcnt[(w4[q >> 2] >> (8 * (q & 3))) & 0xFFu], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        }
+                    }
+                }
+            } else {
+                for (uint32_t pos = lane; pos < nbytes; pos += 64u)
+                    __hip_atomic_fetch_add(&tcnt[blk[pos]], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
         }
         __asm__ volatile("" ::: "memory");
@@ -672,6 +719,7 @@ __global__ void __launch_bounds__(64) k_partition8(PredictArgs a) {
 template <int NBYTES>
 __global__ void __launch_bounds__(64) k_rank_sorted(PredictArgs a) {
     __shared__ uint32_t tbl[8 * 256];
+    __shared__ uint2 st_r[W3_PF * 64];   // record staging (one batch of rounds)
     const int lane = threadIdx.x;
     const uint32_t njobs = a.nblocks * W3_SLICES;
     // jobs are handed out in block-major order from one counter: slices are very uneven (a block's biggest
@@ -697,15 +745,28 @@ __global__ void __launch_bounds__(64) k_rank_sorted(PredictArgs a) {
         bool exact = (a.dbg_flags & 2u) != 0u;   // ballot rounds only (see atomic_round)
         bool dirty = false;              // table holds states of group open_g
         uint32_t open_g = 0xFFFFFFFFu;   // group the table describes (also: group of the previous round's last element)
-        // software pipeline: the record of round r+1 is loaded while round r is ranked
+        // records travel in batches of W3_PF rounds through LDS (see k_predict_small: no load is in flight beside the stores)
         const uint32_t last = len - 1u;
-        uint2 r_n = perm[min((uint32_t)lane, last)], r_nn = perm[min((uint32_t)lane + 64u, last)];
-        for (uint32_t base = 0; base < len; base += 64) {
+        uint2 rn[W3_PF];
+#pragma unroll
+        for (int r = 0; r < W3_PF; r++) rn[r] = perm[min((uint32_t)(r * 64 + lane), last)];
+        for (uint32_t bbase = 0; bbase < len; bbase += 64u * W3_PF) {
+            __asm__ volatile("" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int r = 0; r < W3_PF; r++) st_r[r * 64 + lane] = rn[r];
+            __asm__ volatile("" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int r = 0; r < W3_PF; r++) rn[r] = perm[min(bbase + (uint32_t)((W3_PF + r) * 64 + lane), last)];
+#pragma unroll 1
+          for (uint32_t rr = 0; rr < W3_PF; rr++) {
+            const uint32_t base = bbase + rr * 64u;
+            if (base >= len) break;
             const uint32_t e = base + lane;
             const bool valid = e < len;
-            const uint32_t i = r_n.x; const uint32_t w = valid ? r_n.y : 0u;
-            r_n = r_nn;
-            r_nn = perm[min(e + 128u, last)];
+            const uint2 r_c = st_r[rr * 64u + lane];
+            const uint32_t i = r_c.x; const uint32_t w = valid ? r_c.y : 0u;
             const uint32_t c0 = w & 0xFFu;
             // group id and the byte that supplies the low key bits
             const uint32_t g = NBYTES == 1 ? ((w >> 8) & 0xFFu) : ((w >> 8) & 0xFFFFu);
@@ -787,7 +848,11 @@ __global__ void __launch_bounds__(64) k_rank_sorted(PredictArgs a) {
             }
             dirty = true;
             open_g = g_last;
-            if (valid && !(a.dbg_flags & 1u)) a.P[off + ((a.dbg_flags & 4u) ? (i & 0xFFFu) : i)] = pack_p(p);  // 16-byte scatter, write-only
+            {   // 16-byte scatter, write-only; unconditional (see PredictArgs::sink)
+                uint4 *dst = (valid && !(a.dbg_flags & 1u)) ? a.P + (off + ((a.dbg_flags & 4u) ? (i & 0xFFFu) : i)) : a.sink + lane;
+                *dst = pack_p(p);
+            }
+          }
         }
         W3_STAMP(3);
         if (a.dbg && lane == 0 && sl == 0) atomicAdd(&a.dbg[7], 1ull);

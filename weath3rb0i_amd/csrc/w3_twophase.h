@@ -215,6 +215,7 @@ static inline int twophase_predict(TwoPhaseWs &ws, hipStream_t s, const ParsedSp
     if (n_live > 1 && (rc = tp_ensure(ws.streams, ws.streams_cap, (size_t)n_live * n * 16, err))) return rc;
     if (n_live <= 1 && (rc = tp_ensure(ws.P, ws.P_cap, n * 16, err))) return rc;
 
+    if ((rc = tp_ensure(ws.dummy, ws.dummy_cap, 2048, err))) return rc;
     if (ev) (void)hipEventRecord(ev[0], s);
     // fork: the partition passes of the wide leaves go to the side stream (they are bound by scattered line requests, the
     // time-ordered kernels by VALU issue); the rank kernels follow on the main stream after the join
@@ -252,6 +253,7 @@ static inline int twophase_predict(TwoPhaseWs &ws, hipStream_t s, const ParsedSp
             continue;
         }
         pa.hbits = nd.bits - 3;
+        pa.sink = (uint4 *)ws.dummy;
         pa.maxseg = W3_ATOMIC_MAXSEG;
         if (const char *ev_ = getenv("W3_ATOMIC_MAXSEG")) pa.maxseg = (uint32_t)std::max(0, atoi(ev_));   // tuning hook
         if (!lds_atomics) pa.dbg_flags |= 2u;
