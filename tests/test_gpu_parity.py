@@ -125,6 +125,22 @@ def test_order2_partition_chained_and_from_scratch(ctx, oracle, monkeypatch):
         check_blocks(ctx, oracle, name, data, 65536, "twophase")
     monkeypatch.setenv("W3_NO_CHAINED_PARTITION", "1")
     check_blocks(ctx, oracle, "best012", data, 65536, "twophase")
+    monkeypatch.delenv("W3_NO_CHAINED_PARTITION")
+    monkeypatch.setenv("W3_PARTITION4", "1")                     # 4-bit LSD passes (k_partition<1>, <3>) instead of k_partition8
+    check_blocks(ctx, oracle, "best012", data, 65536, "twophase")
+
+
+def test_ballot_rounds_without_lds_atomics(oracle, monkeypatch):
+    """A device that fails the lane-order self-test of returning LDS adds (forced with the hook; the result is cached per
+    context, hence a fresh one) runs the ballot rounds and the 4-bit partition passes everywhere: same streams."""
+    monkeypatch.setenv("W3_NO_LDS_ATOMICS", "1")
+    c = w3.Context(0)
+    try:
+        data = markov_text(150000, seed=22) + bytes(66000) + lcg_text(9000, seed=5)
+        for name in ("order0", "best012", "main_default", "best_ac_wide"):
+            check_blocks(c, oracle, name, data, 65536, "twophase")
+    finally:
+        c.close()
 
 
 @pytest.mark.parametrize("parts", [2, 3, 4])
