@@ -1,0 +1,80 @@
+"""OrderN parameter sweep on the device — the reference's research driver `src/bin/ordern/main.rs:9-58`.
+
+The reference runs `OrderN::new(ctx_bits, alignment_bits)` over one file for ctx_bits 8..=30 x alignment_bits 0..=4,
+three times each, prints `[ordern] [ctx: B, align: A] csize: N (ratio: r), ctime: t (t/bit per bit)` for the fastest run
+and tracks the best parameters per ctx_bits and overall (`best`/`params`, levels = 2).  Here every configuration is one
+`w3_encode_blocks_device` call on the block container: csize = the sum of the block streams, each of
+which is the reference's stream for that block alone — so the figures are those of the reference run per block, not of
+its single whole-file stream.  Same line format, same tie rule (a later configuration replaces the best on equality,
+`main.rs:21-26`: `if res > best[i] { continue }`).
+"""
+import sys
+import time
+
+from . import models
+
+
+def exec_one(ctx, data, block_size, ctx_bits, alignment_bits, repeats=3, out=print):
+    """`exec` (`bin/ordern/main.rs:42-66`): fastest of `repeats` runs; returns (csize, seconds)."""
+    model = models.OrderN(ctx_bits, alignment_bits)
+    best = None
+    for _ in range(repeats):
+        t0 = time.perf_counter()
+        _, lens = ctx.encode_blocks(model, data, block_size)
+        dt = time.perf_counter() - t0
+        res = int(lens.sum())
+        if best is None or dt < best[1]:
+            best = (res, dt)
+    res, dt = best
+    nbits = max(1, len(data) * 8)
+    out("[ordern] [ctx: %2d, align: %d] csize: %d (ratio: %.3f), ctime: %.3fms (%.3fns per bit)"
+        % (ctx_bits, alignment_bits, res, res / max(1, len(data)), dt * 1e3, dt * 1e9 / nbits))
+    return res, dt
+
+
+def sweep_ordern(ctx, data, block_size=65536, ctx_bits=range(8, 31), alignment_bits=range(0, 5), repeats=3, out=print):
+    """`main` (`bin/ordern/main.rs:9-40`).  Returns (global best csize, (ctx_bits, alignment_bits), {(B, A): csize})."""
+    levels = 2
+    best = [len(data)] * levels
+    params = [(0, 0)] * levels
+    table = {}
+    for b in ctx_bits:
+        best[1] = len(data)
+        params[1] = (0, 0)
+        for a in alignment_bits:
+            if a > b:          # OrderN needs alignment_bits <= bits_in_context (the crate would underflow `bits - align`)
+                continue
+            res, _ = exec_one(ctx, data, block_size, b, a, repeats, out)
+            table[(b, a)] = res
+            for i in range(levels):
+                if res > best[i]:
+                    continue
+                best[i] = res
+                params[i] = (b, a)
+        out("-> best: %d for [ctx: %d, align: %d]" % (best[1], params[1][0], params[1][1]))
+    out("-> gloabl best: %d for [ctx: %d, align: %d]" % (best[0], params[0][0], params[0][1]))   # (sic, main.rs:35)
+    return best[0], params[0], table
+
+
+def main(argv=None):
+    import argparse
+    from .api import Context
+    ap = argparse.ArgumentParser(description="OrderN (ctx_bits, alignment_bits) sweep on the GPU, block container")
+    ap.add_argument("path")
+    ap.add_argument("--block-size", type=int, default=65536)
+    ap.add_argument("--ctx-bits", default="8:30", help="lo:hi inclusive")
+    ap.add_argument("--align-bits", default="0:4", help="lo:hi inclusive")
+    ap.add_argument("--repeats", type=int, default=3)
+    args = ap.parse_args(argv)
+    data = open(args.path, "rb").read()
+    lo, hi = (int(x) for x in args.ctx_bits.split(":"))
+    alo, ahi = (int(x) for x in args.align_bits.split(":"))
+    ctx = Context(0)
+    try:
+        sweep_ordern(ctx, data, args.block_size, range(lo, hi + 1), range(alo, ahi + 1), args.repeats)
+    finally:
+        ctx.close()
+
+
+if __name__ == "__main__":
+    sys.exit(main())
