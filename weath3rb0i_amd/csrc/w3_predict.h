@@ -382,7 +382,8 @@ __device__ __forceinline__ uint32_t wave_excl_scan_u32(uint32_t v, uint32_t *tot
     return inc - v;
 }
 
-// Stable LSD partition of the block's positions by the previous byte(s), 4 bits per pass.
+// (Fallback when the LDS-add lane order is not available, and for an order-2 leaf with no Order1 leaf ahead of it; the default
+// is k_partition8 below.)  Stable LSD partition of the block's positions by the previous byte(s), 4 bits per pass.
 // 16 bins keep only 16 open output lines per wave, so the scattered position writes merge
 // into full lines in L2 (256 bins x 4096 waves overflowed the L2s: every 4-byte store became
 // its own HBM transaction).  hist[pass][16] is filled in ONE time-ordered sweep up front.
@@ -712,7 +713,8 @@ __global__ void __launch_bounds__(64) k_partition8(PredictArgs a) {
 }
 
 // k_rank_sorted<NBYTES>: job = (block, slice).  A persistent grid of 2048 wavefronts walks the jobs in
-// block-major order, so only ~2048/W3_SLICES = 128 blocks are being scattered into at any time: their
+// block-major order, so only ~2048/W3_SLICES = 32 blocks (more while a block's largest group is still running) are being
+// scattered into at any time: their
 // P regions (1 MiB each) then stay in the 256 MiB Infinity Cache, where the eight partial 16-byte
 // writes every 128-byte line receives merge (3.2x cheaper than with 4096 blocks live; see
 // profiles/r1_ubench_partial_line_merge_vs_footprint.txt).
