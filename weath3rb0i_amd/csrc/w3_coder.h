@@ -207,6 +207,9 @@ __global__ void __launch_bounds__(64) k_coder_fast(CoderArgs a) {
 // ---------------------------------------------------------------------------
 #define W3_X2_RING 16u          // ring depth in input bytes (power of two, two halves of 8)
 #define W3_X2_SPIN_LIMIT (1u << 24)
+#ifndef W3_X3_LAZY
+#define W3_X3_LAZY 8            // s_sleep units between polls of the mix / output waves of k_coder_x3
+#endif
 
 __device__ __forceinline__ uint32_t lds_load_u32(const volatile uint32_t *p) {
     return __hip_atomic_load(const_cast<const uint32_t *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -394,10 +397,14 @@ struct Coder3Args {
     uint32_t acc_limit;
 };
 
+// SLEEP: s_sleep units (64 clocks) between polls.  The recurrence wave polls eagerly (it is the critical path); the mix and
+// output waves wait for it half a ring (8 bytes = 64 steps, ~9,000 clocks) at a time, and their polls are LDS reads that
+// queue up in front of the recurrence wave's ring accesses: at s_sleep 1 they were 3x its own LDS traffic.
+template <int SLEEP = 1>
 __device__ __forceinline__ uint32_t spin_until_ge(const volatile uint32_t *ctr, uint32_t need, volatile uint32_t *abortf, bool &dead) {
     uint32_t v = lds_load_u32(ctr), spins = 0;
     while (v < need) {
-        __builtin_amdgcn_s_sleep(1);
+        __builtin_amdgcn_s_sleep(SLEEP);
         if (++spins > W3_X2_SPIN_LIMIT || lds_load_u32(abortf)) { lds_store_u32(abortf, 1u); dead = true; break; }
         v = lds_load_u32(ctr);
     }
@@ -439,7 +446,7 @@ __global__ void __launch_bounds__(192) k_coder_x3(Coder3Args a) {
         uint32_t seen = 0;   // last value read from x_cons
         for (uint32_t i = 0; i < maxlen && !dead; i += 4) {
             if ((i & 7u) == 0u && i + 8u > seen + W3_X2_RING) {   // ring slots of bytes [i, i+8) must have been consumed
-                seen = spin_until_ge(x_cons, i + 8u - W3_X2_RING, abortf, dead);
+                seen = spin_until_ge<W3_X3_LAZY>(x_cons, i + 8u - W3_X2_RING, abortf, dead);
                 if (dead) break;
             }
             uint4 cur[L][4]; uint32_t cb[4];
@@ -571,7 +578,7 @@ __global__ void __launch_bounds__(192) k_coder_x3(Coder3Args a) {
     uint32_t seen_x = 0;
     for (uint32_t i = 0; i < maxlen && !dead; i += 8) {
         const uint32_t need = min(i + 8u, maxlen);
-        if (seen_x < need) { seen_x = spin_until_ge(x_prod, need, abortf, dead); if (dead) break; }
+        if (seen_x < need) { seen_x = spin_until_ge<W3_X3_LAZY>(x_prod, need, abortf, dead); if (dead) break; }
         __asm__ volatile("" ::: "memory");
 #pragma unroll 1
         for (uint32_t k = 0; k < 8u; k++) {
