@@ -94,6 +94,7 @@ def main():
     ap.add_argument("--block-size", type=int, default=65536)
     ap.add_argument("--path", default="auto", help="auto | generic | twophase")
     ap.add_argument("--parts", type=int, default=0, help="block ranges pipelined inside one encode call (W3_OPT_PARTS): 0 = auto, 1..4")
+    ap.add_argument("--coder", default="x4", help="two-phase coder kernel: x4 (default) | x3 | x2 | fast | robust")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--force-exchange", action="store_true", help="run the RCCL exchange step even with 1 rank (rehearsal)")
@@ -127,6 +128,7 @@ def main():
     ctx = w3.Context(local_rank)
     ctx.set_path(args.path)
     ctx.set_parts(args.parts)
+    ctx.set_coder(args.coder)
 
     # rank r owns chunks [r*chunks, (r+1)*chunks) of one global seeded stream (weak scaling: n bytes per GPU)
     chunks_per_rank = (n + (1 << 20) - 1) >> 20

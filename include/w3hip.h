@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define W3_ABI_VERSION 4
+#define W3_ABI_VERSION 5
 
 /* ---- error codes --------------------------------------------------------- */
 enum {
@@ -34,7 +34,8 @@ enum {
     W3_E_HIP         = -3,  /* HIP runtime error (w3_last_error has the text)         */
     W3_E_UNSUPPORTED = -4,  /* valid spec the device path does not implement          */
     W3_E_NOMEM       = -5,  /* device workspace does not fit                          */
-    W3_E_FORMAT      = -6   /* bad container magic (main.rs:123-124 assert_eq!)       */
+    W3_E_FORMAT      = -6   /* bad container magic (main.rs:123-124 assert_eq!) or a block length table that
+                               claims more compressed bytes than the input buffer holds */
 };
 
 /* ---- model spec ----------------------------------------------------------
@@ -106,12 +107,15 @@ int         w3_spec_validate(const w3_model_spec *spec);
 enum {
     W3_OPT_PATH   = 1,  /* W3_PATH_*: which device implementation encode uses      */
     W3_OPT_TIMING = 2,  /* 1 = record per-kernel hipEvent timings (w3_get_timing) */
-    W3_OPT_CODER  = 3,  /* two-phase coder kernel: 0 = k_coder_x3 (default), 1 = k_coder_fast, 2 = robust k_coder only, 3 = k_coder_x2 */
+    W3_OPT_CODER  = 3,  /* two-phase coder kernel: 0 = k_coder_x4 (default), 1 = k_coder_fast, 2 = robust k_coder only, 3 = k_coder_x2, 4 = k_coder_x3 */
     W3_OPT_ACC_LIMIT = 4, /* test hook (19..46): accumulator fill at which the fast coder hands a block back */
     W3_OPT_DEBUG_STAMPS = 5, /* diagnostic: 1 = the partitioned predict kernel sums s_memtime per phase */
-    W3_OPT_PARTS = 6    /* two-phase encode: block ranges pipelined on separate streams inside one call (the coder and APM
-                           kernels of one range beside the predict kernels of the next); 0/1 = one range (default), 2..4.
-                           Output is identical; measured no faster on MI355X */
+    W3_OPT_PARTS = 6,   /* EXPERIMENTAL, not part of the stable surface: block ranges of one call pipelined on separate streams;
+                           0/1 = one range (default), 2..4.  Output is identical; measured no faster on MI355X */
+    W3_OPT_VARIANT = 7, /* cross-check hook for the tests: bit mask of alternative, bit-exact implementations — 1 = Counter rounds
+                           with ballots instead of returning LDS adds, 2 = 4-bit partition passes, 4 = order-2 partition from
+                           scratch, 8 = CM decoder without LDS staging, 16 = no side stream.  0 = defaults */
+    W3_OPT_SLOT_BUDGET_MB = 8 /* cap (MiB) on the device memory one batch of slot-state hash maps may take; 0 = derive from free memory */
 };
 enum { W3_PATH_AUTO = 0, W3_PATH_GENERIC = 1, W3_PATH_TWOPHASE = 2 };
 int         w3_ctx_set_option(w3_ctx *ctx, int opt, int64_t value);
@@ -130,14 +134,18 @@ int w3_encode_blocks(w3_ctx *ctx, const w3_model_spec *spec,
                      const uint8_t *in, size_t n, size_t block_size,
                      uint8_t *out, size_t out_cap, size_t *out_len, uint32_t *block_lens);
 
+/* in_len = bytes readable at `in`; a length table whose sum exceeds it is rejected with W3_E_FORMAT before
+ * anything is read (the reference reads through ACReader, which cannot run past its file: io.rs:23-26). */
 int w3_decode_blocks(w3_ctx *ctx, const w3_model_spec *spec,
-                     const uint8_t *in, const uint32_t *block_lens, size_t nblocks,
+                     const uint8_t *in, size_t in_len, const uint32_t *block_lens, size_t nblocks,
                      size_t block_size, uint64_t orig_len, uint8_t *out);
 
 /* ---- same, device-resident (no PCIe in the call) ---------------------------
- * d_* are device pointers on ctx's GPU.  `stream` is a hipStream_t (NULL =
- * the ctx's own stream); the call only enqueues work and reads back one
- * status word, so it can be timed with events on that stream.
+ * d_* are device pointers on ctx's GPU.  `stream` is a hipStream_t; NULL = the
+ * ctx's own stream, an ordinary blocking stream, i.e. ordered against work on
+ * the legacy default stream like the default stream itself.  The call only
+ * enqueues work and reads back one status word, so it can be timed with events
+ * on that stream.
  * d_block_lens[nblocks] u32, d_total[1] u64.                                  */
 int w3_encode_blocks_device(w3_ctx *ctx, const w3_model_spec *spec,
                             const uint8_t *d_in, size_t n, size_t block_size,
@@ -145,7 +153,7 @@ int w3_encode_blocks_device(w3_ctx *ctx, const w3_model_spec *spec,
                             uint32_t *d_block_lens, uint64_t *d_total, void *stream);
 
 int w3_decode_blocks_device(w3_ctx *ctx, const w3_model_spec *spec,
-                            const uint8_t *d_in, const uint32_t *d_block_lens, size_t nblocks,
+                            const uint8_t *d_in, size_t in_len, const uint32_t *d_block_lens, size_t nblocks,
                             size_t block_size, uint64_t orig_len, uint8_t *d_out, void *stream);
 
 /* ---- the reference's whole-file container ----------------------------------

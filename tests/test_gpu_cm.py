@@ -172,20 +172,21 @@ def test_apm_robust_coder_handback(ctx, oracle):
     assert lens.tolist() == wlens.tolist() and out.tobytes() == want.tobytes()
 
 
-def test_slot_tables_in_batches(ctx, oracle, monkeypatch):
+def test_slot_tables_in_batches(ctx, oracle):
     """When the hash maps of all blocks do not fit the device budget, k_slot runs in equal batches of blocks
     (tables zero-filled per batch); forced here with the tuning hook."""
     data = markov_text(130 * 512 + 77, seed=14)
-    monkeypatch.setenv("W3_SLOT_BUDGET_MB", "40")     # slot2: 2^12 cells x 128 B = 512 KiB per block -> 64 blocks per batch
-    check(ctx, oracle, "slot2", data, 512, decode=False)
-    assert ctx.timing()["path"] == 1                   # (check() ends on its k_cm cross-check)
-    dev, _ = pair(oracle, "slot2")
-    ctx.set_timing(True)
+    ctx.set_slot_budget_mb(40)                         # slot2: 2^12 cells x 128 B = 512 KiB per block -> 64 blocks per batch
     try:
+        check(ctx, oracle, "slot2", data, 512, decode=False)
+        assert ctx.timing()["path"] == 1                   # (check() ends on its k_cm cross-check)
+        dev, _ = pair(oracle, "slot2")
+        ctx.set_timing(True)
         ctx.encode_blocks(dev(), data, 512)
         assert ctx.timing()["n_slot_launches"] == 3
     finally:
         ctx.set_timing(False)
+        ctx.set_slot_budget_mb(0)
 
 
 def test_apm_models_in_block_ranges(ctx, oracle):
@@ -202,12 +203,15 @@ def test_apm_models_in_block_ranges(ctx, oracle):
         ctx.set_parts(0)
 
 
-def test_cm_unstaged_kernel_still_agrees(ctx, oracle, monkeypatch):
+def test_cm_unstaged_kernel_still_agrees(ctx, oracle):
     """k_cm (cells in global memory, used beyond 8 slot leaves) against k_cm_staged and the oracle."""
     data = markov_text(20000, seed=15) + mixed_bytes(6000, seed=16)
-    monkeypatch.setenv("W3_CM_UNSTAGED", "1")
-    for name in ("slot_mix", "full_cm_small_tables"):
-        check(ctx, oracle, name, data, 4096)
+    ctx.set_variant("cm_unstaged")
+    try:
+        for name in ("slot_mix", "full_cm_small_tables"):
+            check(ctx, oracle, name, data, 4096)
+    finally:
+        ctx.set_variant()
 
 
 def test_cm_reference_container(ctx, oracle):

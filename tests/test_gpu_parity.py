@@ -117,24 +117,28 @@ def test_twophase_path_models(ctx, oracle, name):
     assert np.array_equal(p, want)
 
 
-def test_order2_partition_chained_and_from_scratch(ctx, oracle, monkeypatch):
+def test_order2_partition_chained_and_from_scratch(ctx, oracle):
     """An order-2 leaf behind an Order1 leaf refines that leaf's c1-sorted records (k_partition<3>, two passes); alone,
     ahead of the Order1 leaf, or with the hook set it sorts from scratch (k_partition<2>, four passes).  Same streams."""
     data = markov_text(150000, seed=21) + bytes(70000) + lcg_text(30001, seed=4)
     for name in ("best012", "best_ac_wide", "order2"):
         check_blocks(ctx, oracle, name, data, 65536, "twophase")
-    monkeypatch.setenv("W3_NO_CHAINED_PARTITION", "1")
-    check_blocks(ctx, oracle, "best012", data, 65536, "twophase")
-    monkeypatch.delenv("W3_NO_CHAINED_PARTITION")
-    monkeypatch.setenv("W3_PARTITION4", "1")                     # 4-bit LSD passes (k_partition<1>, <3>) instead of k_partition8
-    check_blocks(ctx, oracle, "best012", data, 65536, "twophase")
+    try:
+        ctx.set_variant("no_chained_partition")
+        check_blocks(ctx, oracle, "best012", data, 65536, "twophase")
+        ctx.set_variant("partition4")                            # 4-bit LSD passes (k_partition<1>, <3>) instead of k_partition8
+        check_blocks(ctx, oracle, "best012", data, 65536, "twophase")
+        ctx.set_variant("no_side_stream")
+        check_blocks(ctx, oracle, "best012", data, 65536, "twophase")
+    finally:
+        ctx.set_variant()
 
 
-def test_ballot_rounds_without_lds_atomics(oracle, monkeypatch):
-    """A device that fails the lane-order self-test of returning LDS adds (forced with the hook; the result is cached per
-    context, hence a fresh one) runs the ballot rounds and the 4-bit partition passes everywhere: same streams."""
-    monkeypatch.setenv("W3_NO_LDS_ATOMICS", "1")
+def test_ballot_rounds_without_lds_atomics(oracle):
+    """A device that fails the lane-order self-test of returning LDS adds (forced with W3_OPT_VARIANT) runs the ballot
+    rounds and the 4-bit partition passes everywhere: same streams."""
     c = w3.Context(0)
+    c.set_variant("no_lds_atomics")
     try:
         data = markov_text(150000, seed=22) + bytes(66000) + lcg_text(9000, seed=5)
         for name in ("order0", "best012", "main_default", "best_ac_wide"):
@@ -205,12 +209,12 @@ def test_coder_variants_and_fallback(ctx, oracle):
     model = w3.BestOfTwoModel(w3.Order0(), w3.Order1())
     ctx.set_path("twophase")
     try:
-        for mode in ("x3", "x2", "fast", "robust"):
+        for mode in ("x4", "x3", "x2", "fast", "robust"):
             ctx.set_coder(mode)
             out, lens = ctx.encode_blocks(model, data, 8192)
             assert lens.tolist() == wlens.tolist() and out.tobytes() == want.tobytes(), mode
             assert ctx.timing()["n_recoded_blocks"] == 0
-        for mode in ("x3", "x2", "fast"):
+        for mode in ("x4", "x3", "x2", "fast"):
             ctx.set_coder(mode)
             for limit in (19, 24, 33):  # force the fast coders to give blocks back to k_coder
                 ctx.set_acc_limit(limit)
@@ -221,7 +225,7 @@ def test_coder_variants_and_fallback(ctx, oracle):
             ctx.set_acc_limit(46)
     finally:
         ctx.set_acc_limit(46)
-        ctx.set_coder("x3")
+        ctx.set_coder("x4")
         ctx.set_path("auto")
 
 
@@ -280,6 +284,53 @@ def test_nospace_and_errors(ctx):
     with pytest.raises(w3.W3Error) as e:
         ctx.encode_blocks(w3.Order0(), data, 0)
     assert e.value.code == L.W3_E_INVALID
+
+
+def test_decode_rejects_inflated_length_table(ctx):
+    """a length table that claims more compressed bytes than the buffer holds is refused (W3_E_FORMAT) before any
+    read — host-buffer and device-resident entry points."""
+    import torch
+    from weath3rb0i_amd import _lib as L
+    data = lcg_text(20000, seed=17)
+    out, lens = ctx.encode_blocks(w3.Order0(), data, 4096)
+    bad = lens.copy()
+    bad[-1] += 100000
+    with pytest.raises(w3.W3Error) as e:
+        ctx.decode_blocks(w3.Order0(), out, bad, 4096, len(data))
+    assert e.value.code == L.W3_E_FORMAT
+    d_comp = torch.from_numpy(np.array(out)).cuda()
+    d_back = torch.empty(len(data), dtype=torch.uint8, device="cuda")
+    with pytest.raises(w3.W3Error) as e:
+        ctx.decode_blocks_device(w3.Order0(), d_comp, torch.from_numpy(bad.astype(np.int32)).cuda(), 4096, len(data), d_back)
+    assert e.value.code == L.W3_E_FORMAT
+    ctx.decode_blocks_device(w3.Order0(), d_comp, torch.from_numpy(lens.astype(np.int32)).cuda(), 4096, len(data), d_back)
+    assert d_back.cpu().numpy().tobytes() == data
+
+
+def test_encode_is_ordered_after_async_producer(ctx, oracle):
+    """the input is produced by an asynchronous torch kernel on the default stream immediately before the call
+    (stream handle 0 = the ctx's own blocking stream, ordered against the legacy default stream), and d_lens / d_total are
+    zeroed the same way.  64 MB keeps the producer running while the encode kernels are enqueued."""
+    import torch
+    n, bs = 1 << 26, 65536
+    nb = n // bs
+    base = torch.from_numpy(np.frombuffer(markov_text(1 << 20, seed=41), dtype=np.uint8).copy()).cuda()
+    d_in = torch.empty(n, dtype=torch.uint8, device="cuda")
+    d_out = torch.empty(n + n // 4 + 64 * nb + 1024, dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    for stream_arg in (None, 0):
+        d_in.zero_()
+        torch.cuda.synchronize()
+        d_in.copy_(base.repeat(n >> 20) ^ 1)          # async: several kernels on the default stream
+        d_lens = torch.zeros(nb, dtype=torch.int32, device="cuda")
+        d_total = torch.zeros(1, dtype=torch.int64, device="cuda")
+        ctx.encode_blocks_device(w3.Order0(), d_in, bs, d_out, d_lens, d_total, stream=stream_arg)
+        lens = d_lens.cpu().numpy().astype(np.uint32)
+        host = d_in.cpu().numpy()
+        for b in (0, nb // 2, nb - 1):
+            want, wl = oracle.encode_blocks(oracle.Order0(), host[b * bs:(b + 1) * bs].tobytes(), bs)
+            off = int(lens[:b].sum())
+            assert wl.tolist() == [int(lens[b])] and d_out[off:off + int(lens[b])].cpu().numpy().tobytes() == want.tobytes(), (stream_arg, b)
 
 
 def test_reference_container(ctx, oracle):

@@ -28,7 +28,8 @@ def test_exports_match_header(lib):
     for name in sorted(declared):
         assert hasattr(lib, name), "libw3hip.so does not export %s" % name
     assert declared == set(L.EXPORTS)
-    assert lib.w3_abi_version() == 4
+    m = re.search(r"#define W3_ABI_VERSION (\d+)", open(os.path.join(ROOT, "include", "w3hip.h")).read())
+    assert lib.w3_abi_version() == int(m.group(1)) == 5
 
 
 def test_struct_layout(lib):

@@ -137,7 +137,7 @@ static int decompress(w3_ctx *ctx, const std::string &in, const std::string &out
     for (uint32_t b = 0; b < nb; b++) { lens[b] = (uint32_t)get_be(data.data() + 21 + 4ull * b, 4); total += lens[b]; }
     if (data.size() < 21 + 4ull * nb + total) return die(ctx, W3_E_FORMAT, "streams");
     std::vector<uint8_t> o((size_t)orig + 1);
-    int rc = w3_decode_blocks(ctx, &spec, data.data() + 21 + 4ull * nb, lens.data(), nb, bs, orig, o.data());
+    int rc = w3_decode_blocks(ctx, &spec, data.data() + 21 + 4ull * nb, data.size() - (21 + 4ull * nb), lens.data(), nb, bs, orig, o.data());
     if (rc) return die(ctx, rc, "w3_decode_blocks");
     return write_file(out, o.data(), (size_t)orig) ? 0 : 1;
 }

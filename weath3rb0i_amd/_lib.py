@@ -12,7 +12,8 @@ W3_APM_ORDER0, W3_APM_ORDER1 = 0, 1
 W3_MAX_APM = 4
 W3_HIST_NONE, W3_HIST_RAW, W3_HIST_AC = 0, 1, 2
 W3_OK, W3_E_INVALID, W3_E_NOSPACE, W3_E_HIP, W3_E_UNSUPPORTED, W3_E_NOMEM, W3_E_FORMAT = 0, -1, -2, -3, -4, -5, -6
-W3_OPT_PATH, W3_OPT_TIMING, W3_OPT_CODER, W3_OPT_ACC_LIMIT, W3_OPT_DEBUG_STAMPS, W3_OPT_PARTS = 1, 2, 3, 4, 5, 6
+W3_OPT_PATH, W3_OPT_TIMING, W3_OPT_CODER, W3_OPT_ACC_LIMIT, W3_OPT_DEBUG_STAMPS, W3_OPT_PARTS, W3_OPT_VARIANT, W3_OPT_SLOT_BUDGET_MB = 1, 2, 3, 4, 5, 6, 7, 8
+W3_VAR_NO_LDS_ATOMICS, W3_VAR_PARTITION4, W3_VAR_NO_CHAINED_PARTITION, W3_VAR_CM_UNSTAGED, W3_VAR_NO_SIDE_STREAM = 1, 2, 4, 8, 16
 W3_PATH_AUTO, W3_PATH_GENERIC, W3_PATH_TWOPHASE = 0, 1, 2
 
 
@@ -72,9 +73,9 @@ def load():
     lib.w3_max_compressed_size.restype = sz
     lib.w3_max_compressed_size.argtypes = [sz, sz]
     lib.w3_encode_blocks.argtypes = [vp, C.POINTER(ModelSpec), vp, sz, sz, vp, sz, C.POINTER(sz), vp]
-    lib.w3_decode_blocks.argtypes = [vp, C.POINTER(ModelSpec), vp, vp, sz, sz, C.c_uint64, vp]
+    lib.w3_decode_blocks.argtypes = [vp, C.POINTER(ModelSpec), vp, sz, vp, sz, sz, C.c_uint64, vp]
     lib.w3_encode_blocks_device.argtypes = [vp, C.POINTER(ModelSpec), vp, sz, sz, vp, sz, vp, vp, vp]
-    lib.w3_decode_blocks_device.argtypes = [vp, C.POINTER(ModelSpec), vp, vp, sz, sz, C.c_uint64, vp, vp]
+    lib.w3_decode_blocks_device.argtypes = [vp, C.POINTER(ModelSpec), vp, sz, vp, sz, sz, C.c_uint64, vp, vp]
     lib.w3_compress_stream.argtypes = [vp, C.POINTER(ModelSpec), vp, sz, vp, sz, C.POINTER(sz)]
     lib.w3_decompress_stream.argtypes = [vp, C.POINTER(ModelSpec), vp, sz, vp, sz, C.POINTER(sz)]
     lib.w3_predict_blocks.argtypes = [vp, C.POINTER(ModelSpec), vp, sz, sz, vp]

@@ -44,7 +44,7 @@ class Context:
         self._chk(self.lib.w3_ctx_set_option(self.h, L.W3_OPT_PATH, {"auto": 0, "generic": 1, "twophase": 2}[path]))
 
     def set_coder(self, mode):
-        self._chk(self.lib.w3_ctx_set_option(self.h, L.W3_OPT_CODER, {"x3": 0, "fast": 1, "robust": 2, "x2": 3}[mode]))
+        self._chk(self.lib.w3_ctx_set_option(self.h, L.W3_OPT_CODER, {"x4": 0, "fast": 1, "robust": 2, "x2": 3, "x3": 4}[mode]))
 
     def set_acc_limit(self, bits):
         self._chk(self.lib.w3_ctx_set_option(self.h, L.W3_OPT_ACC_LIMIT, bits))
@@ -52,6 +52,19 @@ class Context:
     def set_parts(self, parts=0):
         """Block ranges a two-phase encode is pipelined in on separate streams (0 = auto, 1 = one range)."""
         self._chk(self.lib.w3_ctx_set_option(self.h, L.W3_OPT_PARTS, int(parts)))
+
+    def set_variant(self, *names):
+        """Cross-check hook (W3_OPT_VARIANT): alternative bit-exact implementations, by name: no_lds_atomics, partition4,
+        no_chained_partition, cm_unstaged, no_side_stream.  No names = defaults."""
+        bits = {"no_lds_atomics": L.W3_VAR_NO_LDS_ATOMICS, "partition4": L.W3_VAR_PARTITION4, "no_chained_partition": L.W3_VAR_NO_CHAINED_PARTITION,
+                "cm_unstaged": L.W3_VAR_CM_UNSTAGED, "no_side_stream": L.W3_VAR_NO_SIDE_STREAM}
+        v = 0
+        for nm in names:
+            v |= bits[nm]
+        self._chk(self.lib.w3_ctx_set_option(self.h, L.W3_OPT_VARIANT, v))
+
+    def set_slot_budget_mb(self, mb=0):
+        self._chk(self.lib.w3_ctx_set_option(self.h, L.W3_OPT_SLOT_BUDGET_MB, int(mb)))
 
     def set_timing(self, on=True):
         self._chk(self.lib.w3_ctx_set_option(self.h, L.W3_OPT_TIMING, int(on)))
@@ -87,7 +100,7 @@ class Context:
         a = _u8(comp)
         lens = np.ascontiguousarray(block_lens, dtype=np.uint32)
         out = np.empty(max(orig_len, 1), dtype=np.uint8)
-        rc = self.lib.w3_decode_blocks(self.h, C.byref(spec), a.ctypes.data_as(C.c_void_p), lens.ctypes.data_as(C.c_void_p),
+        rc = self.lib.w3_decode_blocks(self.h, C.byref(spec), a.ctypes.data_as(C.c_void_p), len(a), lens.ctypes.data_as(C.c_void_p),
                                        len(lens), block_size, orig_len, out.ctypes.data_as(C.c_void_p))
         self._chk(rc)
         return out[:orig_len]
@@ -137,6 +150,8 @@ class Context:
     def encode_blocks_device(self, model, d_in, block_size, d_out, d_lens, d_total, stream=None):
         """d_in/d_out: torch.uint8 CUDA tensors, d_lens: int32/uint32[nb], d_total: int64[1].  Returns rc-checked None."""
         spec = model.spec() if isinstance(model, Model) else model
+        # stream: a hipStream_t handle as an int.  None or 0 = the ctx's own (blocking) stream, which is ordered against the
+        # legacy default stream — torch's default stream IS that stream (handle 0), so both spellings mean the same order.
         st = C.c_void_p(stream) if stream else None
         rc = self.lib.w3_encode_blocks_device(self.h, C.byref(spec), C.c_void_p(d_in.data_ptr()), d_in.numel(), block_size,
                                               C.c_void_p(d_out.data_ptr()), d_out.numel(), C.c_void_p(d_lens.data_ptr()),
@@ -146,6 +161,6 @@ class Context:
     def decode_blocks_device(self, model, d_comp, d_lens, block_size, orig_len, d_out, stream=None):
         spec = model.spec() if isinstance(model, Model) else model
         st = C.c_void_p(stream) if stream else None
-        rc = self.lib.w3_decode_blocks_device(self.h, C.byref(spec), C.c_void_p(d_comp.data_ptr()), C.c_void_p(d_lens.data_ptr()),
+        rc = self.lib.w3_decode_blocks_device(self.h, C.byref(spec), C.c_void_p(d_comp.data_ptr()), d_comp.numel(), C.c_void_p(d_lens.data_ptr()),
                                               d_lens.numel(), block_size, orig_len, C.c_void_p(d_out.data_ptr()), st)
         self._chk(rc)

@@ -14,9 +14,24 @@
 
 #include "w3_apm.h"
 #include "w3_coder.h"
+#include "w3_coder4.h"
 #include "w3_predict.h"
 #include "w3_slot.h"
 #include "w3_spec.h"
+
+// Tuning / timing-experiment hooks read from the environment exist only in -DW3_TUNING builds: the shipped library never
+// calls getenv.  (Some of them make the kernels skip work, i.e. produce wrong results.)
+static inline const char *w3_tune_env(const char *name) {
+#ifdef W3_TUNING
+    return getenv(name);
+#else
+    (void)name;
+    return nullptr;
+#endif
+}
+
+// W3_OPT_VARIANT bits: alternative (bit-exact) implementations that the tests cross-check against the default ones
+enum { W3_VAR_NO_LDS_ATOMICS = 1, W3_VAR_PARTITION4 = 2, W3_VAR_NO_CHAINED_PARTITION = 4, W3_VAR_CM_UNSTAGED = 8, W3_VAR_NO_SIDE_STREAM = 16 };
 
 struct TwoPhaseWs {
     void *P = nullptr, *keys = nullptr, *perm = nullptr, *redo = nullptr, *streams = nullptr, *rec = nullptr, *splits = nullptr;
@@ -48,8 +63,10 @@ struct TwoPhaseWs {
     size_t dummy_cap = 0;
     void *slot_tables = nullptr;        // per-lane HashMaps of the slot-state leaves
     size_t slot_tables_cap = 0;
-    int coder_mode = 0;        // 0 = k_coder_x3 (mix+recurrence+output waves), 1 = k_coder_fast, 2 = k_coder only, 3 = k_coder_x2
+    int coder_mode = 0;        // 0 = k_coder_x4 (mix + asm recurrence + output waves), 1 = k_coder_fast, 2 = k_coder only, 3 = k_coder_x2, 4 = k_coder_x3
     uint32_t acc_limit = 46;   // test hook: lower values force the fast coder's fallback
+    uint32_t variant = 0;      // W3_VAR_* (W3_OPT_VARIANT)
+    uint32_t slot_budget_mb = 0;   // W3_OPT_SLOT_BUDGET_MB: cap on the slot leaves' hash-map batch (0 = from the free device memory)
     void release() {
         if (P) (void)hipFree(P);
         if (keys) (void)hipFree(keys);
@@ -151,7 +168,7 @@ static inline int twophase_mix(TwoPhaseWs &ws, hipStream_t s, size_t n, std::str
 static inline bool twophase_lds_order_ok(TwoPhaseWs &ws, hipStream_t s) {
     if (ws.lds_order >= 0) return ws.lds_order == 1;
     ws.lds_order = 0;
-    if (getenv("W3_NO_LDS_ATOMICS")) return false;
+    if (ws.variant & W3_VAR_NO_LDS_ATOMICS) return false;
     const uint32_t waves = 64, rounds = 32, n = waves * rounds * 64;
     uint32_t *d_old = nullptr;
     if (hipMalloc(&d_old, (size_t)n * 4) != hipSuccess) { (void)hipGetLastError(); return false; }
@@ -219,7 +236,7 @@ static inline int twophase_predict(TwoPhaseWs &ws, hipStream_t s, const ParsedSp
     if (ev) (void)hipEventRecord(ev[0], s);
     // fork: the partition passes of the wide leaves go to the side stream (they are bound by scattered line requests, the
     // time-ordered kernels by VALU issue); the rank kernels follow on the main stream after the join
-    const bool forked = need_perm && !getenv("W3_NO_SIDE_STREAM");
+    const bool forked = need_perm && !(ws.variant & W3_VAR_NO_SIDE_STREAM);
     hipStream_t sp = forked ? ws.side : s;
     if (forked) { (void)hipEventRecord(ws.ev_fork, s); (void)hipStreamWaitEvent(ws.side, ws.ev_fork, 0); }
     ws.wide1_slot = -1;
@@ -255,7 +272,7 @@ static inline int twophase_predict(TwoPhaseWs &ws, hipStream_t s, const ParsedSp
         pa.hbits = nd.bits - 3;
         pa.sink = (uint4 *)ws.dummy;
         pa.maxseg = W3_ATOMIC_MAXSEG;
-        if (const char *ev_ = getenv("W3_ATOMIC_MAXSEG")) pa.maxseg = (uint32_t)std::max(0, atoi(ev_));   // tuning hook
+        if (const char *ev_ = w3_tune_env("W3_ATOMIC_MAXSEG")) pa.maxseg = (uint32_t)std::max(0, atoi(ev_));   // tuning hook
         if (!lds_atomics) pa.dbg_flags |= 2u;
         bytes += n * 17;
         if (c == LEAF_SMALL_AC) {
@@ -286,20 +303,20 @@ static inline int twophase_predict(TwoPhaseWs &ws, hipStream_t s, const ParsedSp
             pa.rec = (uint2 *)ws.rec_w[w]; pa.splits = (uint32_t *)ws.splits_w[w];
             pa.job_counter = (uint32_t *)ws.splits_w[w] + (size_t)nb * (W3_SLICES + 1);   // lives behind the split table
             (void)hipMemsetAsync(pa.job_counter, 0, 4, sp);
-            if (const char *ev_ = getenv("W3_DEBUG_NOSTORE")) pa.dbg_flags = (uint32_t)atoi(ev_) & 5u;   // timing experiments: results are wrong
+            if (const char *ev_ = w3_tune_env("W3_DEBUG_NOSTORE")) pa.dbg_flags = (uint32_t)atoi(ev_) & 5u;   // -DW3_TUNING timing experiments: results are wrong
             if (!lds_atomics) pa.dbg_flags |= 2u;
             // A persistent grid of 2048 wavefronts walks the (block, slice) jobs in block order, so only the blocks in flight
             // (~32 with 64 slices each, more while a block's largest group is still running) are being scattered into and their
             // P regions stay in the Infinity Cache.  Measured at 1e9 B, whole predict phase (grid 1024 / 1536 / 2048 / 2560 / 3072 /
             // 4096): 64.0 / 59.1 / 54.6 / 55.1 / 58.7 / 58.7 ms.
             uint32_t rank_waves = 2048u;
-            if (const char *ev_ = getenv("W3_RANK_GRID")) rank_waves = (uint32_t)std::max(64, atoi(ev_));   // tuning hook
+            if (const char *ev_ = w3_tune_env("W3_RANK_GRID")) rank_waves = (uint32_t)std::max(64, atoi(ev_));   // tuning hook
             const uint32_t grid_rank = std::min<uint32_t>(nb * W3_SLICES, rank_waves);
             // an order-2 leaf behind an Order1 leaf starts from that leaf's records (sorted by c1; same stream, so they are ready)
-            const bool chained = c == LEAF_WIDE2 && ws.wide1_slot >= 0 && !getenv("W3_NO_CHAINED_PARTITION");
+            const bool chained = c == LEAF_WIDE2 && ws.wide1_slot >= 0 && !(ws.variant & W3_VAR_NO_CHAINED_PARTITION);
             if (chained) pa.rec_src = (const uint2 *)ws.rec_w[ws.wide1_slot];
             // one 8-bit pass through LDS tiles (k_partition8) needs the lane-ordered LDS adds; otherwise 4-bit passes
-            const bool p8 = lds_atomics && !getenv("W3_PARTITION4");
+            const bool p8 = lds_atomics && !(ws.variant & W3_VAR_PARTITION4);
             if (c == LEAF_WIDE1 && p8) hipLaunchKernelGGL(w3::k_partition8<1>, dim3(grid_wide), dim3(64), 0, sp, pa);
             else if (chained && p8) hipLaunchKernelGGL(w3::k_partition8<3>, dim3(grid_wide), dim3(64), 0, sp, pa);
             else if (c == LEAF_WIDE1) hipLaunchKernelGGL(w3::k_partition<1>, dim3(grid_wide), dim3(64), 0, sp, pa);
@@ -341,7 +358,7 @@ static inline int twophase_predict(TwoPhaseWs &ws, hipStream_t s, const ParsedSp
         }
         const uint64_t avail = (uint64_t)free_b + ws.slot_tables_cap;
         uint64_t budget = avail > later ? avail - later : 0;
-        if (const char *ev_ = getenv("W3_SLOT_BUDGET_MB")) budget = (uint64_t)std::max(1, atoi(ev_)) << 20;   // test / tuning hook
+        if (ws.slot_budget_mb) budget = (uint64_t)ws.slot_budget_mb << 20;   // W3_OPT_SLOT_BUDGET_MB (tests: several batches on a small input)
         uint64_t lanes = std::min<uint64_t>(budget / slot_stride, nb);
         if (lanes < nb) {
             // equal batches: a batch costs at least the lone-wave latency of a whole block, however few lanes it has
@@ -354,7 +371,7 @@ static inline int twophase_predict(TwoPhaseWs &ws, hipStream_t s, const ParsedSp
         sa.st = ws.st;
         if ((rc = tp_ensure(ws.dummy, ws.dummy_cap, 2048, err))) return rc;
         sa.dummy = (uint8_t *)ws.dummy;
-        if (const char *ev_ = getenv("W3_SLOT_DEBUG")) sa.dbg_flags = (uint32_t)atoi(ev_);   // timing experiments only
+        if (const char *ev_ = w3_tune_env("W3_SLOT_DEBUG")) sa.dbg_flags = (uint32_t)atoi(ev_);   // -DW3_TUNING timing experiments only: results are wrong
         if (ev) (void)hipEventRecord(ev[10], s);
         for (uint32_t first = 0; first < nb; first += (uint32_t)lanes) {
             const uint32_t cnt = std::min<uint32_t>((uint32_t)lanes, nb - first);
@@ -455,7 +472,7 @@ static inline int twophase_encode(TwoPhaseWs &ws, hipStream_t s, const ParsedSpe
                                   w3_timing *tm, std::string &err) {
     int n_live = 0;
     for (int l = 0; l < ps.n_leaves; l++) n_live += leaf_class(ps.leaf[l]) != LEAF_FROZEN;
-    const bool x3 = ws.coder_mode == 0 && (n_live <= 4 || ps.n_apm > 0);   // more leaves: merge with k_mix first, then k_coder_x2
+    const bool x3 = (ws.coder_mode == 0 || ws.coder_mode == 4) && (n_live <= 4 || ps.n_apm > 0);   // more leaves: merge with k_mix first, then k_coder_x2
     int rc = twophase_predict(ws, s, ps, d_in, n, block_size, nb, !x3 && ps.n_apm == 0, nullptr, ev, tm, err);
     if (rc) return rc;
     if (ws.ev_pred_done) (void)hipEventRecord(ws.ev_pred_done, s);   // the next block range may start its predict kernels
@@ -472,7 +489,7 @@ static inline int twophase_encode(TwoPhaseWs &ws, hipStream_t s, const ParsedSpe
         s = ws.hi;
     }
     if ((rc = twophase_apm(ws, s, ps, d_in, n, block_size, nb, ev, tm, err))) return rc;   // leaves ws.P as the one source stream
-    if (getenv("W3_DEBUG_NOSTORE")) { err = "W3_DEBUG_NOSTORE: predict-only timing experiment"; return W3_E_UNSUPPORTED; }
+    if (w3_tune_env("W3_DEBUG_NOSTORE")) { err = "W3_DEBUG_NOSTORE: predict-only timing experiment"; return W3_E_UNSUPPORTED; }
     if ((rc = tp_ensure(ws.redo, ws.redo_cap, (size_t)nb * 4, err))) return rc;
     const uint32_t limit = std::min<uint32_t>(ws.acc_limit, 46u);
     if (ev) (void)hipEventRecord(ev[2], s);
@@ -484,11 +501,20 @@ static inline int twophase_encode(TwoPhaseWs &ws, hipStream_t s, const ParsedSpe
         c3.stripes = stripes; c3.stripe_cap = stripe_cap; c3.out_len = d_lens; c3.flags = d_flag; c3.redo = (uint32_t *)ws.redo;
         c3.acc_limit = limit;
         const dim3 grid((nb + 63) / 64), blk(192);
-        switch (ws.mix.n_src) {
-        case 1: hipLaunchKernelGGL(w3::k_coder_x3<1>, grid, blk, 0, s, c3); break;
-        case 2: hipLaunchKernelGGL(w3::k_coder_x3<2>, grid, blk, 0, s, c3); break;
-        case 3: hipLaunchKernelGGL(w3::k_coder_x3<3>, grid, blk, 0, s, c3); break;
-        default: hipLaunchKernelGGL(w3::k_coder_x3<4>, grid, blk, 0, s, c3); break;
+        if (ws.coder_mode == 4) {
+            switch (ws.mix.n_src) {
+            case 1: hipLaunchKernelGGL(w3::k_coder_x3<1>, grid, blk, 0, s, c3); break;
+            case 2: hipLaunchKernelGGL(w3::k_coder_x3<2>, grid, blk, 0, s, c3); break;
+            case 3: hipLaunchKernelGGL(w3::k_coder_x3<3>, grid, blk, 0, s, c3); break;
+            default: hipLaunchKernelGGL(w3::k_coder_x3<4>, grid, blk, 0, s, c3); break;
+            }
+        } else {
+            switch (ws.mix.n_src) {
+            case 1: hipLaunchKernelGGL(w3::k_coder_x4<1>, grid, blk, 0, s, c3); break;
+            case 2: hipLaunchKernelGGL(w3::k_coder_x4<2>, grid, blk, 0, s, c3); break;
+            case 3: hipLaunchKernelGGL(w3::k_coder_x4<3>, grid, blk, 0, s, c3); break;
+            default: hipLaunchKernelGGL(w3::k_coder_x4<4>, grid, blk, 0, s, c3); break;
+            }
         }
         if (tm) tm->coder_bytes = (uint64_t)n * (16 * ws.mix.n_src + 1);
     } else {

@@ -98,7 +98,10 @@ extern "C" int w3_ctx_create(int device, w3_ctx **out) {
     if (hipSetDevice(device) != hipSuccess) return W3_E_HIP;
     w3_ctx *c = new w3_ctx();
     c->device = device;
-    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return W3_E_HIP; }
+    // A BLOCKING stream: it is ordered against the legacy default (NULL) stream like any ordinary stream, so a caller that
+    // produces d_in on the default stream and passes stream = NULL (or torch's default-stream handle, which is 0) gets the
+    // order it expects.  The side streams of the predict phase fork from and join the launch stream with events.
+    if (hipStreamCreate(&c->stream) != hipSuccess) { delete c; return W3_E_HIP; }
     for (auto &e : c->ev)
         if (hipEventCreate(&e) != hipSuccess) { delete c; return W3_E_HIP; }
     *out = c;
@@ -137,7 +140,7 @@ extern "C" int w3_ctx_set_option(w3_ctx *ctx, int opt, int64_t value) {
         return W3_OK;
     case W3_OPT_TIMING: ctx->opt_timing = value ? 1 : 0; return W3_OK;
     case W3_OPT_CODER:
-        if (value < 0 || value > 3) return W3_E_INVALID;
+        if (value < 0 || value > 4) return W3_E_INVALID;
         ctx->tp.coder_mode = (int)value;
         return W3_OK;
     case W3_OPT_DEBUG_STAMPS: ctx->tp.debug_stamps = value ? 1 : 0; return W3_OK;
@@ -148,6 +151,15 @@ extern "C" int w3_ctx_set_option(w3_ctx *ctx, int opt, int64_t value) {
     case W3_OPT_ACC_LIMIT:
         if (value < 19 || value > 46) return W3_E_INVALID;
         ctx->tp.acc_limit = (uint32_t)value;
+        return W3_OK;
+    case W3_OPT_VARIANT:
+        if (value < 0 || value > 31) return W3_E_INVALID;
+        ctx->tp.variant = (uint32_t)value;
+        ctx->tp.lds_order = -1;   // re-run the lane-order self-test under the new setting
+        return W3_OK;
+    case W3_OPT_SLOT_BUDGET_MB:
+        if (value < 0 || value > (1 << 20)) return W3_E_INVALID;
+        ctx->tp.slot_budget_mb = (uint32_t)value;
         return W3_OK;
     default: return W3_E_INVALID;
     }
@@ -456,7 +468,7 @@ static int cm_run(w3_ctx *ctx, hipStream_t s, CmArgs &ca, uint64_t lane_stride, 
         } else {
             int n_slot = 0;
             for (int l = 0; l < ca.g.n_leaves; l++) n_slot += ca.g.leaf[l].kind == 1;
-            if (n_slot <= W3_CM_STAGED_MAX && !getenv("W3_CM_UNSTAGED")) hipLaunchKernelGGL(k_cm_staged<DECODE>, grid, blk, 0, s, ca);   // slot cells staged in LDS
+            if (n_slot <= W3_CM_STAGED_MAX && !(ctx->tp.variant & W3_VAR_CM_UNSTAGED)) hipLaunchKernelGGL(k_cm_staged<DECODE>, grid, blk, 0, s, ca);   // slot cells staged in LDS
             else hipLaunchKernelGGL(k_cm<DECODE>, grid, blk, 0, s, ca);
         }
         HIPCHK(ctx, hipGetLastError());
@@ -525,7 +537,7 @@ static float elapsed_ev(hipEvent_t *ev, int slot) {
 static int choose_parts(const w3_ctx *ctx, const ParsedSpec &ps, uint32_t nb) {
     if (ps.has_slot) return 1;
     int k = ctx->opt_parts;
-    if (const char *e = getenv("W3_PARTS")) k = atoi(e);   // tuning hook
+    if (const char *e = w3_tune_env("W3_PARTS")) k = atoi(e);   // -DW3_TUNING builds only
     if (k <= 0) k = 1;
     k = std::min(k, W3_MAX_PARTS);
     while (k > 1 && nb / (uint32_t)k < 256u) k--;
@@ -544,6 +556,7 @@ static int ensure_ranges(w3_ctx *ctx, int parts, bool timing) {
             for (auto &e : r.ev)
                 if (!e) HIPCHK(ctx, hipEventCreate(&e));
         r.ws.coder_mode = ctx->tp.coder_mode; r.ws.acc_limit = ctx->tp.acc_limit; r.ws.debug_stamps = 0;
+        r.ws.variant = ctx->tp.variant; r.ws.slot_budget_mb = ctx->tp.slot_budget_mb;
         r.ws.stretch = ctx->tp.stretch; r.ws.squash = ctx->tp.squash; r.ws.st = ctx->tp.st;
     }
     return W3_OK;
@@ -604,7 +617,7 @@ extern "C" int w3_encode_blocks_device(w3_ctx *ctx, const w3_model_spec *spec, c
                     HIPCHK(ctx, hipStreamWaitEvent(sp, ctx->ev_fork, 0));
                     HIPCHK(ctx, hipStreamWaitEvent(sp, ctx->ev_pred[p - 1], 0));
                 }
-                ws.use_hi = parts > 1 && !getenv("W3_NO_HI_STREAM");
+                ws.use_hi = parts > 1 && !w3_tune_env("W3_NO_HI_STREAM");
                 ws.ev_pred_done = parts > 1 ? ctx->ev_pred[p] : nullptr;
                 if (p && ctx->tp.lds_order >= 0) ws.lds_order = ctx->tp.lds_order;   // (range 0 has run the self-test)
                 rc = twophase_encode(ws, sp, ps, d_in + o, np, block_size, pb[p + 1] - pb[p], (uint8_t *)ctx->stripes.p + (size_t)pb[p] * cap, cap,
@@ -687,7 +700,7 @@ extern "C" int w3_encode_blocks_device(w3_ctx *ctx, const w3_model_spec *spec, c
     return W3_OK;
 }
 
-extern "C" int w3_decode_blocks_device(w3_ctx *ctx, const w3_model_spec *spec, const uint8_t *d_in, const uint32_t *d_block_lens,
+extern "C" int w3_decode_blocks_device(w3_ctx *ctx, const w3_model_spec *spec, const uint8_t *d_in, size_t in_len, const uint32_t *d_block_lens,
                                        size_t nblocks, size_t block_size, uint64_t orig_len, uint8_t *d_out, void *stream) {
     int rc = check_args(ctx, (size_t)orig_len, block_size);
     if (rc) return rc;
@@ -699,6 +712,15 @@ extern "C" int w3_decode_blocks_device(w3_ctx *ctx, const w3_model_spec *spec, c
     if (!d_in || !d_block_lens || !d_out) return W3_E_INVALID;
     HIPCHK(ctx, hipSetDevice(ctx->device));
     hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
+    {   // the length table must not claim more than the caller's buffer holds: the kernels read cin + offset for clens[b] bytes
+        ENSURE(ctx, ctx->coffs, (size_t)nb * 8);
+        ENSURE(ctx, ctx->total, 8);
+        hipLaunchKernelGGL(k_scan_lens, dim3(1), dim3(1024), 0, s, d_block_lens, (uint64_t *)ctx->coffs.p, (uint64_t *)ctx->total.p, (uint32_t)nb);
+        uint64_t total = 0;
+        HIPCHK(ctx, hipMemcpyAsync(&total, ctx->total.p, 8, hipMemcpyDeviceToHost, s));
+        HIPCHK(ctx, hipStreamSynchronize(s));
+        if (total > in_len) { ctx->err = "block length table claims " + std::to_string(total) + " compressed bytes, the buffer holds " + std::to_string(in_len); return W3_E_FORMAT; }
+    }
     rc = ps.is_cm() ? cm_decode(ctx, s, ps, d_in, d_block_lens, (uint32_t)nb, block_size, orig_len, d_out)
                     : generic_decode(ctx, s, ps, d_in, d_block_lens, (uint32_t)nb, block_size, orig_len, d_out);
     if (rc) return rc;
@@ -738,21 +760,22 @@ extern "C" int w3_encode_blocks(w3_ctx *ctx, const w3_model_spec *spec, const ui
     return W3_OK;
 }
 
-extern "C" int w3_decode_blocks(w3_ctx *ctx, const w3_model_spec *spec, const uint8_t *in, const uint32_t *block_lens, size_t nblocks,
+extern "C" int w3_decode_blocks(w3_ctx *ctx, const w3_model_spec *spec, const uint8_t *in, size_t in_len, const uint32_t *block_lens, size_t nblocks,
                                 size_t block_size, uint64_t orig_len, uint8_t *out) {
     int rc = check_args(ctx, (size_t)orig_len, block_size);
     if (rc) return rc;
     if (nblocks == 0 && orig_len == 0) return w3_spec_validate(spec);
     if (!in || !block_lens || !out) return W3_E_INVALID;
     HIPCHK(ctx, hipSetDevice(ctx->device));
-    size_t total = 0;
+    uint64_t total = 0;
     for (size_t b = 0; b < nblocks; b++) total += block_lens[b];
+    if (total > in_len) { ctx->err = "block length table claims " + std::to_string(total) + " compressed bytes, the buffer holds " + std::to_string(in_len); return W3_E_FORMAT; }
     ENSURE(ctx, ctx->io_in, std::max<size_t>(total, 16));
     ENSURE(ctx, ctx->io_out, (size_t)orig_len);
     ENSURE(ctx, ctx->lens, nblocks * 4);
     HIPCHK(ctx, hipMemcpy(ctx->io_in.p, in, total, hipMemcpyHostToDevice));
     HIPCHK(ctx, hipMemcpy(ctx->lens.p, block_lens, nblocks * 4, hipMemcpyHostToDevice));
-    rc = w3_decode_blocks_device(ctx, spec, (const uint8_t *)ctx->io_in.p, (const uint32_t *)ctx->lens.p, nblocks, block_size, orig_len,
+    rc = w3_decode_blocks_device(ctx, spec, (const uint8_t *)ctx->io_in.p, (size_t)total, (const uint32_t *)ctx->lens.p, nblocks, block_size, orig_len,
                                  (uint8_t *)ctx->io_out.p, ctx->stream);
     if (rc) return rc;
     HIPCHK(ctx, hipMemcpy(out, ctx->io_out.p, (size_t)orig_len, hipMemcpyDeviceToHost));
@@ -803,7 +826,7 @@ extern "C" int w3_decompress_stream(w3_ctx *ctx, const w3_model_spec *spec, cons
     uint32_t blen = (uint32_t)(in_len - 12);
     uint8_t zero = 0;
     const uint8_t *body = blen ? in + 12 : &zero;  // ACReader pads with zeros past EOF (io.rs:23-26)
-    return w3_decode_blocks(ctx, spec, body, &blen, 1, (size_t)len, len, out);
+    return w3_decode_blocks(ctx, spec, body, blen, &blen, 1, (size_t)len, len, out);
 }
 
 // ---------------------------------------------------------------------------
