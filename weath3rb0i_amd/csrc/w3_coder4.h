@@ -168,6 +168,113 @@ namespace w3 {
     "Lexit%=:\n"                                                                                     \
     "s_waitcnt lgkmcnt(0)\n"                                                                         \
     "v_mov_b32 %[x1], v110\n"
+// ---------------------------------------------------------------------------------------------------------------------
+// OUTPUT wave: a run of full chunks as one asm loop.  Per input byte (8 tokens (x_j, s_j) in v[T .. T+15]):
+//   S = sum s_j;  if (S > 31 || nb + S > fill) leave to the C path (nothing of the byte has been applied yet)
+//   xt_j = x_j ^ (xr & 2^31), xr = x_j << s_j        the TRUE low end of every token (see k_coder_x4's header)
+//   U_j  = xt_j >> (31 - s_j)                        carry into the slot | the s_j new bits
+//   merge pairwise: (U_a, s_a) . (U_b, s_b) = ((U_a << s_b) + U_b, s_a + s_b);  acc = (acc << S) + U_0..7;  nb += S
+//   move 32 finalised bits out when nb >= 33 + (trailing ones of acc)        (never the slot or the pending ones)
+// Fixed registers: acc v[84:85], nb v86, pos v87, xr v88, v77 = 0 (high half of the merged value), v96 = token address of the chunk.
+#define W3_O4_TOKRD(T, K)                                                                                   \
+    "ds_read2st64_b64 v[" W3S(T) "+0:" W3S(T) "+3], v96 offset0:" W3S(K) "*8+0 offset1:" W3S(K) "*8+1\n"      \
+    "ds_read2st64_b64 v[" W3S(T) "+4:" W3S(T) "+7], v96 offset0:" W3S(K) "*8+2 offset1:" W3S(K) "*8+3\n"      \
+    "ds_read2st64_b64 v[" W3S(T) "+8:" W3S(T) "+11], v96 offset0:" W3S(K) "*8+4 offset1:" W3S(K) "*8+5\n"     \
+    "ds_read2st64_b64 v[" W3S(T) "+12:" W3S(T) "+15], v96 offset0:" W3S(K) "*8+6 offset1:" W3S(K) "*8+7\n"
+#define W3_O4_XT(T, J, D)                                                                                   \
+    "v_bitop3_b32 " D ", v88, v[" W3S(T) "+2*" W3S(J) "], %[k31] bitop3:0x6c\n"                               \
+    "v_lshlrev_b32 v88, v[" W3S(T) "+2*" W3S(J) "+1], v[" W3S(T) "+2*" W3S(J) "]\n"
+#define W3_O4_U(T, J, D, TMP)                                                                               \
+    "v_sub_u32 " TMP ", 31, v[" W3S(T) "+2*" W3S(J) "+1]\n"                                                   \
+    "v_lshrrev_b32 " D ", " TMP ", " D "\n"
+#define W3_O4_BYTE(T, K)                                                                                    \
+    /* widths and the fast-path test first: a byte that leaves for the C path has changed nothing */         \
+    "v_add_u32 v73, v[" W3S(T) "+5], v[" W3S(T) "+7]\n"                  /* w23   */                         \
+    "v_add_u32 v74, v[" W3S(T) "+13], v[" W3S(T) "+15]\n"                /* w67   */                         \
+    "v_add3_u32 v75, v74, v[" W3S(T) "+9], v[" W3S(T) "+11]\n"           /* w4567 */                         \
+    "v_add3_u32 v79, v73, v[" W3S(T) "+1], v[" W3S(T) "+3]\n"            /* w0123 */                         \
+    "v_add_u32 v79, v79, v75\n"                                          /* S     */                         \
+    "v_add_u32 v78, v86, v79\n"                                          /* nb + S */                        \
+    "v_cmp_lt_u32 vcc, 31, v79\n"                                                                            \
+    "v_cmp_lt_u32 s[52:53], %[fill], v78\n"                                                                  \
+    "s_or_b64 vcc, vcc, s[52:53]\n"                                                                          \
+    "s_cbranch_vccnz Lbail" W3S(K) "%=\n"                                                                    \
+    W3_O4_XT(T, 0, "v64") W3_O4_XT(T, 1, "v65") W3_O4_XT(T, 2, "v66") W3_O4_XT(T, 3, "v67")                  \
+    W3_O4_XT(T, 4, "v68") W3_O4_XT(T, 5, "v69") W3_O4_XT(T, 6, "v70") W3_O4_XT(T, 7, "v71")                  \
+    W3_O4_U(T, 0, "v64", "v72") W3_O4_U(T, 1, "v65", "v80") W3_O4_U(T, 2, "v66", "v72") W3_O4_U(T, 3, "v67", "v80") \
+    W3_O4_U(T, 4, "v68", "v72") W3_O4_U(T, 5, "v69", "v80") W3_O4_U(T, 6, "v70", "v72") W3_O4_U(T, 7, "v71", "v80") \
+    "v_lshl_add_u32 v64, v64, v[" W3S(T) "+3], v65\n"                    /* U01 */                           \
+    "v_lshl_add_u32 v66, v66, v[" W3S(T) "+7], v67\n"                    /* U23 */                           \
+    "v_lshl_add_u32 v68, v68, v[" W3S(T) "+11], v69\n"                   /* U45 */                           \
+    "v_lshl_add_u32 v70, v70, v[" W3S(T) "+15], v71\n"                   /* U67 */                           \
+    "v_lshl_add_u32 v64, v64, v73, v66\n"                                /* U03 */                           \
+    "v_lshl_add_u32 v68, v68, v74, v70\n"                                /* U47 */                           \
+    "v_lshl_add_u32 v76, v64, v75, v68\n"                                /* U07 */                           \
+    "v_lshlrev_b64 v[84:85], v79, v[84:85]\n"                                                                \
+    "v_lshl_add_u64 v[84:85], v[84:85], 0, v[76:77]\n"                                                       \
+    "v_mov_b32 v86, v78\n"                                                                                   \
+    "v_not_b32 v80, v84\n"                                                                                   \
+    "v_ffbl_b32 v80, v80\n"                                                                                  \
+    "v_min_u32 v80, 32, v80\n"                                                                               \
+    "v_add_u32 v80, 33, v80\n"                                                                               \
+    "v_cmp_ge_u32 vcc, v86, v80\n"                                                                           \
+    "s_and_saveexec_b64 s[54:55], vcc\n"                                                                     \
+    "s_cbranch_execz Lnf" W3S(K) "%=\n"                                                                      \
+    "v_subrev_u32 v86, 32, v86\n"                                                                            \
+    "v_lshrrev_b64 v[80:81], v86, v[84:85]\n"                                                                \
+    "v_perm_b32 v80, 0, v80, %[bsw]\n"                                                                       \
+    "v_add_u32 v82, 4, v87\n"                                                                                \
+    "v_cmp_le_u32 vcc, v82, %[cap]\n"                                                                        \
+    "s_and_saveexec_b64 s[56:57], vcc\n"                                                                     \
+    "v_add_u32 v83, %[voff], v87\n"                                                                          \
+    "global_store_dword v83, v80, %[base]\n"                                                                 \
+    "s_mov_b64 exec, s[56:57]\n"                                                                             \
+    "v_mov_b32 v87, v82\n"                                                                                   \
+    "Lnf" W3S(K) "%=:\n"                                                                                     \
+    "s_or_b64 exec, exec, s[54:55]\n"
+// Absorbs the chunks [i, iend); st = 0 done, 1 = pipeline abort, 2 = byte %[k] of chunk %[i] must take the C path.
+#define W3_O4_LOOP                                                                                   \
+    "v_mov_b32 v84, %[alo]\n v_mov_b32 v85, %[ahi]\n v_mov_b32 v86, %[nb]\n v_mov_b32 v87, %[pos]\n"  \
+    "v_mov_b32 v88, %[xr]\n v_mov_b32 v77, 0\n"                                                      \
+    "Ltop%=:\n"                                                                                      \
+    "s_add_u32 s41, %[i], " W3S(W3_X4_CH) "\n"                                                       \
+    "s_cmp_ge_u32 %[sx], s41\n"                                                                      \
+    "s_cbranch_scc1 Lx_done%=\n"                                                                     \
+    W3_X4_SPIN("Lx", W3_X4_SYNC_X, "s41", "%[sx]")                                                   \
+    "s_lshl_b32 s40, %[slot], 14\n"                                                                  \
+    "v_add_u32 v96, s40, %[tkl]\n"                                                                   \
+    W3_X4_NEXTSLOT                                                                                   \
+    W3_O4_TOKRD(32, 0) W3_O4_TOKRD(48, 1) "s_waitcnt lgkmcnt(4)\n" W3_O4_BYTE(32, 0)                 \
+    W3_O4_TOKRD(32, 2) "s_waitcnt lgkmcnt(4)\n" W3_O4_BYTE(48, 1)                                    \
+    W3_O4_TOKRD(48, 3) "s_waitcnt lgkmcnt(4)\n" W3_O4_BYTE(32, 2)                                    \
+    "s_waitcnt lgkmcnt(0)\n" W3_O4_BYTE(48, 3)                                                       \
+    "v_mov_b32 v108, s41\n"                                                                          \
+    "ds_write_b32 %[sync], v108 offset:" W3S(W3_X4_SYNC_O) "\n"                                      \
+    "s_mov_b32 %[i], s41\n"                                                                          \
+    "s_mov_b32 %[slot], s47\n"                                                                       \
+    "s_cmp_lt_u32 %[i], %[iend]\n"                                                                   \
+    "s_cbranch_scc1 Ltop%=\n"                                                                        \
+    "s_branch Lexit%=\n"                                                                             \
+    "Lbail0%=:\n s_mov_b32 %[k], 0\n s_branch Lbail%=\n"                                             \
+    "Lbail1%=:\n s_mov_b32 %[k], 1\n s_branch Lbail%=\n"                                             \
+    "Lbail2%=:\n s_mov_b32 %[k], 2\n s_branch Lbail%=\n"                                             \
+    "Lbail3%=:\n s_mov_b32 %[k], 3\n"                                                                \
+    "Lbail%=:\n"                                                                                     \
+    "s_mov_b32 %[st], 2\n"                                                                           \
+    "s_branch Lexit%=\n"                                                                             \
+    "Ldead%=:\n"                                                                                     \
+    "v_mov_b32 v108, 1\n"                                                                            \
+    "ds_write_b32 %[sync], v108 offset:" W3S(W3_X4_SYNC_ABORT) "\n"                                  \
+    "s_mov_b32 %[st], 1\n"                                                                           \
+    "Lexit%=:\n"                                                                                     \
+    "s_waitcnt lgkmcnt(0)\n"                                                                         \
+    "v_mov_b32 %[alo], v84\n v_mov_b32 %[ahi], v85\n v_mov_b32 %[nb], v86\n v_mov_b32 %[pos], v87\n v_mov_b32 %[xr], v88\n"
+#define W3_O4_CLOBBERS                                                                                                     \
+    "v32", "v33", "v34", "v35", "v36", "v37", "v38", "v39", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47",         \
+    "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63",         \
+    "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75", "v76", "v77", "v78", "v79",         \
+    "v80", "v81", "v82", "v83", "v84", "v85", "v86", "v87", "v88", "v96", "v108", "v109",                                   \
+    "s40", "s41", "s44", "s45", "s47", "s52", "s53", "s54", "s55", "s56", "s57", "vcc", "scc", "memory"
 #define W3_X4_CLOBBERS                                                                                                     \
     "v32", "v33", "v34", "v35", "v36", "v37", "v38", "v39", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47",         \
     "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63",         \
@@ -377,108 +484,112 @@ __global__ void __launch_bounds__(192) k_coder_x4(Coder3Args a) {
     const uint32_t limit = a.acc_limit, fast_fill = a.acc_limit + 18u;   // 64 for the default limit of 46
     uint64_t acc = 0ull; uint32_t nb = 1u, pos = 0u;
     uint32_t xr = 0u;   // the raw x1 the next token grew from (its bit 31 is all that matters)
-    bool failed = false;
-    uint32_t seen_x = 0;
-    for (uint32_t i = 0; i < maxlen && !dead; i += CH) {
-        const uint32_t need = min(i + CH, maxlen);
-#if !(W3_X4_EXP & 32)
-        if (seen_x < need) { seen_x = spin_until_ge<1>(x_done, need, abortf, dead); if (dead) break; }
-#endif
-        __asm__ volatile("" ::: "memory");
+    uint32_t failed = 0u;
+    uint32_t seen_x = 0, i = 0;
+    const uint32_t tok_lane = (uint32_t)(uintptr_t)(w3_lds_u8 *)(tok + lane);
+    const uint32_t sync_addr = (uint32_t)(uintptr_t)(w3_lds_u8 *)sync_w;
+    const uint8_t *wg_base = a.stripes + (uint64_t)blockIdx.x * 64u * a.stripe_cap;   // stripe of this workgroup's first block
+    const uint32_t voff = lane * a.stripe_cap;                                       // (64 stripes: below 2^32 for every block size)
+    const uint32_t full_end = maxlen / CH * CH;
+
+    // one byte's eight tokens the careful way: per-step accumulator guard, hand-back to k_coder when a pending run outgrows it
+    auto byte_c = [&](uint32_t j0) {
+        const uint2 *slot = tok + ((size_t)x4_ring_pos(j0) * 8u) * 64u + lane;
+#pragma unroll 1
+        for (int j = 0; j < 8; j++) {
+            const uint2 t = slot[j * 64];
+            if (nb > limit) {
+                // accumulator nearly full: drain finalised bytes (those above the slot) one at a time
+                const uint32_t pend = trailing_ones64(acc) + 1u;
+#pragma unroll 1
+                while (nb >= pend + 8u) {
+                    const uint8_t v = (uint8_t)(acc >> (nb - 8u));
+                    if (pos < cap) out[pos] = v;
+                    pos += 1u; nb -= 8u;
+                }
+                if (nb > limit) { failed = 1u; acc = 0ull; nb = 1u; }   // pending run longer than the accumulator: k_coder re-codes the block
+            }
+            const uint32_t xt = t.x ^ (xr & 0x80000000u), sj = t.y;   // the TRUE low end
+            xr = t.x << sj;
+            acc += xt >> 31;
+            acc = (acc << sj) | __builtin_amdgcn_ubfe(xt, 31u - sj, sj);
+            nb += sj;
+        }
+        // once per input byte: move 32 finalised bits out (never the slot or the pending ones)
+        const uint32_t lo = (uint32_t)acc;
+        const uint32_t pend = (~lo ? (uint32_t)__builtin_ctz(~lo) : 32u) + 1u;
+        if (nb >= pend + 32u) {
+            const uint32_t wv = (uint32_t)(acc >> (nb - 32u));
+            if (pos + 4u <= cap) { const uint32_t be = __builtin_bswap32(wv); __builtin_memcpy(out + pos, &be, 4); }
+            pos += 4u; nb -= 32u;
+        }
+    };
+    // ArithmeticCoder::flush -> ACWriter::flush(x2) (arithmetic_coder.rs:67-71, io.rs:91-100): first bit x2 >> 31 (= 1) resolves
+    // the slot and the pending bits, then x2's next bits pad to a byte
+    auto finish = [&]() {
+        const uint2 f = fin[lane];
+        const uint32_t x2f = ((f.x & 0x7FFFFFFFu) + f.y) | 0x80000000u;
+        uint64_t fa = acc + 1ull; uint32_t fnb = nb, fpos = pos;
+        const uint32_t idx = fnb & 7u;
+        if (idx) { const uint32_t kk = 8u - idx; fa = (fa << kk) | ((x2f << 1) >> (32u - kk)); fnb += kk; }
+#pragma unroll 1
+        while (fnb >= 8u) {
+            const uint8_t v = (uint8_t)(fa >> (fnb - 8u));
+            if (fpos < cap) out[fpos] = v;
+            fpos += 1u; fnb -= 8u;
+        }
+        if (failed) { const uint32_t kk = atomicAdd(&a.flags[1], 1u); a.redo[kk] = b; }
+        else { a.out_len[b] = fpos; if (fpos > cap) atomicOr(&a.flags[0], 1u); }
+        cap = 0u;   // the lane keeps absorbing the tokens of clamped operands; nothing of it is stored any more
+    };
+
+    while (i < maxlen && !dead) {
+        uint32_t run_end = full_end;
+        if (lenB > i) run_end = min(run_end, lenB / CH * CH);
 #if W3_X4_EXP & 1
-        if (need == maxlen && act) a.out_len[b] = 0u;
-        lds_store_u32(o_cons, need);
-        continue;
-#endif
-        const uint32_t nbytes = need - i;
-        uint2 tn[8];
         {
-            const uint2 *slot = tok + ((size_t)x4_ring_pos(i) * 8u) * 64u + lane;
-#pragma unroll
-            for (int j = 0; j < 8; j++) tn[j] = slot[j * 64];
+            const uint32_t need = min(i + CH, maxlen);
+#if !(W3_X4_EXP & 32)
+            if (seen_x < need) { seen_x = __builtin_amdgcn_readfirstlane(spin_until_ge<1>(x_done, need, abortf, dead)); if (dead) break; }
+#endif
+            if (need == maxlen && act) a.out_len[b] = 0u;
+            lds_store_u32(o_cons, need);
+            i += CH;
+            continue;
         }
-#pragma unroll 1
-        for (uint32_t k = 0; k < nbytes; k++) {
-            uint2 t[8];
-#pragma unroll
-            for (int j = 0; j < 8; j++) t[j] = tn[j];
-            {   // the next byte's tokens (of this chunk; the last byte re-reads itself) while this byte is absorbed
-                const uint32_t kn = min(k + 1u, nbytes - 1u);
-                const uint2 *slot = tok + ((size_t)x4_ring_pos(i + kn) * 8u) * 64u + lane;
-#pragma unroll
-                for (int j = 0; j < 8; j++) tn[j] = slot[j * 64];
+#endif
+        if (run_end > i) {
+            uint32_t status = 0, slot = (i / CH) % W3_X4_NCH, kbail = 0;
+            uint32_t alo = (uint32_t)acc, ahi = (uint32_t)(acc >> 32);
+            asm volatile(W3_O4_LOOP
+                         : [alo] "+v"(alo), [ahi] "+v"(ahi), [nb] "+v"(nb), [pos] "+v"(pos), [xr] "+v"(xr), [i] "+s"(i), [slot] "+s"(slot),
+                           [sx] "+s"(seen_x), [st] "+s"(status), [k] "+s"(kbail)
+                         : [iend] "s"(run_end), [tkl] "v"(tok_lane), [sync] "v"(sync_addr), [cap] "v"(cap), [voff] "v"(voff),
+                           [base] "s"(wg_base), [fill] "s"(fast_fill), [k31] "s"(0x80000000u), [bsw] "s"(0x00010203u)
+                         : W3_O4_CLOBBERS);
+            acc = ((uint64_t)ahi << 32) | alo;
+            if (status == 1u) { dead = true; break; }
+            if (status == 2u) {   // bytes kbail.. of chunk i the careful way (x_done already covers the chunk)
+                for (uint32_t k = kbail; k < CH; k++) byte_c(i + k);
+                if (len == i + CH) finish();
+                __asm__ volatile("" ::: "memory");
+                lds_store_u32(o_cons, i + CH);
+                i += CH;
+                continue;
             }
-            // the TRUE low ends: token j's bit 31 is inverted when the raw x1 it grew from (the previous token shifted) had bit 31 set
-            uint32_t xt[8];
-#pragma unroll
-            for (int j = 0; j < 8; j++) { xt[j] = t[j].x ^ (xr & 0x80000000u); xr = t[j].x << t[j].y; }
-            const uint32_t w01 = t[0].y + t[1].y, w23 = t[2].y + t[3].y, w45 = t[4].y + t[5].y, w67 = t[6].y + t[7].y;
-            const uint32_t w4567 = w45 + w67, S = w01 + w23 + w4567;
-            if (__builtin_expect(__ballot(S > 31u || nb + S > fast_fill) == 0ull, 1)) {
-                // The whole byte fits: no per-step guard, and the eight tokens are merged pairwise before they touch the 64-bit
-                // accumulator.  Token j contributes U_j = top s_j + 1 bits of its low end = (carry into the slot) | s_j new bits, and
-                // acc' = (acc << s_j) + U_j is associative: (U_a, s_a) . (U_b, s_b) = ((U_a << s_b) + U_b, s_a + s_b); the merged
-                // value stays below 2^(S+1) because a carry never travels past the slot.
-                uint32_t U[8];
-#pragma unroll
-                for (int j = 0; j < 8; j++) U[j] = xt[j] >> (31u - t[j].y);
-                const uint32_t P01 = (U[0] << t[1].y) + U[1], P23 = (U[2] << t[3].y) + U[3];
-                const uint32_t P45 = (U[4] << t[5].y) + U[5], P67 = (U[6] << t[7].y) + U[7];
-                const uint32_t P03 = (P01 << w23) + P23, P47 = (P45 << w67) + P67;
-                const uint32_t P07 = (P03 << w4567) + P47;
-                acc = (acc << S) + P07;
-                nb += S;
-            } else {
-#pragma unroll
-                for (int j = 0; j < 8; j++) {
-                    if (nb > limit) {
-                        // accumulator nearly full: drain finalised bytes (those above the slot) one at a time
-                        const uint32_t pend = trailing_ones64(acc) + 1u;
-#pragma unroll 1
-                        while (nb >= pend + 8u) {
-                            const uint8_t v = (uint8_t)(acc >> (nb - 8u));
-                            if (pos < cap) out[pos] = v;
-                            pos += 1u; nb -= 8u;
-                        }
-                        if (nb > limit) { failed = true; acc = 0ull; nb = 1u; }   // pending run longer than the accumulator: k_coder re-codes the block
-                    }
-                    const uint32_t sj = t[j].y;
-                    acc += xt[j] >> 31;
-                    acc = (acc << sj) | __builtin_amdgcn_ubfe(xt[j], 31u - sj, sj);
-                    nb += sj;
-                }
+            if (len == run_end) finish();
+        } else {
+            const uint32_t need = min(i + CH, maxlen);
+            if (seen_x < need) { seen_x = __builtin_amdgcn_readfirstlane(spin_until_ge<1>(x_done, need, abortf, dead)); if (dead) break; }
+            __asm__ volatile("" ::: "memory");
+            for (uint32_t k = 0; i + k < need; k++) {
+                byte_c(i + k);
+                if (i + k + 1u == len) finish();
             }
-            // once per input byte: move 32 finalised bits out (never the slot or the pending ones)
-            const uint32_t lo = (uint32_t)acc;
-            const uint32_t pend = (~lo ? (uint32_t)__builtin_ctz(~lo) : 32u) + 1u;
-            if (nb >= pend + 32u) {
-                const uint32_t wv = (uint32_t)(acc >> (nb - 32u));
-                if (pos + 4u <= cap) { const uint32_t be = __builtin_bswap32(wv); __builtin_memcpy(out + pos, &be, 4); }
-                pos += 4u; nb -= 32u;
-            }
-            if (__builtin_expect(i + k + 1u == lenB || i + k + 1u == maxlen, 0)) {
-                if (len == i + k + 1u) {
-                    // ArithmeticCoder::flush -> ACWriter::flush(x2) (arithmetic_coder.rs:67-71, io.rs:91-100): first bit x2 >> 31 (= 1)
-                    // resolves the slot and the pending bits, then x2's next bits pad to a byte
-                    const uint2 f = fin[lane];
-                    const uint32_t x2f = ((f.x & 0x7FFFFFFFu) + f.y) | 0x80000000u;
-                    uint64_t fa = acc + 1ull; uint32_t fnb = nb, fpos = pos;
-                    const uint32_t idx = fnb & 7u;
-                    if (idx) { const uint32_t kk = 8u - idx; fa = (fa << kk) | ((x2f << 1) >> (32u - kk)); fnb += kk; }
-#pragma unroll 1
-                    while (fnb >= 8u) {
-                        const uint8_t v = (uint8_t)(fa >> (fnb - 8u));
-                        if (fpos < cap) out[fpos] = v;
-                        fpos += 1u; fnb -= 8u;
-                    }
-                    if (failed) { const uint32_t kk = atomicAdd(&a.flags[1], 1u); a.redo[kk] = b; }
-                    else { a.out_len[b] = fpos; if (fpos > cap) atomicOr(&a.flags[0], 1u); }
-                    cap = 0u;   // the lane keeps absorbing the tokens of clamped operands; nothing of it is stored any more
-                }
-            }
+            __asm__ volatile("" ::: "memory");
+            lds_store_u32(o_cons, need);
+            i += CH;
         }
-        __asm__ volatile("" ::: "memory");
-        lds_store_u32(o_cons, need);
     }
     if (dead && lane == 0) atomicOr(&a.flags[0], 2u);
 }
