@@ -303,8 +303,11 @@ __device__ __forceinline__ uint2 x4_step_c(uint32_t &x1, uint32_t &d, const uint
 typedef uint32_t w3_u32x3 __attribute__((ext_vector_type(3)));
 typedef __attribute__((address_space(3))) uint8_t w3_lds_u8;
 
+// L > 1 leaf streams: the mix makes the M-wave's chunk longer than the X-wave's, so TWO M-waves take alternate chunks
+// (workgroup = M0, M1, X, O: one wave per SIMD of the CU); with a single stream one M-wave keeps up (51 vs 72 cycles per step).
 template <int L>
-__global__ void __launch_bounds__(192) k_coder_x4(Coder3Args a) {
+__global__ void __launch_bounds__(L > 1 ? 256 : 192) k_coder_x4(Coder3Args a) {
+    constexpr uint32_t NM = L > 1 ? 2u : 1u;   // M-waves
     __shared__ X4Op opq[W3_X4_RING * 8u * 64u];    // M -> X: (z, z, q) per step           [ring byte][bit][lane]
     __shared__ uint2 tok[W3_X4_RING * 8u * 64u];   // X -> O: (x1n raw, s) per step        [ring byte][bit][lane]
     __shared__ uint2 fin[64];                      // X -> O: (x1 raw, d) after the lane's last step
@@ -328,8 +331,8 @@ __global__ void __launch_bounds__(192) k_coder_x4(Coder3Args a) {
     bool dead = false;
     constexpr uint32_t CH = W3_X4_CH, RING = W3_X4_RING;
 
-    if (wave == 0) {
-        // ------------------------------ M-wave ------------------------------
+    if (wave < NM) {
+        // ------------------------------ M-wave(s) ------------------------------
         // Operands are fetched several chunks ahead with unconditional loads (hipcc waits vmcnt(0) after a load it has to branch
         // around): a lane streams its own block, 64 B of probabilities per chunk, so every second chunk opens a new line
         // with a full memory latency, and a chunk is coded in under a microsecond.  Positions past the end of a lane's block
@@ -407,28 +410,35 @@ __global__ void __launch_bounds__(192) k_coder_x4(Coder3Args a) {
             }
 #endif
             __asm__ volatile("" ::: "memory");
+            if (NM > 1u && i > 0u) {   // chunks are published in order: the other M-wave's chunk before this one
+                (void)spin_until_ge<1>(m_prod, i, abortf, dead);
+                if (dead) return;
+            }
             lds_store_u32(m_prod, min(i + CH, maxlen));   // after the operands: the LDS executes one wave's operations in order
         };
-        // four buffers in flight: a chunk's loads are issued three chunk-times (~3 us) before its operands are built
+        // four buffers in flight per wave: a chunk's loads are issued three of this wave's chunk-times (>= 3 us) before its
+        // operands are built.  M-wave w takes the chunks w, w + NM, w + 2 NM, ...
+        constexpr uint32_t ST = NM * CH;   // bytes between two chunks of one M-wave
+        const uint32_t i0 = wave * CH;
         Buf bA, bB, bC, bD;
-        load(bA, 0u); load(bB, CH); load(bC, 2u * CH); load(bD, 3u * CH);
-        for (uint32_t i = 0; i < maxlen && !dead; i += 4u * CH) {
+        load(bA, i0); load(bB, i0 + ST); load(bC, i0 + 2u * ST); load(bD, i0 + 3u * ST);
+        for (uint32_t i = i0; i < maxlen && !dead; i += 4u * ST) {
             produce(bA, i);
-            load(bA, i + 4u * CH);
-            if (dead || i + CH >= maxlen) break;
-            produce(bB, i + CH);
-            load(bB, i + 5u * CH);
-            if (dead || i + 2u * CH >= maxlen) break;
-            produce(bC, i + 2u * CH);
-            load(bC, i + 6u * CH);
-            if (dead || i + 3u * CH >= maxlen) break;
-            produce(bD, i + 3u * CH);
-            load(bD, i + 7u * CH);
+            load(bA, i + 4u * ST);
+            if (dead || i + ST >= maxlen) break;
+            produce(bB, i + ST);
+            load(bB, i + 5u * ST);
+            if (dead || i + 2u * ST >= maxlen) break;
+            produce(bC, i + 2u * ST);
+            load(bC, i + 6u * ST);
+            if (dead || i + 3u * ST >= maxlen) break;
+            produce(bD, i + 3u * ST);
+            load(bD, i + 7u * ST);
         }
         return;
     }
 
-    if (wave == 1) {
+    if (wave == NM) {
         // ------------------------------ X-wave ------------------------------
 #if W3_X4_EXP & 64
         return;

@@ -509,11 +509,12 @@ static inline int twophase_encode(TwoPhaseWs &ws, hipStream_t s, const ParsedSpe
             default: hipLaunchKernelGGL(w3::k_coder_x3<4>, grid, blk, 0, s, c3); break;
             }
         } else {
+            const dim3 blk2(256);   // two M-waves when the leaves are mixed on the fly
             switch (ws.mix.n_src) {
             case 1: hipLaunchKernelGGL(w3::k_coder_x4<1>, grid, blk, 0, s, c3); break;
-            case 2: hipLaunchKernelGGL(w3::k_coder_x4<2>, grid, blk, 0, s, c3); break;
-            case 3: hipLaunchKernelGGL(w3::k_coder_x4<3>, grid, blk, 0, s, c3); break;
-            default: hipLaunchKernelGGL(w3::k_coder_x4<4>, grid, blk, 0, s, c3); break;
+            case 2: hipLaunchKernelGGL(w3::k_coder_x4<2>, grid, blk2, 0, s, c3); break;
+            case 3: hipLaunchKernelGGL(w3::k_coder_x4<3>, grid, blk2, 0, s, c3); break;
+            default: hipLaunchKernelGGL(w3::k_coder_x4<4>, grid, blk2, 0, s, c3); break;
             }
         }
         if (tm) tm->coder_bytes = (uint64_t)n * (16 * ws.mix.n_src + 1);
