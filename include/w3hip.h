@@ -42,10 +42,12 @@ enum {
  * Mirrors the compile-time composition done in init_model() (main.rs:146-152)
  * as a caller-owned, read-only POD: the model tree in POSTFIX order.
  *   leaf  W3_NODE_ORDERN : OrderN::new(bits, align)              models/ordern.rs:14-23
- *                          history = W3_HIST_RAW / W3_HIST_AC makes it
+ *                          history = W3_HIST_RAW / W3_HIST_AC / W3_HIST_HUFF makes it
  *                          OrderNEntropy::new(bits, align, hist) models/ordern_entropy.rs:15-24
  *                          (RawHistory history/raw_history.rs; ACHistory::new(max_bits,
- *                          StationaryModel::from_table(table)) history/ac_history.rs:16-19)
+ *                          StationaryModel::from_table(table)) history/ac_history.rs:16-19;
+ *                          HuffHistory history/huff_history.rs:9-76 with the two code tables
+ *                          spec->huff[node.reserved], see w3_huff_table below)
  *                          frozen=1 wraps it in FrozenModel      models/frozen.rs:7-11
  *                          Order0 == (11,3), Order1 == (19,3)    models/order0.rs, order1.rs
  *                          (bijective re-indexing, bin/cmp/main.rs:14-24)
@@ -67,11 +69,12 @@ enum {
  *                          max_bits = adaptation rate (1..15).  Only as a chain at the root.
  */
 enum { W3_NODE_ORDERN = 1, W3_NODE_BEST_OF_TWO = 2, W3_NODE_SLOT_STATE = 3, W3_NODE_APM = 4 };
-enum { W3_HIST_NONE = 0, W3_HIST_RAW = 1, W3_HIST_AC = 2 };
+enum { W3_HIST_NONE = 0, W3_HIST_RAW = 1, W3_HIST_AC = 2, W3_HIST_HUFF = 3 };
 enum { W3_APM_ORDER0 = 0, W3_APM_ORDER1 = 1 };
 #define W3_MAX_NODES  31
 #define W3_MAX_LEAVES 16
 #define W3_MAX_APM    4
+#define W3_MAX_HUFF   4
 
 typedef struct w3_node {
     uint8_t  kind;      /* W3_NODE_*                                  */
@@ -81,13 +84,24 @@ typedef struct w3_node {
     uint8_t  max_bits;  /* ACHistory max_bits (0..32)                 */
     uint8_t  frozen;    /* 1 = FrozenModel wrapper                    */
     uint8_t  log_cells; /* SLOT_STATE: HashMap log_cell_count (1..24) */
-    uint8_t  reserved;
+    uint8_t  reserved;  /* W3_HIST_HUFF: index into spec->huff         */
     uint16_t table[8];  /* StationaryModel table, index 0 = MSB       */
 } w3_node;
+
+/* The two code tables of a HuffHistory (history/huff_history.rs:9-15): (code, len) of every byte and of every
+ * partial-byte symbol (1 << bit_len | the bit_len bits seen), codes already bit-reversed as HuffHistory::new leaves
+ * them (:21-25, :38-42).  Caller-supplied like StationaryModel's table: w3_huff_tables() builds them the way
+ * HuffHistory::new does, or pass tables produced by the reference itself. */
+typedef struct w3_huff_table {
+    uint16_t code[256];     uint8_t len[256];
+    uint16_t rem_code[256]; uint8_t rem_len[256];
+} w3_huff_table;
 
 typedef struct w3_model_spec {
     uint32_t n_nodes;
     w3_node  nodes[W3_MAX_NODES];
+    uint32_t n_huff;               /* table sets referenced by W3_HIST_HUFF leaves (<= W3_MAX_HUFF) */
+    const w3_huff_table *huff;     /* caller-owned, read-only; may be NULL when n_huff == 0          */
 } w3_model_spec;
 
 /* ---- lifecycle ------------------------------------------------------------ */
@@ -174,6 +188,15 @@ int w3_predict_blocks(w3_ctx *ctx, const w3_model_spec *spec,
  * Host-side table preparation for ACHistory: 8 Counters by bit position walked
  * over `buf`, table[i] = p().  Model construction, not the hot path.          */
 int w3_stationary_table(const uint8_t *buf, size_t n, uint16_t table[8]);
+
+/* ---- HuffHistory::new(buf, huff_size, rem_huff_size) (history/huff_history.rs:17-55) --------
+ * Host-side table preparation: byte histogram (helpers.rs:30-36) -> length-limited Huffman code lengths
+ * (entropy_coding/package_merge.rs:1-84) -> canonical codes (:87-117), bit-reversed; the same for the 255 partial-byte
+ * symbols.  The reference sorts with sort_unstable_by (:9, :92): among EQUAL counts / lengths its order is an
+ * implementation detail of Rust's unstable sort; this implementation takes them in ascending symbol order (the order the
+ * reference's own tests show for small inputs).  Model construction, not the hot path.
+ * Returns W3_E_INVALID for the reference's panics (no symbols, max length > 32 or too small for the alphabet).      */
+int w3_huff_tables(const uint8_t *buf, size_t n, uint8_t huff_size, uint8_t rem_huff_size, w3_huff_table *out);
 
 /* ---- read-only tables of the CM kernels (host-side; for known-answer tests) -----------
  * w3_state_table: NaiveStateTable (state_table/naive.rs:7-115) as 3963 rows of

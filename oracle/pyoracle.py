@@ -112,9 +112,13 @@ class Stationary(C.Structure):
     _fields_ = [("table", C.c_uint16 * 8), ("alignment", C.c_uint8)]
 
 
+class HuffTables(C.Structure):
+    _fields_ = [("code", C.c_uint16 * 256), ("len", C.c_uint8 * 256), ("rem_code", C.c_uint16 * 256), ("rem_len", C.c_uint8 * 256)]
+
+
 class History(C.Structure):
     _fields_ = [("kind", C.c_int), ("raw_bits", C.c_uint32), ("pos", C.c_uint64), ("bits", C.c_uint64),
-                ("max_bits", C.c_uint8), ("model", Stationary)]
+                ("max_bits", C.c_uint8), ("model", Stationary), ("compressed_bits", C.c_uint32), ("huff", HuffTables)]
 
 
 class Cell(C.Structure):
@@ -262,6 +266,55 @@ class ACHistory:
 
 
 lib.w3o_history_hash.restype = C.c_uint32
+
+
+# ---- length-limited Huffman (entropy_coding/package_merge.rs) and HuffHistory (history/huff_history.rs) -------------
+PM_ERRORS = {-1: "No symbols provided", -2: "Max length is too big", -3: "Max length is too small"}
+
+
+def package_merge(counts, max_len):
+    """package_merge.rs:1-29 (ties sorted stably; see w3_oracle.h).  Raises AssertionError with the reference's panic text."""
+    c = (C.c_uint32 * max(len(counts), 1))(*counts)
+    out = (C.c_uint8 * max(len(counts), 1))()
+    rc = lib.w3o_package_merge(c, len(counts), C.c_uint8(max_len), out)
+    if rc:
+        raise AssertionError(PM_ERRORS[rc])
+    return list(out[: len(counts)])
+
+
+def canonical(code_lens):
+    """package_merge.rs:87-117 -> [(code, len)]"""
+    n = len(code_lens)
+    cl = (C.c_uint8 * max(n, 1))(*code_lens)
+    codes = (C.c_uint16 * max(n, 1))()
+    lens = (C.c_uint8 * max(n, 1))()
+    lib.w3o_canonical(cl, n, codes, lens)
+    return [(codes[i], lens[i]) for i in range(n)]
+
+
+def huff_tables(buf, huff_size, rem_huff_size):
+    """HuffHistory::new's two tables (huff_history.rs:17-43) -> HuffTables"""
+    a, p = _buf(buf)
+    t = HuffTables()
+    rc = lib.w3o_huff_tables_new(p, len(a), C.c_uint8(huff_size), C.c_uint8(rem_huff_size), C.byref(t))
+    if rc:
+        raise AssertionError(PM_ERRORS[rc])
+    return t
+
+
+class HuffHistory:
+    """HuffHistory::new(buf, huff_size, rem_huff_size) (history/huff_history.rs:17-55), or from ready tables."""
+
+    def __init__(self, buf=None, huff_size=12, rem_huff_size=12, tables=None):
+        self.tables = tables if tables is not None else huff_tables(buf, huff_size, rem_huff_size)
+        self.h = History()
+        lib.w3o_history_huff(C.byref(self.h), C.byref(self.tables))
+
+    def update(self, bit):
+        lib.w3o_history_update(C.byref(self.h), C.c_uint8(bit))
+
+    def hash(self):
+        return lib.w3o_history_hash(C.byref(self.h))
 
 
 class Model:

@@ -248,6 +248,123 @@ static inline uint16_t stationary_predict(w3o_stationary *m) { /* :54-57: walks 
 }
 
 /* ================================================================== */
+/* Length-limited Huffman  entropy_coding/package_merge.rs             */
+/* ================================================================== */
+
+typedef struct { uint32_t sym, key; } pm_item;
+static void pm_stable_sort(pm_item *a, size_t n) {   /* insertion sort: stable, n <= 256 */
+    for (size_t i = 1; i < n; i++) {
+        pm_item x = a[i];
+        size_t j = i;
+        while (j > 0 && a[j - 1].key > x.key) { a[j] = a[j - 1]; j--; }
+        a[j] = x;
+    }
+}
+
+/* package_merge_sorted (:34-84): `a` ascending; returns the code length of every element */
+static void pm_sorted(const uint32_t *a, size_t n, uint8_t max_len, uint8_t *code_lens) {
+    if (n == 1) { code_lens[0] = 0; return; }                    /* 2n-2 = 0 relevant symbols: every length stays 0 */
+    const size_t cap = 2 * n - 1;
+    uint32_t *depths = (uint32_t *)calloc(cap, sizeof(uint32_t));
+    uint64_t *prev = (uint64_t *)malloc(cap * sizeof(uint64_t)), *curr = (uint64_t *)malloc(cap * sizeof(uint64_t));
+    size_t nprev = n, ncurr = 0;
+    for (size_t i = 0; i < n; i++) prev[i] = a[i];
+    for (unsigned depth = 1; depth < max_len; depth++) {         /* :40-63 */
+        const uint32_t mask = 1u << depth;
+        size_t si = 0, pi = 0;
+        const size_t npk = nprev / 2;                            /* chunks_exact(2) */
+        ncurr = 0;
+        for (;;) {
+            int is_package;
+            if (pi >= npk && si >= n) break;
+            if (pi >= npk) is_package = 0;
+            else if (si >= n) is_package = 1;
+            else is_package = (prev[2 * pi] + prev[2 * pi + 1]) <= a[si];
+            if (is_package) { depths[ncurr] |= mask; curr[ncurr++] = prev[2 * pi] + prev[2 * pi + 1]; pi++; }
+            else curr[ncurr++] = a[si++];
+        }
+        uint64_t *t = prev; prev = curr; curr = t;
+        nprev = ncurr;
+    }
+    memset(code_lens, 0, n);
+    size_t relevant = 2 * n - 2;                                  /* :66-82 */
+    for (int depth = (int)max_len - 1; depth >= 0; depth--) {
+        if (relevant == 0) break;
+        const uint32_t mask = 1u << depth;
+        size_t sym = 0;
+        for (size_t i = 0; i < relevant && i < cap; i++)
+            if ((depths[i] & mask) == 0) { code_lens[sym] += 1; sym++; }
+        relevant = (relevant - sym) * 2;
+    }
+    free(depths); free(prev); free(curr);
+}
+
+int w3o_package_merge(const uint32_t *counts, size_t n, uint8_t max_len, uint8_t *code_lens) { /* :1-29 */
+    pm_item *it = (pm_item *)malloc((n ? n : 1) * sizeof(pm_item));
+    size_t m = 0;
+    for (size_t i = 0; i < n; i++)
+        if (counts[i] != 0) { it[m].sym = (uint32_t)i; it[m].key = counts[i]; m++; }
+    pm_stable_sort(it, m);                                        /* :9 sort_unstable_by: ties in ascending symbol order here */
+    int rc = W3O_PM_OK;
+    if (m == 0) rc = W3O_PM_NO_SYMBOLS;                           /* :12 */
+    else if (max_len > 32) rc = W3O_PM_MAX_LEN_TOO_BIG;           /* :13 */
+    else if (max_len < 32 && m > ((size_t)1 << max_len)) rc = W3O_PM_MAX_LEN_TOO_SMALL;   /* :14-17 */
+    if (rc) { free(it); return rc; }
+    uint32_t *sorted = (uint32_t *)malloc(m * sizeof(uint32_t));
+    uint8_t *lens = (uint8_t *)malloc(m);
+    for (size_t i = 0; i < m; i++) sorted[i] = it[i].key;
+    pm_sorted(sorted, m, max_len, lens);
+    memset(code_lens, 0, n);
+    for (size_t i = 0; i < m; i++) code_lens[it[i].sym] = lens[i]; /* :21-27 */
+    free(it); free(sorted); free(lens);
+    return W3O_PM_OK;
+}
+
+void w3o_canonical(const uint8_t *code_lens, size_t n, uint16_t *codes_out, uint8_t *lens_out) { /* :87-117 */
+    pm_item *it = (pm_item *)malloc((n ? n : 1) * sizeof(pm_item));
+    size_t m = 0;
+    unsigned max_len = 0;
+    for (size_t i = 0; i < n; i++) {
+        if (code_lens[i] > max_len) max_len = code_lens[i];
+        if (code_lens[i] != 0) { it[m].sym = (uint32_t)i; it[m].key = code_lens[i]; m++; }
+    }
+    pm_stable_sort(it, m);                                        /* :92 sort_unstable_by on the lengths */
+    uint16_t count_lens[260], codes[260];
+    memset(count_lens, 0, sizeof count_lens); memset(codes, 0, sizeof codes);
+    for (size_t i = 0; i < m; i++) count_lens[it[i].key] += 1;
+    for (unsigned i = 0; i < max_len; i++) codes[i + 1] = (uint16_t)((codes[i] + count_lens[i]) << 1);   /* :107-109 */
+    for (size_t i = 0; i < n; i++) { codes_out[i] = 0; lens_out[i] = 0; }
+    for (size_t i = 0; i < m; i++) {                              /* :112-115 */
+        const unsigned l = it[i].key;
+        codes_out[it[i].sym] = codes[l]; lens_out[it[i].sym] = (uint8_t)l;
+        codes[l] = (uint16_t)(codes[l] + 1);
+    }
+    free(it);
+}
+
+static uint16_t rev16(uint16_t v) { uint16_t r = 0; for (int i = 0; i < 16; i++) r = (uint16_t)((r << 1) | ((v >> i) & 1)); return r; }
+
+int w3o_huff_tables_new(const uint8_t *buf, size_t n, uint8_t huff_size, uint8_t rem_huff_size, w3o_huff_tables *out) { /* huff_history.rs:17-55 */
+    uint32_t counts[256], rem_counts[256];
+    uint8_t lens[256];
+    memset(counts, 0, sizeof counts); memset(rem_counts, 0, sizeof rem_counts);
+    for (size_t i = 0; i < n; i++) counts[buf[i]] += 1;           /* helpers.rs:30-36 */
+    int rc = w3o_package_merge(counts, 256, huff_size, lens);
+    if (rc) return rc;
+    w3o_canonical(lens, 256, out->code, out->len);
+    for (int i = 0; i < 256; i++)                                  /* :21-25: reverse_bits().overflowing_shr(16 - len): amount taken mod 16 */
+        out->code[i] = (uint16_t)(rev16(out->code[i]) >> ((16u - out->len[i]) & 15u));
+    for (int byte = 0; byte < 256; byte++)                         /* :27-34 */
+        for (int bit_len = 0; bit_len < 8; bit_len++) rem_counts[(1 << bit_len) | (byte >> (8 - bit_len))] += counts[byte];
+    rc = w3o_package_merge(rem_counts, 256, rem_huff_size, lens);
+    if (rc) return rc;
+    w3o_canonical(lens, 256, out->rem_code, out->rem_len);
+    for (int i = 0; i < 256; i++)
+        out->rem_code[i] = (uint16_t)(rev16(out->rem_code[i]) >> ((16u - out->rem_len[i]) & 15u));
+    return W3O_PM_OK;
+}
+
+/* ================================================================== */
 /* History  history/raw_history.rs, history/ac_history.rs              */
 /* ================================================================== */
 
@@ -258,16 +375,33 @@ void w3o_history_ac(w3o_history *h, uint8_t max_bits, const w3o_stationary *m) {
     h->max_bits = max_bits;
     h->model = *m;
 }
+void w3o_history_huff(w3o_history *h, const w3o_huff_tables *t) { /* huff_history.rs:44-50 */
+    memset(h, 0, sizeof *h);
+    h->kind = W3O_HIST_HUFF;
+    h->huff = *t;
+}
 void w3o_history_update(w3o_history *h, uint8_t bit) {
     if (h->kind == W3O_HIST_RAW) { /* raw_history.rs:14-16 */
         h->raw_bits = (h->raw_bits << 1) | bit;
-    } else { /* ac_history.rs:23-26 */
+    } else { /* ac_history.rs:23-26, huff_history.rs:59-62 */
         h->bits = (h->bits << 1) | bit;
         h->pos += 1;
     }
 }
 uint32_t w3o_history_hash(w3o_history *h) {
     if (h->kind == W3O_HIST_RAW) return h->raw_bits; /* raw_history.rs:18-20 */
+    if (h->kind == W3O_HIST_HUFF) { /* huff_history.rs:64-76 */
+        const unsigned alignment = (unsigned)(h->pos & 7);
+        if (alignment == 0) {   /* a byte has just been completed: append its code (u32: old bits fall off the top) */
+            const uint8_t byte = (uint8_t)(h->bits & 255);
+            const unsigned len = h->huff.len[byte];
+            h->compressed_bits = (len >= 32 ? 0u : (h->compressed_bits << len)) | h->huff.code[byte];
+        }
+        const uint32_t mask = (1u << alignment) - 1u;
+        const uint8_t rem_sym = (uint8_t)((h->bits & mask) | (1u << alignment));
+        const unsigned len = h->huff.rem_len[rem_sym];
+        return (len >= 32 ? 0u : (h->compressed_bits << len)) | h->huff.rem_code[rem_sym];
+    }
     /* ac_history.rs:28-46 */
     w3o_ac ac; w3o_sink w;
     w3o_ac_new_coder(&ac);

@@ -82,16 +82,34 @@ void w3o_stationary_from_table(w3o_stationary *m, const uint16_t table[8]);
 void w3o_stationary_for_book1(w3o_stationary *m);
 void w3o_stationary_for_enwik7(w3o_stationary *m);
 
-/* History  history/{mod,raw_history,ac_history}.rs */
-enum { W3O_HIST_RAW = 0, W3O_HIST_AC = 1 };
+/* Length-limited Huffman (entropy_coding/package_merge.rs): host-side table preparation of HuffHistory.
+ * The reference sorts with sort_unstable_by (package_merge.rs:9, :92): the order of EQUAL keys is an implementation detail
+ * of Rust's unstable sort (insertion sort = stable up to 20 elements, pattern-defeating quicksort beyond).  This
+ * restatement sorts STABLY (ties in ascending symbol order): identical whenever the reference's result does not depend
+ * on the tie order — all 12 reference tests (package_merge.rs:127-267) are of that kind, see tests/test_oracle_kats.py —
+ * and a documented choice otherwise.  Return codes mirror the reference's asserts (:13-18). */
+enum { W3O_PM_OK = 0, W3O_PM_NO_SYMBOLS = -1, W3O_PM_MAX_LEN_TOO_BIG = -2, W3O_PM_MAX_LEN_TOO_SMALL = -3 };
+int  w3o_package_merge(const uint32_t *counts, size_t n, uint8_t max_len, uint8_t *code_lens /* [n] */);      /* :1-29, :34-84 */
+void w3o_canonical(const uint8_t *code_lens, size_t n, uint16_t *codes /* [n] */, uint8_t *lens /* [n] */);    /* :87-117 */
+
+/* The two code tables of a HuffHistory (history/huff_history.rs:9-15): (code, len) per byte and per partial-byte symbol
+ * (1 << bit_len | top bits), codes bit-reversed as at :21-25 / :38-42. */
+typedef struct w3o_huff_tables { uint16_t code[256]; uint8_t len[256]; uint16_t rem_code[256]; uint8_t rem_len[256]; } w3o_huff_tables;
+int  w3o_huff_tables_new(const uint8_t *buf, size_t n, uint8_t huff_size, uint8_t rem_huff_size, w3o_huff_tables *out);   /* HuffHistory::new :17-55 */
+
+/* History  history/{mod,raw_history,ac_history,huff_history}.rs */
+enum { W3O_HIST_RAW = 0, W3O_HIST_AC = 1, W3O_HIST_HUFF = 2 };
 typedef struct w3o_history {
     int kind;
     uint32_t raw_bits;                       /* RawHistory */
-    uint64_t pos, bits; uint8_t max_bits;    /* ACHistory  */
+    uint64_t pos, bits; uint8_t max_bits;    /* ACHistory (pos, bits also HuffHistory) */
     w3o_stationary model;
+    uint32_t compressed_bits;                /* HuffHistory */
+    w3o_huff_tables huff;
 } w3o_history;
 void     w3o_history_raw(w3o_history *h);
 void     w3o_history_ac(w3o_history *h, uint8_t max_bits, const w3o_stationary *m);
+void     w3o_history_huff(w3o_history *h, const w3o_huff_tables *t);
 void     w3o_history_update(w3o_history *h, uint8_t bit);
 uint32_t w3o_history_hash(w3o_history *h);
 

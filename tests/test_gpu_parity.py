@@ -17,8 +17,30 @@ def ctx():
     c.close()
 
 
+_HUFF = {}
+
+
+def huff_pair(oracle, key="text"):
+    """One HuffHistory table set on both sides, from the oracle's package-merge (the device gets the tables across the ABI):
+    trained on text (typical code lengths) or on a skewed buffer (1-bit codes, zero-count symbols: len 0)."""
+    if key not in _HUFF:
+        train = markov_text(40000, seed=61) if key == "text" else (b"e" * 30000 + b" " * 9000 + b"tao" * 700)
+        t = oracle.huff_tables(train, 12, 12)
+        dev = w3.HuffHistory.from_tables(list(t.code), list(t.len), list(t.rem_code), list(t.rem_len))
+        _HUFF[key] = (dev, t)
+    return _HUFF[key]
+
+
 def pair(oracle, name):
     """(device model, oracle model factory) for a named configuration."""
+    if name.startswith("huff"):
+        _, bits, key = name.split("_")
+        dev_h, orc_t = huff_pair(oracle, key)
+        if bits == "mix":
+            return (lambda: w3.BestOfTwoModel(w3.Order0(), w3.BestOfTwoModel(w3.OrderNEntropy(11, 3, dev_h), w3.OrderNEntropy(10, 3, huff_pair(oracle, "skew")[0]))),
+                    lambda: oracle.BestOfTwoModel(oracle.Order0(), oracle.BestOfTwoModel(oracle.OrderNEntropy(11, 3, oracle.HuffHistory(tables=orc_t)),
+                                                                                         oracle.OrderNEntropy(10, 3, oracle.HuffHistory(tables=huff_pair(oracle, "skew")[1])))))
+        return (lambda: w3.OrderNEntropy(int(bits), 3, dev_h), lambda: oracle.OrderNEntropy(int(bits), 3, oracle.HuffHistory(tables=orc_t)))
     book1 = [1, 50188, 62497, 15819, 22545, 31499, 22988, 29616]
     enwik7 = [752, 50314, 58928, 21421, 24680, 30788, 24297, 32530]
     edge = [0, 65535, 1, 32768, 0, 65535, 12345, 1]
@@ -80,13 +102,14 @@ def check_blocks(ctx, oracle, name, data, bs, path):
 
 
 ALL = ["order0", "order1", "order2", "ordern_12_0", "ordern_14_4", "ordern_9_1", "ordern_8_3", "ordern_22_2", "ordern_30_3",
-       "raw_16_3", "main_default", "ac_19_3_enwik7", "ac_10_2_mb0", "frozen0", "best01", "best012", "best_right"]
+       "raw_16_3", "main_default", "ac_19_3_enwik7", "ac_10_2_mb0", "frozen0", "best01", "best012", "best_right",
+       "huff_11_text", "huff_19_text", "huff_24_text", "huff_11_skew", "huff_mix_text"]
 
 
 TWOPHASE = ["order0", "order1", "order2", "ordern_8_3", "ordern_5_3", "ordern_3_3", "ordern_10_3", "main_default", "ac_7_3_mb4",
             "ac_11_3_mb16", "ac_edge_table_mb8", "ac_edge_table_mb32", "frozen0", "best01", "best012", "best_right", "best_frozen_first",
-            "best_ac_wide"]
-NOT_TWOPHASE = ["ordern_12_0", "ordern_14_4", "ordern_22_2", "ordern_30_3", "raw_16_3", "ac_19_3_enwik7"]
+            "best_ac_wide", "huff_11_text", "huff_7_text", "huff_11_skew", "huff_mix_text"]
+NOT_TWOPHASE = ["ordern_12_0", "ordern_14_4", "ordern_22_2", "ordern_30_3", "raw_16_3", "ac_19_3_enwik7", "huff_19_text"]
 
 
 def test_counter_p_exhaustive(ctx):

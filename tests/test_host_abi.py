@@ -34,7 +34,8 @@ def test_exports_match_header(lib):
 
 def test_struct_layout(lib):
     assert C.sizeof(L.Node) == 24
-    assert C.sizeof(L.ModelSpec) == 4 + 24 * 31 + 0 or C.sizeof(L.ModelSpec) == 748
+    assert C.sizeof(L.HuffTable) == 1536
+    assert C.sizeof(L.ModelSpec) == 760        # 4 + 24 * 31 + n_huff (4) + pointer (8); static_assert'ed in w3hip.hip too
 
 
 def test_spec_building(lib):
@@ -108,3 +109,39 @@ def test_ac_history_cached_is_ac_history():
     a = w3.OrderNEntropy(20, 3, w3.ACHistory(8, w3.StationaryModel.for_book1())).spec()
     b = w3.OrderNEntropy(20, 3, w3.ACHistoryCached.new(8, w3.StationaryModel.for_book1(), 24)).spec()
     assert bytes(a) == bytes(b)
+
+
+def test_huff_tables_match_oracle(lib, oracle):
+    """w3_huff_tables (HuffHistory::new's table prep, host-side) against the oracle's package-merge + canonical codes — both
+    take equal counts in ascending symbol order — on typical, tie-heavy and degenerate buffers; error codes for the
+    reference's asserts."""
+    import ctypes as C
+    import numpy as np
+    from tests.synth import lcg_text, markov_text
+    bufs = [markov_text(50000, seed=71), lcg_text(3000, seed=72), bytes(range(256)) * 3, b"ab" * 500 + b"c", b"zzzz"]
+    for buf in bufs:
+        for hs, rs in ((12, 12), (9, 10), (16, 15)):
+            if len(set(buf)) > (1 << hs):
+                continue
+            t = L.HuffTable()
+            a = np.frombuffer(buf, dtype=np.uint8)
+            assert lib.w3_huff_tables(a.ctypes.data_as(C.c_void_p), len(a), hs, rs, C.byref(t)) == 0
+            want = oracle.huff_tables(buf, hs, rs)
+            for f in ("code", "len", "rem_code", "rem_len"):
+                assert list(getattr(t, f)) == list(getattr(want, f)), (f, hs, rs)
+    t = L.HuffTable()
+    a = np.frombuffer(bytes(range(256)), dtype=np.uint8)
+    assert lib.w3_huff_tables(a.ctypes.data_as(C.c_void_p), 256, 7, 12, C.byref(t)) == L.W3_E_INVALID      # "Max length is too small"
+    assert lib.w3_huff_tables(a.ctypes.data_as(C.c_void_p), 0, 12, 12, C.byref(t)) == L.W3_E_INVALID        # "No symbols provided"
+    assert lib.w3_huff_tables(a.ctypes.data_as(C.c_void_p), 256, 33, 12, C.byref(t)) == L.W3_E_INVALID      # "Max length is too big"
+
+
+def test_huff_spec_validation(lib):
+    import weath3rb0i_amd as w3
+    h = w3.HuffHistory(b"hello world, hello huffman", 12, 12)
+    s = w3.OrderNEntropy(11, 3, h).spec()
+    assert s.n_huff == 1 and s.nodes[0].history == L.W3_HIST_HUFF and s.nodes[0].reserved == 0
+    s2 = w3.BestOfTwoModel(w3.OrderNEntropy(11, 3, h), w3.OrderNEntropy(19, 3, w3.HuffHistory(b"other text", 8, 8))).spec()
+    assert s2.n_huff == 2 and [s2.nodes[0].reserved, s2.nodes[1].reserved] == [0, 1]
+    s.n_huff = 0                                           # a HUFF leaf without its tables is malformed
+    assert lib.w3_spec_validate(s) == L.W3_E_INVALID

@@ -7,6 +7,8 @@ Vectors are re-expressed from the reference's unit tests:
 import hashlib
 
 import numpy as np
+import os
+
 import pytest
 
 from tests.synth import lcg_text
@@ -268,3 +270,100 @@ def test_block_mode(oracle):
     assert back.tobytes() == d
     out0, lens0 = oracle.encode_blocks(oracle.Order0(), b"", bs)
     assert len(out0) == 0 and len(lens0) == 0
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Length-limited Huffman + HuffHistory (entropy_coding/package_merge.rs:127-267, history/huff_history.rs)
+# ---------------------------------------------------------------------------------------------------------------------
+def _pm_kats():
+    import json
+    return json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "package_merge_kats.json")))
+
+
+def _tie_order_free(counts, lens):
+    """The reference sorts with sort_unstable_by: a known answer pins the oracle (which sorts stably) only if it does not depend on
+    the order of equal counts, i.e. if symbols with equal counts got equal lengths."""
+    by = {}
+    for c, l in zip(counts, lens):
+        if c:
+            by.setdefault(c, set()).add(l)
+    return all(len(v) == 1 for v in by.values())
+
+
+def test_package_merge_reference_tests(oracle):
+    """The 9 value tests of package_merge.rs (:128-208) — none of them depends on the tie order (checked) — and its three
+    should_panic tests (:173-189) as error codes."""
+    pm = oracle.package_merge
+    cases = [([1, 32, 16, 4, 8, 2, 1], 8, [6, 1, 2, 4, 3, 5, 6]), ([1, 32, 16, 4, 8, 2, 1], 5, [5, 1, 2, 5, 3, 5, 5]),        # sellibitze_example
+             ([270, 20, 10, 0, 1, 6, 1], 4, [1, 2, 4, 0, 4, 4, 4]), ([10, 20, 270, 0, 1, 6, 1], 4, [4, 2, 1, 0, 4, 4, 4])]    # stephan_brumme_example
+    k = _pm_kats()
+    cases.append((k["book1_counts"], 12, k["book1_code_lens_max12"]))                                                         # book1
+    for counts, max_len, want in cases:
+        assert pm(counts, max_len) == want
+        assert _tie_order_free(counts, want)
+    for max_len in (1, 2, 8):                                                                                                 # single_symbol, two_symbols
+        assert pm([1], max_len) == [0] and pm([10], max_len) == [0]
+        assert pm([1, 1], max_len) == [1, 1] and pm([10, 10], max_len) == [1, 1] and pm([1, 100], max_len) == [1, 1]
+    for args, msg in (([], 8), "No symbols provided"), (([1, 1, 2, 4, 8, 16, 32], 33), "Max length is too big"), (([1, 1, 2, 4, 8, 16, 32], 2), "Max length is too small"):
+        with pytest.raises(AssertionError, match=msg):
+            pm(*args)
+
+
+def test_canonical_reference_tests(oracle):
+    """package_merge.rs:191-266.  check_canonical_unsorted pins ascending symbol order among equal lengths for a 5-element
+    input (Rust's unstable sort is an insertion sort, i.e. stable, up to 20 elements); for the 256-entry tables of HuffHistory
+    the reference's order among equal lengths is Rust's pattern-defeating quicksort's — this oracle keeps ascending symbol order."""
+    assert oracle.canonical([2, 2, 2, 3, 3]) == [(0, 2), (1, 2), (2, 2), (6, 3), (7, 3)]
+    assert oracle.canonical([2, 3, 2, 3, 2]) == [(0, 2), (6, 3), (1, 2), (7, 3), (2, 2)]
+    for code, ln in oracle.canonical(_pm_kats()["canonical_zeroes_code_lens"]):
+        assert code <= (1 << ln)
+    lens = oracle.package_merge([1 << x for x in range(18)], 16)                                                              # test_canonical_max_len
+    want = [(0b1111111111111100, 16), (0b1111111111111101, 16), (0b1111111111111110, 16), (0b1111111111111111, 16), (0b11111111111110, 14),
+            (0b1111111111110, 13), (0b111111111110, 12), (0b11111111110, 11), (0b1111111110, 10), (0b111111110, 9), (0b11111110, 8),
+            (0b1111110, 7), (0b111110, 6), (0b11110, 5), (0b1110, 4), (0b110, 3), (0b10, 2), (0b0, 1)]
+    assert oracle.canonical(lens) == want
+
+
+def _huff_hash_py(tables, data):
+    """HuffHistory::update + hash (huff_history.rs:58-76) restated a second time in plain Python: the hash after every bit."""
+    bits = pos = cb = 0
+    out = []
+    for byte in data:
+        for j in range(8):
+            bit = (byte >> (7 - j)) & 1
+            bits = ((bits << 1) | bit) & (2**64 - 1)
+            pos += 1
+            al = pos & 7
+            if al == 0:
+                b = bits & 255
+                cb = ((cb << tables.len[b]) | tables.code[b]) & 0xFFFFFFFF
+            rem = (bits & ((1 << al) - 1)) | (1 << al)
+            out.append(((cb << tables.rem_len[rem]) | tables.rem_code[rem]) & 0xFFFFFFFF)
+    return out
+
+
+def test_huff_history_hash_and_model(oracle):
+    from tests.synth import markov_text
+    train = markov_text(30000, seed=51)
+    t = oracle.huff_tables(train, 12, 12)
+    # prefix-free, bit-reversed canonical codes: every used byte has a code of <= 12 bits, Kraft sum <= 1
+    used = [b for b in range(256) if t.len[b]]
+    assert set(used) == set(train) and max(t.len[b] for b in used) <= 12
+    assert sum(2.0 ** -t.len[b] for b in used) <= 1.0 + 1e-9
+    rev = lambda v, n: int(format(v, "0%db" % n)[::-1], 2) if n else 0
+    codes = sorted((format(rev(t.code[b], t.len[b]), "0%db" % t.len[b]) for b in used))
+    assert all(not codes[i + 1].startswith(codes[i]) for i in range(len(codes) - 1))
+    data = markov_text(3000, seed=52)
+    h = oracle.HuffHistory(tables=t)
+    got = []
+    for byte in data:
+        for j in range(8):
+            h.update((byte >> (7 - j)) & 1)
+            got.append(h.hash())
+    assert got == _huff_hash_py(t, data)
+    # the model on top: OrderNEntropy(B, 3, HuffHistory) round trips and differs from RawHistory's stream
+    for bits in (11, 19, 24):
+        mk = lambda: oracle.OrderNEntropy(bits, 3, oracle.HuffHistory(tables=t))
+        s = oracle.encode_stream(mk(), data)
+        assert oracle.decode_stream(mk(), s, len(data)) == data
+        assert s != oracle.encode_stream(oracle.OrderNEntropy(bits, 3, oracle.RawHistory()), data)

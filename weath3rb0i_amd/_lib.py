@@ -10,7 +10,8 @@ W3_MAX_NODES = 31
 W3_NODE_ORDERN, W3_NODE_BEST_OF_TWO, W3_NODE_SLOT_STATE, W3_NODE_APM = 1, 2, 3, 4
 W3_APM_ORDER0, W3_APM_ORDER1 = 0, 1
 W3_MAX_APM = 4
-W3_HIST_NONE, W3_HIST_RAW, W3_HIST_AC = 0, 1, 2
+W3_HIST_NONE, W3_HIST_RAW, W3_HIST_AC, W3_HIST_HUFF = 0, 1, 2, 3
+W3_MAX_HUFF = 4
 W3_OK, W3_E_INVALID, W3_E_NOSPACE, W3_E_HIP, W3_E_UNSUPPORTED, W3_E_NOMEM, W3_E_FORMAT = 0, -1, -2, -3, -4, -5, -6
 W3_OPT_PATH, W3_OPT_TIMING, W3_OPT_CODER, W3_OPT_ACC_LIMIT, W3_OPT_DEBUG_STAMPS, W3_OPT_PARTS, W3_OPT_VARIANT, W3_OPT_SLOT_BUDGET_MB = 1, 2, 3, 4, 5, 6, 7, 8
 W3_VAR_NO_LDS_ATOMICS, W3_VAR_PARTITION4, W3_VAR_NO_CHAINED_PARTITION, W3_VAR_CM_UNSTAGED, W3_VAR_NO_SIDE_STREAM = 1, 2, 4, 8, 16
@@ -22,8 +23,12 @@ class Node(C.Structure):
                 ("max_bits", C.c_uint8), ("frozen", C.c_uint8), ("log_cells", C.c_uint8), ("reserved", C.c_uint8), ("table", C.c_uint16 * 8)]
 
 
+class HuffTable(C.Structure):
+    _fields_ = [("code", C.c_uint16 * 256), ("len", C.c_uint8 * 256), ("rem_code", C.c_uint16 * 256), ("rem_len", C.c_uint8 * 256)]
+
+
 class ModelSpec(C.Structure):
-    _fields_ = [("n_nodes", C.c_uint32), ("nodes", Node * W3_MAX_NODES)]
+    _fields_ = [("n_nodes", C.c_uint32), ("nodes", Node * W3_MAX_NODES), ("n_huff", C.c_uint32), ("huff", C.POINTER(HuffTable))]
 
 
 class Timing(C.Structure):
@@ -37,7 +42,7 @@ EXPORTS = [
     "w3_abi_version", "w3_strerror", "w3_last_error", "w3_ctx_create", "w3_ctx_destroy", "w3_spec_validate",
     "w3_ctx_set_option", "w3_max_compressed_size", "w3_encode_blocks", "w3_decode_blocks", "w3_encode_blocks_device",
     "w3_decode_blocks_device", "w3_compress_stream", "w3_decompress_stream", "w3_predict_blocks", "w3_stationary_table",
-    "w3_get_timing", "w3_selftest_counter_p", "w3_debug_get_stamps", "w3_state_table", "w3_stretch_squash",
+    "w3_get_timing", "w3_selftest_counter_p", "w3_debug_get_stamps", "w3_state_table", "w3_stretch_squash", "w3_huff_tables",
 ]
 
 _lib = None
@@ -85,5 +90,6 @@ def load():
     lib.w3_get_timing.argtypes = [vp, C.POINTER(Timing)]
     lib.w3_state_table.argtypes = [vp]
     lib.w3_stretch_squash.argtypes = [vp, vp]
+    lib.w3_huff_tables.argtypes = [vp, sz, C.c_uint8, C.c_uint8, C.POINTER(HuffTable)]
     _lib = lib
     return lib

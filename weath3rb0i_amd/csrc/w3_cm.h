@@ -144,6 +144,7 @@ __global__ void __launch_bounds__(64) k_cm(CmArgs a) {
     }
 
     uint64_t hist64 = 0, hist_bytes = 0; uint32_t t = 0, c0 = 1, c1 = 0;
+    HuffState hs;
     for (uint32_t i = 0; i < len; i++) {
         uint32_t byte = DECODE ? 0u : g.in[off + i];
         for (int s = 7; s >= 0; s--) {
@@ -159,7 +160,7 @@ __global__ void __launch_bounds__(64) k_cm(CmArgs a) {
                     st[l] = slot_get_state(cellp[l], sid[l], bit_id, nib_ctx);
                     pl = s_st[st[l]].x & 0xFFFFu;                       // StateTable::p  state_table/mod.rs:47-49
                 } else if (!lp.frozen) {
-                    cslot[l] = leaf_slot(lp, lane_tbl, leaf_ctx(lp, hist64, t));
+                    cslot[l] = leaf_slot(lp, lane_tbl, leaf_ctx(lp, hist64, t, hs, a.g.huff));
                     pl = counter_p_packed(*cslot[l]);
                 }
                 const uint32_t d = opinion_dist(pl);
@@ -203,6 +204,7 @@ __global__ void __launch_bounds__(64) k_cm(CmArgs a) {
                                                    slot_hash(s_leaf[l].order, hist_bytes, second, c0 & 15u), s_st, sid[l]);
             }
         }
+        if (g.n_huff) hs.push_byte(g.huff, g.n_huff, byte & 0xFFu);
         if (DECODE) g.dout[off + i] = (uint8_t)byte;
     }
     if (!DECODE) {
@@ -339,6 +341,7 @@ __global__ void __launch_bounds__(64) k_cm_staged(CmArgs a) {
     }
 
     uint64_t hist64 = 0, hist_bytes = 0; uint32_t t = 0, c0 = 1, c1 = 0;
+    HuffState hs;
     for (uint32_t i = 0; i < len; i++) {
         uint32_t byte = DECODE ? 0u : g.in[off + i];
         for (int s = 7; s >= 0; s--) {
@@ -356,7 +359,7 @@ __global__ void __launch_bounds__(64) k_cm_staged(CmArgs a) {
                     st[l] = cmc_state(cb, slot_idx(sid[l], bit_id, nib_ctx), r, v);
                     pl = s_st[st[l]].x & 0xFFFFu;                       // StateTable::p  state_table/mod.rs:47-49
                 } else if (!lp.frozen) {
-                    cslot[l] = leaf_slot(lp, lane_tbl, leaf_ctx(lp, hist64, t));
+                    cslot[l] = leaf_slot(lp, lane_tbl, leaf_ctx(lp, hist64, t, hs, a.g.huff));
                     pl = counter_p_packed(*cslot[l]);
                 }
                 const uint32_t d = opinion_dist(pl);
@@ -404,6 +407,7 @@ __global__ void __launch_bounds__(64) k_cm_staged(CmArgs a) {
                         if (s_leaf[l].kind == 1) stage(l, slot_hash(s_leaf[l].order, hist_bytes, second, c0 & 15u));
             }
         }
+        if (g.n_huff) hs.push_byte(g.huff, g.n_huff, byte & 0xFFu);
         if (DECODE) g.dout[off + i] = (uint8_t)byte;
     }
     if (!DECODE) {
@@ -441,6 +445,7 @@ __global__ void __launch_bounds__(64) k_cm_nl(CmArgs a) {
     else enc.init(g.stripes + (uint64_t)lane * g.stripe_cap, g.stripe_cap);
 
     uint64_t hist64 = 0; uint32_t t = 0, c0 = 1, c1 = 0;
+    HuffState hs;
     for (uint32_t i = 0; i < len; i++) {
         uint32_t byte = DECODE ? 0u : g.in[off + i];
         for (int s = 7; s >= 0; s--) {
@@ -449,7 +454,7 @@ __global__ void __launch_bounds__(64) k_cm_nl(CmArgs a) {
             for (int l = 0; l < NL; l++) {
                 slot[l] = nullptr; val[l] = 0u; key[l] = 0u; ctx[l] = 0u;
                 if (!lp[l].frozen) {
-                    ctx[l] = leaf_ctx(lp[l], hist64, t);
+                    ctx[l] = leaf_ctx(lp[l], hist64, t, hs, a.g.huff);
                     uint32_t *tbl = reinterpret_cast<uint32_t *>(lane_tbl + lp[l].tbl_off);
                     slot[l] = lp[l].use_hash ? tbl + 2u * (((ctx[l] * 2654435761u) ^ (ctx[l] >> 15)) & lp[l].hash_mask) : tbl + ctx[l];
                 }
@@ -501,6 +506,7 @@ __global__ void __launch_bounds__(64) k_cm_nl(CmArgs a) {
             if (c0 >= 256u) { c1 = c0 & 0xFFu; c0 = 1u; }
             if (!DECODE) enc.encode(bit, p);
         }
+        if (g.n_huff) hs.push_byte(g.huff, g.n_huff, byte & 0xFFu);
         if (DECODE) g.dout[off + i] = (uint8_t)byte;
     }
     if (!DECODE) {

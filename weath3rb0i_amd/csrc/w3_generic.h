@@ -5,6 +5,7 @@
 // (decoding is serial by nature: the next context depends on the decoded bit).
 #pragma once
 #include "w3_device.h"
+#include "../../include/w3hip.h"
 
 namespace w3 {
 
@@ -12,7 +13,8 @@ struct LeafParam {
     uint8_t  bits, align, hist, max_bits, frozen, use_hash;
     uint8_t  kind;           // 0 = Counter table leaf, 1 = slot-state leaf (w3_cm.h)
     uint8_t  log_cells;      // slot leaf: HashMap log_cell_count
-    uint8_t  order, pad;     // slot leaf: previous bytes in the context
+    uint8_t  order;          // slot leaf: previous bytes in the context
+    uint8_t  huff_idx;       // HuffHistory leaf: its table set in GenericArgs::huff
     uint16_t table[8];       // StationaryModel table (ACHistory)
     uint64_t tbl_off;        // byte offset of this leaf's table inside the lane's region
     uint32_t hash_mask;      // slots-1 when use_hash
@@ -41,6 +43,9 @@ struct GenericArgs {
     const uint64_t *coffs;   // [nblocks] offsets into cin
     const uint32_t *clens;   // [nblocks]
     uint8_t  *dout;          // original bytes out
+    // HuffHistory leaves: the spec's table sets, copied to the device for the call
+    const w3_huff_table *huff;
+    int       n_huff;
 };
 
 // Context of a leaf at step t, given the lane's common 64-bit history (newest
@@ -50,10 +55,29 @@ struct GenericArgs {
 //   alignment= t mod 2^align                     (incremented once per update)
 // Both models start with ctx = 0 and only form ctx inside update(), so t == 0
 // is ctx 0 even for ACHistory (whose hash of an empty history is not 0).
-__device__ __forceinline__ uint32_t leaf_ctx(const LeafParam &lp, uint64_t hist64, uint32_t t) {
+// HuffHistory (history/huff_history.rs:58-76) keeps one piece of running state: compressed_bits, the concatenated codes of
+// the completed bytes (u32: old bits fall off the top).  One value per table set, advanced by the kernels' loops once per
+// completed byte — hash() does it at alignment 0, i.e. before the first context of the next byte is formed.
+struct HuffState {
+    uint32_t cb0 = 0u, cb1 = 0u, cb2 = 0u, cb3 = 0u;
+    __device__ __forceinline__ uint32_t get(uint32_t k) const { return k == 0u ? cb0 : k == 1u ? cb1 : k == 2u ? cb2 : cb3; }
+    __device__ __forceinline__ void push_byte(const w3_huff_table *tb, int n, uint32_t byte) {
+        if (n > 0) cb0 = (cb0 << tb[0].len[byte]) | tb[0].code[byte];
+        if (n > 1) cb1 = (cb1 << tb[1].len[byte]) | tb[1].code[byte];
+        if (n > 2) cb2 = (cb2 << tb[2].len[byte]) | tb[2].code[byte];
+        if (n > 3) cb3 = (cb3 << tb[3].len[byte]) | tb[3].code[byte];
+    }
+};
+
+__device__ __forceinline__ uint32_t leaf_ctx(const LeafParam &lp, uint64_t hist64, uint32_t t, const HuffState &hs, const w3_huff_table *huff) {
     if (t == 0u) return 0u;
     uint32_t h;
-    if (lp.hist == 2) {
+    if (lp.hist == W3_HIST_HUFF) {
+        const uint32_t al = t & 7u;
+        const uint32_t rem = ((uint32_t)hist64 & ((1u << al) - 1u)) | (1u << al);   // the partial byte with a leading 1 (:71-73)
+        const w3_huff_table &tb = huff[lp.huff_idx];
+        h = (hs.get(lp.huff_idx) << tb.rem_len[rem]) | tb.rem_code[rem];            // :74-75
+    } else if (lp.hist == 2) {
         if (lp.lut) {
             // the 16-bit prefix table of k_achash (w3_predict.h): most hashes are complete there; the rest resume at step 16.
             // (The literal one-bit-at-a-time form made the reference's default model decode at 12 MiB/s.)
@@ -119,6 +143,7 @@ __global__ void __launch_bounds__(64) k_generic(GenericArgs a) {
     else enc.init(a.stripes + (uint64_t)lane * a.stripe_cap, a.stripe_cap);
 
     uint64_t hist64 = 0; uint32_t t = 0;
+    HuffState hs;
     for (uint32_t i = 0; i < len; i++) {
         uint32_t byte = DECODE ? 0u : a.in[off + i];
         for (int s = 7; s >= 0; s--) {
@@ -130,7 +155,7 @@ __global__ void __launch_bounds__(64) k_generic(GenericArgs a) {
                 uint32_t pl = 32768u;
                 slot[l] = nullptr;
                 if (!lp.frozen) {                       // FrozenModel never adapts: Counter stays (0,0)
-                    slot[l] = leaf_slot(lp, lane_tbl, leaf_ctx(lp, hist64, t));
+                    slot[l] = leaf_slot(lp, lane_tbl, leaf_ctx(lp, hist64, t, hs, a.huff));
                     pl = counter_p_packed(*slot[l]);
                 }
                 uint32_t d = opinion_dist(pl);
@@ -146,6 +171,7 @@ __global__ void __launch_bounds__(64) k_generic(GenericArgs a) {
             t++;
             if (!DECODE) enc.encode(bit, p);
         }
+        if (a.n_huff) hs.push_byte(a.huff, a.n_huff, byte & 0xFFu);
         if (DECODE) a.dout[off + i] = (uint8_t)byte;
     }
     if (!DECODE) {
@@ -178,6 +204,7 @@ __global__ void __launch_bounds__(64) k_generic_nl(GenericArgs a) {
     else enc.init(a.stripes + (uint64_t)lane * a.stripe_cap, a.stripe_cap);
 
     uint64_t hist64 = 0; uint32_t t = 0;
+    HuffState hs;
     for (uint32_t i = 0; i < len; i++) {
         uint32_t byte = DECODE ? 0u : a.in[off + i];
         for (int s = 7; s >= 0; s--) {
@@ -187,7 +214,7 @@ __global__ void __launch_bounds__(64) k_generic_nl(GenericArgs a) {
             for (int l = 0; l < NL; l++) {
                 slot[l] = nullptr; val[l] = 0u; key[l] = 0u; ctx[l] = 0u;
                 if (!lp[l].frozen) {
-                    ctx[l] = leaf_ctx(lp[l], hist64, t);
+                    ctx[l] = leaf_ctx(lp[l], hist64, t, hs, a.huff);
                     uint32_t *tbl = reinterpret_cast<uint32_t *>(lane_tbl + lp[l].tbl_off);
                     if (!lp[l].use_hash) slot[l] = tbl + ctx[l];
                     else slot[l] = tbl + 2u * (((ctx[l] * 2654435761u) ^ (ctx[l] >> 15)) & lp[l].hash_mask);   // first probe (leaf_slot)
@@ -228,6 +255,7 @@ __global__ void __launch_bounds__(64) k_generic_nl(GenericArgs a) {
             t++;
             if (!DECODE) enc.encode(bit, p);
         }
+        if (a.n_huff) hs.push_byte(a.huff, a.n_huff, byte & 0xFFu);
         if (DECODE) a.dout[off + i] = (uint8_t)byte;
     }
     if (!DECODE) {

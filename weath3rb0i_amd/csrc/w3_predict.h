@@ -30,6 +30,7 @@
 // maximal |p-1/2|; see w3_device.h), so the coder reads 16 B per input byte.
 #pragma once
 #include "w3_device.h"
+#include "../../include/w3hip.h"
 
 namespace w3 {
 
@@ -725,7 +726,11 @@ __global__ void __launch_bounds__(64) k_rank_sorted(PredictArgs a) {
     const int lane = threadIdx.x;
     const uint32_t njobs = a.nblocks * W3_SLICES;
     // jobs are handed out in block-major order from one counter: slices are very uneven (a block's biggest
-    // group is one slice), and in-order hand-out keeps the set of blocks being scattered into small
+    // group is one slice), and in-order hand-out keeps the set of blocks being scattered into small.
+    // (Round 2 tried one queue per XCD — block b to queue b % 8, waves pulling from the queue of HW_REG_XCC_ID — so that the
+    // eight 16-byte pieces of a line would meet in ONE L2: WRITE_SIZE went UP, 31.4 -> 34.6 GB and 32.4 -> 44.5 GB per launch,
+    // and the phase from 47.5 to 48.5 ms: four blocks' streams fill an XCD's 4 MiB L2, lines are evicted before their
+    // pieces meet, and the partial writes no longer merge in the Infinity Cache behind a single stream of jobs either.)
     for (;;) {
         uint32_t job = 0;
         if (lane == 0) job = atomicAdd(a.job_counter, 1u);
@@ -859,6 +864,42 @@ __global__ void __launch_bounds__(64) k_rank_sorted(PredictArgs a) {
         W3_STAMP(3);
         if (a.dbg && lane == 0 && sl == 0) atomicAdd(&a.dbg[7], 1ull);
     }
+}
+
+// ---------------------------------------------------------------------------
+// HuffHistory keys (history/huff_history.rs:58-76): one thread per byte position computes the 8 context hashes of its
+// bit positions.  compressed_bits before byte i is the concatenation of the codes of the bytes before it (newest lowest),
+// cut to 32 bits: walk back until 32 bits are covered (a handful of bytes: codes average 4-6 bits).
+// ---------------------------------------------------------------------------
+struct HuffKeyArgs { const uint8_t *in; uint64_t n; uint32_t block_size; uint32_t hmask; const w3_huff_table *tb; uint2 *keys; };
+
+__global__ void __launch_bounds__(256) k_huffkeys(HuffKeyArgs a) {
+    __shared__ uint16_t s_code[256], s_rcode[256];
+    __shared__ uint8_t s_len[256], s_rlen[256];
+    s_code[threadIdx.x] = a.tb->code[threadIdx.x]; s_len[threadIdx.x] = a.tb->len[threadIdx.x];
+    s_rcode[threadIdx.x] = a.tb->rem_code[threadIdx.x]; s_rlen[threadIdx.x] = a.tb->rem_len[threadIdx.x];
+    __syncthreads();
+    const uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= a.n) return;
+    const uint64_t b = g / a.block_size;
+    const uint32_t i = (uint32_t)(g - b * a.block_size);
+    const uint8_t *blk = a.in + b * a.block_size;
+    uint32_t cb = 0u, have = 0u;
+    for (uint32_t k = 1; k <= i && have < 32u; k++) {
+        const uint32_t byte = blk[i - k];
+        cb |= (uint32_t)s_code[byte] << have;
+        have += s_len[byte];
+    }
+    const uint32_t c0 = blk[i];
+    uint32_t out[2] = {0u, 0u};
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        if (i == 0u && j == 0) continue;                                  // ctx starts at 0 (ordern_entropy.rs:19)
+        const uint32_t rem = (1u << j) | (c0 >> (8 - j));                 // partial byte with a leading 1 (:71-73)
+        const uint32_t h = (cb << s_rlen[rem]) | s_rcode[rem];            // :74-75
+        out[j >> 2] |= (h & a.hmask & 0xFFu) << (8 * (j & 3));
+    }
+    a.keys[g] = make_uint2(out[0], out[1]);
 }
 
 // ---------------------------------------------------------------------------

@@ -9,5 +9,7 @@ struct ParsedSpec {
     int n_apm = 0;
     w3_node apm[W3_MAX_APM];
     bool has_slot = false;
+    uint32_t n_huff = 0;                  // HuffHistory table sets (caller's memory, valid during the call)
+    const w3_huff_table *huff = nullptr;
     bool is_cm() const { return has_slot || n_apm > 0; }
 };

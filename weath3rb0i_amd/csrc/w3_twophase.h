@@ -46,6 +46,7 @@ struct TwoPhaseWs {
     const int16_t *stretch = nullptr;   // APM LUTs (device; owned by the ctx)
     const uint16_t *squash = nullptr;
     const uint2 *st = nullptr;          // NaiveStateTable rows for the slot-state leaves (device; owned by the ctx)
+    const w3_huff_table *huff = nullptr;   // HuffHistory table sets of the current call's spec (device; owned by the ctx)
     // wide Counter leaves: their k_partition passes run on a side stream beside the time-ordered leaves' kernels
     void *rec_w[4] = {nullptr, nullptr, nullptr, nullptr}, *perm_w[4] = {nullptr, nullptr, nullptr, nullptr}, *splits_w[4] = {nullptr, nullptr, nullptr, nullptr};
     size_t rec_w_cap[4] = {0, 0, 0, 0}, perm_w_cap[4] = {0, 0, 0, 0}, splits_w_cap[4] = {0, 0, 0, 0};
@@ -112,13 +113,14 @@ static inline int tp_ensure(void *&p, size_t &cap, size_t bytes, std::string &er
     return W3_OK;
 }
 
-enum { LEAF_FROZEN = 0, LEAF_SMALL = 1, LEAF_SMALL_AC = 2, LEAF_WIDE1 = 3, LEAF_WIDE2 = 4, LEAF_SLOT = 5, LEAF_NONE = -1 };
+enum { LEAF_FROZEN = 0, LEAF_SMALL = 1, LEAF_SMALL_AC = 2, LEAF_WIDE1 = 3, LEAF_WIDE2 = 4, LEAF_SLOT = 5, LEAF_SMALL_HUFF = 6, LEAF_NONE = -1 };
 
 static inline int leaf_class(const w3_node &nd) {
     if (nd.kind == W3_NODE_SLOT_STATE) return LEAF_SLOT;
     if (nd.frozen) return LEAF_FROZEN;
     if (nd.align != 3 || nd.bits < 3) return LEAF_NONE;
     const int H = nd.bits - 3;
+    if (nd.history == W3_HIST_HUFF) return H <= 8 ? LEAF_SMALL_HUFF : LEAF_NONE;   // wide Huffman-hashed contexts: generic kernel
     if (H <= 8) return nd.history == W3_HIST_AC ? LEAF_SMALL_AC : LEAF_SMALL;
     if (nd.history == W3_HIST_AC) return LEAF_NONE;
     if (H == 16) return LEAF_WIDE1;
@@ -204,7 +206,7 @@ static inline int twophase_predict(TwoPhaseWs &ws, hipStream_t s, const ParsedSp
     bool need_keys = false, need_perm = false;
     for (int l = 0; l < ps.n_leaves; l++) {
         int c = leaf_class(ps.leaf[l]);
-        need_keys |= c == LEAF_SMALL_AC;
+        need_keys |= c == LEAF_SMALL_AC || c == LEAF_SMALL_HUFF;
         need_perm |= c == LEAF_WIDE1 || c == LEAF_WIDE2;
     }
     if (need_keys && (rc = tp_ensure(ws.keys, ws.keys_cap, n * 8, err))) return rc;
@@ -288,6 +290,15 @@ static inline int twophase_predict(TwoPhaseWs &ws, hipStream_t s, const ParsedSp
             hipLaunchKernelGGL(w3::k_achash_lut, dim3((8u << W3_ACHASH_LUT_BITS) / 256), dim3(256), 0, s, ha);
             hipLaunchKernelGGL(w3::k_achash, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, ha);
             if (ev && !achash_timed) { (void)hipEventRecord(ev[13], s); achash_timed = true; ws.achash_timed = true; }
+            pa.keys = (const uint2 *)ws.keys;
+            launch_small<true>(nd.bits - 3, dim3(grid_small), s, pa);
+            bytes += n * 17;
+        } else if (c == LEAF_SMALL_HUFF) {
+            if (!ws.huff) { err = "HuffHistory tables not staged"; return W3_E_HIP; }
+            w3::HuffKeyArgs hk;
+            hk.in = d_in; hk.n = n; hk.block_size = (uint32_t)block_size; hk.hmask = (1u << (nd.bits - 3)) - 1u;
+            hk.tb = ws.huff + nd.reserved; hk.keys = (uint2 *)ws.keys;
+            hipLaunchKernelGGL(w3::k_huffkeys, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, hk);
             pa.keys = (const uint2 *)ws.keys;
             launch_small<true>(nd.bits - 3, dim3(grid_small), s, pa);
             bytes += n * 17;
@@ -419,7 +430,7 @@ static inline int twophase_apm(TwoPhaseWs &ws, hipStream_t s, const ParsedSpec &
             if (ws.P_valid) aa.src[0] = (const uint16_t *)ws.P;
             else if (ws.mix.n_src <= 8) { L = ws.mix.n_src; for (int l = 0; l < L; l++) aa.src[l] = (const uint16_t *)ws.mix.src[l]; }
             else { if ((rc = twophase_mix(ws, s, n, err))) return rc; aa.src[0] = (const uint16_t *)ws.P; bytes += n * 16 * (ws.mix.n_src + 1); }
-            const dim3 grid((nb + W3_APM_WAVES - 1) / W3_APM_WAVES), blk(64 * W3_APM_WAVES);
+            const dim3 grid((nb + W3_APM_WAVES - 1) / W3_APM_WAVES), blk(128 * W3_APM_WAVES);   // two wavefronts per block
             switch (L) {
             case 1: hipLaunchKernelGGL(w3::k_apm0<1>, grid, blk, 0, s, aa); break;
             case 2: hipLaunchKernelGGL(w3::k_apm0<2>, grid, blk, 0, s, aa); break;

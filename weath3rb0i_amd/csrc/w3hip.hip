@@ -12,6 +12,7 @@
 #include <vector>
 
 #include "w3_spec.h"
+#include "w3_huff.h"
 #include "w3_generic.h"
 #include "w3_cm.h"
 #include "w3_pack.h"
@@ -19,6 +20,8 @@
 #include "w3_selftest.h"
 
 using namespace w3;
+
+static_assert(sizeof(w3_node) == 24 && sizeof(w3_huff_table) == 1536 && sizeof(w3_model_spec) == 760, "ABI struct layout (tests/test_host_abi.py)");
 
 // ---------------------------------------------------------------------------
 // ctx
@@ -39,7 +42,7 @@ struct w3_ctx {
     w3_timing timing{};
     hipEvent_t ev[14]{};
     // workspace
-    DevBuf tables, stripes, lens, offs, total, flag, io_in, io_out, coffs, misc, cm_luts, achash_luts;
+    DevBuf tables, stripes, lens, offs, total, flag, io_in, io_out, coffs, misc, cm_luts, achash_luts, huff;
     TwoPhaseWs tp;
     // block ranges 1..3 of a pipelined two-phase encode (range 0 uses tp, ev and the caller's stream)
     struct Range { TwoPhaseWs ws; hipStream_t stream = nullptr; hipEvent_t ev[14]{}; hipEvent_t ev_done = nullptr; };
@@ -113,7 +116,7 @@ extern "C" void w3_ctx_destroy(w3_ctx *ctx) {
     (void)hipSetDevice(ctx->device);
     (void)hipDeviceSynchronize();
     DevBuf *bufs[] = {&ctx->tables, &ctx->stripes, &ctx->lens, &ctx->offs, &ctx->total, &ctx->flag,
-                      &ctx->io_in, &ctx->io_out, &ctx->coffs, &ctx->misc, &ctx->cm_luts, &ctx->achash_luts};
+                      &ctx->io_in, &ctx->io_out, &ctx->coffs, &ctx->misc, &ctx->cm_luts, &ctx->achash_luts, &ctx->huff};
     for (DevBuf *b : bufs)
         if (b->p) (void)hipFree(b->p);
     ctx->tp.release();
@@ -202,8 +205,9 @@ static int parse_spec(const w3_model_spec *spec, ParsedSpec &ps) {
             // OrderN::new allocates 1<<bits counters; masks are u32/u8 (ordern.rs:35-43)
             if (nd.bits < 1 || nd.bits > 32 || nd.align > 7 || nd.align > nd.bits) return W3_E_INVALID;
             if ((int)nd.bits - (int)nd.align > 31) return W3_E_INVALID;
-            if (nd.history > W3_HIST_AC) return W3_E_INVALID;
+            if (nd.history > W3_HIST_HUFF) return W3_E_INVALID;
             if (nd.history == W3_HIST_AC && nd.max_bits > 32) return W3_E_INVALID;
+            if (nd.history == W3_HIST_HUFF && (spec->n_huff > W3_MAX_HUFF || nd.reserved >= spec->n_huff || !spec->huff)) return W3_E_INVALID;
             if (ps.n_leaves == W3_MAX_LEAVES) return W3_E_UNSUPPORTED;
             ps.leaf[ps.n_leaves++] = nd;
             depth++;
@@ -220,7 +224,25 @@ static int parse_spec(const w3_model_spec *spec, ParsedSpec &ps) {
             return W3_E_INVALID;
         }
     }
+    ps.n_huff = spec->n_huff <= W3_MAX_HUFF ? spec->n_huff : 0;
+    ps.huff = ps.n_huff ? spec->huff : nullptr;
+    if (ps.n_huff) {   // code lengths index shifts of u32 values
+        for (uint32_t k = 0; k < ps.n_huff; k++)
+            for (int v = 0; v < 256; v++)
+                if (ps.huff[k].len[v] > 16 || ps.huff[k].rem_len[v] > 16) return W3_E_INVALID;
+    }
     return depth == 1 ? W3_OK : W3_E_INVALID;
+}
+
+// HuffHistory table sets of the spec -> device (per call: the tables are the caller's memory)
+static int stage_huff(w3_ctx *ctx, hipStream_t s, const ParsedSpec &ps) {
+    ctx->tp.huff = nullptr;
+    if (!ps.n_huff) return W3_OK;
+    ENSURE(ctx, ctx->huff, sizeof(w3_huff_table) * W3_MAX_HUFF);
+    HIPCHK(ctx, hipMemcpyAsync(ctx->huff.p, ps.huff, sizeof(w3_huff_table) * ps.n_huff, hipMemcpyHostToDevice, s));
+    HIPCHK(ctx, hipStreamSynchronize(s));   // (pageable source: the caller may free it after the call)
+    ctx->tp.huff = (const w3_huff_table *)ctx->huff.p;
+    return W3_OK;
 }
 
 extern "C" int w3_spec_validate(const w3_model_spec *spec) {
@@ -246,6 +268,7 @@ static uint64_t layout_generic(const ParsedSpec &ps, size_t block_size, GenericA
         LeafParam &lp = ga.leaf[l];
         memset(&lp, 0, sizeof lp);
         lp.bits = nd.bits; lp.align = nd.align; lp.hist = nd.history; lp.max_bits = nd.max_bits; lp.frozen = nd.frozen;
+        lp.huff_idx = nd.history == W3_HIST_HUFF ? nd.reserved : 0;
         memcpy(lp.table, nd.table, sizeof lp.table);
         lp.tbl_off = off;
         if (nd.kind == W3_NODE_SLOT_STATE) {   // HashMap of 2^log_cells 96-byte Cells (hashmap.rs:7-22)
@@ -346,6 +369,7 @@ static int generic_encode(w3_ctx *ctx, hipStream_t s, const ParsedSpec &ps, cons
     if ((rc = prepare_achash_luts(ctx, s, ga))) return rc;
     ENSURE(ctx, ctx->tables, (size_t)lanes * lane_stride);
     ga.n = n; ga.block_size = (uint32_t)block_size;
+    ga.huff = ctx->tp.huff; ga.n_huff = (int)ps.n_huff;
     ga.tables = (uint8_t *)ctx->tables.p; ga.lane_stride = lane_stride;
     ga.in = d_in; ga.stripe_cap = stripe_cap; ga.out_len = d_lens; ga.overflow = (uint32_t *)ctx->flag.p;
     for (uint32_t first = 0; first < nb; first += lanes) {
@@ -379,6 +403,7 @@ static int generic_decode(w3_ctx *ctx, hipStream_t s, const ParsedSpec &ps, cons
     ENSURE(ctx, ctx->total, 8);
     hipLaunchKernelGGL(k_scan_lens, dim3(1), dim3(1024), 0, s, d_lens, (uint64_t *)ctx->coffs.p, (uint64_t *)ctx->total.p, nb);
     ga.n = orig_len; ga.block_size = (uint32_t)block_size;
+    ga.huff = ctx->tp.huff; ga.n_huff = (int)ps.n_huff;
     ga.tables = (uint8_t *)ctx->tables.p; ga.lane_stride = lane_stride;
     ga.cin = d_cin; ga.coffs = (const uint64_t *)ctx->coffs.p; ga.clens = d_lens; ga.dout = d_out;
     for (uint32_t first = 0; first < nb; first += lanes) {
@@ -483,6 +508,7 @@ static int cm_encode(w3_ctx *ctx, hipStream_t s, const ParsedSpec &ps, const uin
     const uint64_t lane_stride = layout_cm(ps, block_size, ca);
     { int rc_ = prepare_achash_luts(ctx, s, ca.g); if (rc_) return rc_; }
     ca.g.n = n; ca.g.block_size = (uint32_t)block_size;
+    ca.g.huff = ctx->tp.huff; ca.g.n_huff = (int)ps.n_huff;
     ca.g.in = d_in; ca.g.stripe_cap = stripe_cap; ca.g.out_len = d_lens; ca.g.overflow = (uint32_t *)ctx->flag.p;
     return cm_run<false>(ctx, s, ca, lane_stride, nb, stripe_cap);
 }
@@ -497,6 +523,7 @@ static int cm_decode(w3_ctx *ctx, hipStream_t s, const ParsedSpec &ps, const uin
     ENSURE(ctx, ctx->total, 8);
     hipLaunchKernelGGL(k_scan_lens, dim3(1), dim3(1024), 0, s, d_lens, (uint64_t *)ctx->coffs.p, (uint64_t *)ctx->total.p, nb);
     ca.g.n = orig_len; ca.g.block_size = (uint32_t)block_size;
+    ca.g.huff = ctx->tp.huff; ca.g.n_huff = (int)ps.n_huff;
     ca.g.cin = d_cin; ca.g.coffs = (const uint64_t *)ctx->coffs.p; ca.g.clens = d_lens; ca.g.dout = d_out;
     return cm_run<true>(ctx, s, ca, lane_stride, nb, 0);
 }
@@ -557,7 +584,7 @@ static int ensure_ranges(w3_ctx *ctx, int parts, bool timing) {
                 if (!e) HIPCHK(ctx, hipEventCreate(&e));
         r.ws.coder_mode = ctx->tp.coder_mode; r.ws.acc_limit = ctx->tp.acc_limit; r.ws.debug_stamps = 0;
         r.ws.variant = ctx->tp.variant; r.ws.slot_budget_mb = ctx->tp.slot_budget_mb;
-        r.ws.stretch = ctx->tp.stretch; r.ws.squash = ctx->tp.squash; r.ws.st = ctx->tp.st;
+        r.ws.stretch = ctx->tp.stretch; r.ws.squash = ctx->tp.squash; r.ws.st = ctx->tp.st; r.ws.huff = ctx->tp.huff;
     }
     return W3_OK;
 }
@@ -581,6 +608,7 @@ extern "C" int w3_encode_blocks_device(w3_ctx *ctx, const w3_model_spec *spec, c
     }
     if (!d_in || !d_out || !d_block_lens) return W3_E_INVALID;
     ENSURE(ctx, ctx->flag, 16);
+    if ((rc = stage_huff(ctx, s, ps))) return rc;
 
     bool two = twophase_supported(ps, block_size, n);   // Counter and slot-state leaves + APM chain (decode: k_generic / k_cm)
     if (ctx->opt_path == W3_PATH_GENERIC) two = false;
@@ -712,6 +740,7 @@ extern "C" int w3_decode_blocks_device(w3_ctx *ctx, const w3_model_spec *spec, c
     if (!d_in || !d_block_lens || !d_out) return W3_E_INVALID;
     HIPCHK(ctx, hipSetDevice(ctx->device));
     hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
+    if ((rc = stage_huff(ctx, s, ps))) return rc;
     {   // the length table must not claim more than the caller's buffer holds: the kernels read cin + offset for clens[b] bytes
         ENSURE(ctx, ctx->coffs, (size_t)nb * 8);
         ENSURE(ctx, ctx->total, 8);
@@ -854,6 +883,15 @@ extern "C" int w3_stationary_table(const uint8_t *buf, size_t n, uint16_t table[
 }
 
 // ---------------------------------------------------------------------------
+// HuffHistory::new (history/huff_history.rs:17-55): constructor-time table prep on the host (w3_huff.h)
+// ---------------------------------------------------------------------------
+extern "C" int w3_huff_tables(const uint8_t *buf, size_t n, uint8_t huff_size, uint8_t rem_huff_size, w3_huff_table *out) {
+    if ((!buf && n) || !out) return W3_E_INVALID;
+    if (huff_size > 16 || rem_huff_size > 16) return W3_E_INVALID;   // codes are u16 (package_merge.rs:87: Vec<(u16, u8)>)
+    return w3huff::build(buf, n, huff_size, rem_huff_size, out) ? W3_OK : W3_E_INVALID;
+}
+
+// ---------------------------------------------------------------------------
 // Model::predict for every step (two-phase predict kernels only)
 // ---------------------------------------------------------------------------
 extern "C" int w3_predict_blocks(w3_ctx *ctx, const w3_model_spec *spec, const uint8_t *in, size_t n, size_t block_size, uint16_t *p_out) {
@@ -872,6 +910,7 @@ extern "C" int w3_predict_blocks(w3_ctx *ctx, const w3_model_spec *spec, const u
         ctx->tp.stretch = lut.stretch; ctx->tp.squash = lut.squash; ctx->tp.st = lut.st;
     }
     const uint32_t nb = (uint32_t)((n + block_size - 1) / block_size);
+    if ((rc = stage_huff(ctx, s, ps))) return rc;
     ENSURE(ctx, ctx->io_in, n);
     HIPCHK(ctx, hipMemcpyAsync(ctx->io_in.p, in, n, hipMemcpyHostToDevice, s));
     const uint16_t *d_p = nullptr;

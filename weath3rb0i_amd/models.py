@@ -87,20 +87,69 @@ class ACHistoryCached(ACHistory):
         return cls(max_bits, model, cache_size)
 
 
+class HuffHistory:
+    """history/huff_history.rs:9-76 — the concatenated canonical Huffman codes of the completed bytes plus the code of the
+    partial byte.  HuffHistory::new(buf, huff_size, rem_huff_size) builds the two code tables on the host (w3_huff_tables;
+    among equal counts the reference's order is that of Rust's sort_unstable_by, here ascending symbol order);
+    from_tables() takes ready (code, len) tables, e.g. ones dumped from the reference itself."""
+    kind = L.W3_HIST_HUFF
+    max_bits = 0
+    table = [0] * 8
+
+    def __init__(self, buf, huff_size, rem_huff_size):
+        a = np.frombuffer(bytes(buf), dtype=np.uint8)
+        self.tables = L.HuffTable()
+        rc = L.load().w3_huff_tables(a.ctypes.data_as(C.c_void_p), len(a), huff_size, rem_huff_size, C.byref(self.tables))
+        if rc:
+            raise W3Error(rc, "HuffHistory::new: no symbols, or max length too big / too small for the alphabet")
+
+    @classmethod
+    def new(cls, buf, huff_size, rem_huff_size):
+        return cls(buf, huff_size, rem_huff_size)
+
+    @classmethod
+    def from_tables(cls, code, length, rem_code, rem_length):
+        o = cls.__new__(cls)
+        o.tables = L.HuffTable()
+        for i in range(256):
+            o.tables.code[i], o.tables.len[i], o.tables.rem_code[i], o.tables.rem_len[i] = code[i], length[i], rem_code[i], rem_length[i]
+        return o
+
+
 class Model:
     """trait Model (models/mod.rs:12-15), as a spec tree."""
+    _cur_huff_index = {}
 
     def _nodes(self):
         raise NotImplementedError
 
+    def _huff_sets(self):
+        """HuffHistory objects of the tree's leaves, in leaf order (each gets a slot in w3_model_spec::huff)."""
+        return []
+
     def spec(self):
-        nodes = self._nodes()
+        huffs = []
+        for h in self._huff_sets():
+            if not any(h is x for x in huffs):
+                huffs.append(h)
+        if len(huffs) > L.W3_MAX_HUFF:
+            raise W3Error(L.W3_E_UNSUPPORTED, "more than %d HuffHistory table sets" % L.W3_MAX_HUFF)
+        Model._cur_huff_index = {id(h): i for i, h in enumerate(huffs)}   # read by AdaptiveModel._leaf while the tree is walked
+        try:
+            nodes = self._nodes()
+        finally:
+            Model._cur_huff_index = {}
         if len(nodes) > L.W3_MAX_NODES:
             raise W3Error(L.W3_E_UNSUPPORTED, "model tree too large")
         s = L.ModelSpec()
         s.n_nodes = len(nodes)
         for i, nd in enumerate(nodes):
             s.nodes[i] = nd
+        if huffs:
+            arr = (L.HuffTable * len(huffs))(*[h.tables for h in huffs])
+            s._huff_keepalive = arr   # the spec points into this array
+            s.n_huff = len(huffs)
+            s.huff = C.cast(arr, C.POINTER(L.HuffTable))
         rc = L.load().w3_spec_validate(C.byref(s))
         if rc:
             raise W3Error(rc, "model spec rejected")
@@ -128,7 +177,13 @@ class AdaptiveModel(Model):
         h = self.history
         if h is None:
             return _leaf(self.bits, self.align, frozen=frozen)
-        return _leaf(self.bits, self.align, h.kind, h.max_bits, h.table, frozen=frozen)
+        nd = _leaf(self.bits, self.align, h.kind, h.max_bits, h.table, frozen=frozen)
+        if h.kind == L.W3_HIST_HUFF:
+            nd.reserved = Model._cur_huff_index.get(id(h), 0)
+        return nd
+
+    def _huff_sets(self):
+        return [self.history] if self.history is not None and self.history.kind == L.W3_HIST_HUFF else []
 
     def _nodes(self):
         return [self._leaf()]
@@ -190,6 +245,9 @@ class FrozenModel(Model):
     def new(cls, model):
         return cls(model)
 
+    def _huff_sets(self):
+        return self.model._huff_sets()
+
     def _nodes(self):
         return [self.model._leaf(frozen=1)]
 
@@ -203,6 +261,9 @@ class BestOfTwoModel(Model):
     @classmethod
     def new(cls, m1, m2):
         return cls(m1, m2)
+
+    def _huff_sets(self):
+        return self.m1._huff_sets() + self.m2._huff_sets()
 
     def _nodes(self):
         nd = L.Node()
@@ -301,6 +362,9 @@ class APM(Model, Mixer):
     @classmethod
     def new(cls, model, ctx=L.W3_APM_ORDER0, rate=7):
         return cls(model, ctx, rate)
+
+    def _huff_sets(self):
+        return self.model._huff_sets()
 
     def _nodes(self):
         nd = L.Node()
