@@ -128,8 +128,13 @@ enum {
                            0/1 = one range (default), 2..4.  Output is identical; measured no faster on MI355X */
     W3_OPT_VARIANT = 7, /* cross-check hook for the tests: bit mask of alternative, bit-exact implementations — 1 = Counter rounds
                            with ballots instead of returning LDS adds, 2 = 4-bit partition passes, 4 = order-2 partition from
-                           scratch, 8 = CM decoder without LDS staging, 16 = no side stream.  0 = defaults */
-    W3_OPT_SLOT_BUDGET_MB = 8 /* cap (MiB) on the device memory one batch of slot-state hash maps may take; 0 = derive from free memory */
+                           scratch, 8 = CM decoder without LDS staging, 16 = no side stream, 32 = FAULT INJECTION: one LDS-add round of
+                           every block returns two lanes each other's value (the sampled verification must catch it).  0 = defaults */
+    W3_OPT_SLOT_BUDGET_MB = 8, /* cap (MiB) on the device memory one batch of slot-state hash maps may take; 0 = derive from free memory */
+    W3_OPT_VERIFY = 9   /* 1 (default): after every two-phase predict that used returning LDS adds — whose lane-ordered resolution is
+                           measured, not documented by the ISA — up to 64 sampled blocks are predicted again with ballot rounds and
+                           compared on the device; on a mismatch the call is re-encoded on the ballot path (w3_timing.n_lds_faults)
+                           and the context stays there.  0 = off */
 };
 enum { W3_PATH_AUTO = 0, W3_PATH_GENERIC = 1, W3_PATH_TWOPHASE = 2 };
 int         w3_ctx_set_option(w3_ctx *ctx, int opt, int64_t value);
@@ -234,6 +239,8 @@ typedef struct w3_timing {
     float    achash_ms;    /* ACHistory key kernels (k_achash_lut + k_achash; also inside predict_ms) */
     uint32_t n_parts;      /* block ranges the call was pipelined in (W3_OPT_PARTS); the *_ms fields above are sums over
                               the ranges' kernels, which overlap in time: their sum can exceed total_ms */
+    uint32_t n_lds_faults; /* wavefronts of the sampled verification whose streams differed (W3_OPT_VERIFY); > 0: the call was
+                              re-encoded with ballot rounds */
 } w3_timing;
 int w3_get_timing(const w3_ctx *ctx, w3_timing *out);
 

@@ -170,6 +170,34 @@ def test_ballot_rounds_without_lds_atomics(oracle):
         c.close()
 
 
+def test_sampled_verification_catches_misordered_lds_adds(oracle):
+    """VERDICT r1 #5 / ADVICE: the default predict kernels rely on returning LDS adds resolving in lane order (measured, not in
+    the ISA manual).  Every call re-predicts sampled blocks with ballot rounds and compares (W3_OPT_VERIFY).  With the fault
+    hook one LDS-add round of every block is corrupted: the verification must notice, the call must still return the
+    oracle's streams (re-encoded on the ballot path) and the context must stay on that path."""
+    data = markov_text(300000, seed=23) + lcg_text(30000, seed=6)
+    for name in ("order0", "best012", "main_default"):
+        c = w3.Context(0)
+        try:
+            c.set_path("twophase")
+            dev, orc = pair(oracle, name)
+            want, wlens = oracle.encode_blocks(orc(), data, 16384, nthreads=8)
+            out, lens = c.encode_blocks(dev(), data, 16384)                    # clean run: verification on, nothing found
+            assert c.timing()["n_lds_faults"] == 0 and out.tobytes() == want.tobytes()
+            c.set_variant("inject_lds_fault")
+            out, lens = c.encode_blocks(dev(), data, 16384)
+            assert c.timing()["n_lds_faults"] > 0, name
+            assert lens.tolist() == wlens.tolist() and out.tobytes() == want.tobytes(), name
+            out, lens = c.encode_blocks(dev(), data, 16384)                    # the context now runs ballot rounds: no fault to find
+            assert c.timing()["n_lds_faults"] == 0 and out.tobytes() == want.tobytes()
+            c.set_variant("inject_lds_fault")                                  # (set_variant re-arms the LDS-add path)
+            c.set_verify(False)
+            out, lens = c.encode_blocks(dev(), data, 16384)                    # verification off: the corruption goes through
+            assert out.tobytes() != want.tobytes(), name
+        finally:
+            c.close()
+
+
 @pytest.mark.parametrize("parts", [2, 3, 4])
 def test_block_ranges_pipelined_on_streams(ctx, oracle, parts):
     """W3_OPT_PARTS: the call's blocks as 2..4 ranges on separate streams (range r's APM / coder kernels beside range

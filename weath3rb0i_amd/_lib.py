@@ -13,8 +13,8 @@ W3_MAX_APM = 4
 W3_HIST_NONE, W3_HIST_RAW, W3_HIST_AC, W3_HIST_HUFF = 0, 1, 2, 3
 W3_MAX_HUFF = 4
 W3_OK, W3_E_INVALID, W3_E_NOSPACE, W3_E_HIP, W3_E_UNSUPPORTED, W3_E_NOMEM, W3_E_FORMAT = 0, -1, -2, -3, -4, -5, -6
-W3_OPT_PATH, W3_OPT_TIMING, W3_OPT_CODER, W3_OPT_ACC_LIMIT, W3_OPT_DEBUG_STAMPS, W3_OPT_PARTS, W3_OPT_VARIANT, W3_OPT_SLOT_BUDGET_MB = 1, 2, 3, 4, 5, 6, 7, 8
-W3_VAR_NO_LDS_ATOMICS, W3_VAR_PARTITION4, W3_VAR_NO_CHAINED_PARTITION, W3_VAR_CM_UNSTAGED, W3_VAR_NO_SIDE_STREAM = 1, 2, 4, 8, 16
+W3_OPT_PATH, W3_OPT_TIMING, W3_OPT_CODER, W3_OPT_ACC_LIMIT, W3_OPT_DEBUG_STAMPS, W3_OPT_PARTS, W3_OPT_VARIANT, W3_OPT_SLOT_BUDGET_MB, W3_OPT_VERIFY = 1, 2, 3, 4, 5, 6, 7, 8, 9
+W3_VAR_NO_LDS_ATOMICS, W3_VAR_PARTITION4, W3_VAR_NO_CHAINED_PARTITION, W3_VAR_CM_UNSTAGED, W3_VAR_NO_SIDE_STREAM, W3_VAR_INJECT_LDS_FAULT = 1, 2, 4, 8, 16, 32
 W3_PATH_AUTO, W3_PATH_GENERIC, W3_PATH_TWOPHASE = 0, 1, 2
 
 
@@ -35,7 +35,8 @@ class Timing(C.Structure):
     _fields_ = [("predict_ms", C.c_float), ("coder_ms", C.c_float), ("pack_ms", C.c_float), ("generic_ms", C.c_float),
                 ("total_ms", C.c_float), ("path", C.c_uint32), ("n_coder_launches", C.c_uint32),
                 ("coder_bytes", C.c_uint64), ("predict_bytes", C.c_uint64), ("n_recoded_blocks", C.c_uint32), ("apm_ms", C.c_float),
-                ("slot_ms", C.c_float), ("n_slot_launches", C.c_uint32), ("achash_ms", C.c_float), ("n_parts", C.c_uint32)]
+                ("slot_ms", C.c_float), ("n_slot_launches", C.c_uint32), ("achash_ms", C.c_float), ("n_parts", C.c_uint32),
+                ("n_lds_faults", C.c_uint32)]
 
 
 EXPORTS = [

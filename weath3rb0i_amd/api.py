@@ -57,11 +57,15 @@ class Context:
         """Cross-check hook (W3_OPT_VARIANT): alternative bit-exact implementations, by name: no_lds_atomics, partition4,
         no_chained_partition, cm_unstaged, no_side_stream.  No names = defaults."""
         bits = {"no_lds_atomics": L.W3_VAR_NO_LDS_ATOMICS, "partition4": L.W3_VAR_PARTITION4, "no_chained_partition": L.W3_VAR_NO_CHAINED_PARTITION,
-                "cm_unstaged": L.W3_VAR_CM_UNSTAGED, "no_side_stream": L.W3_VAR_NO_SIDE_STREAM}
+                "cm_unstaged": L.W3_VAR_CM_UNSTAGED, "no_side_stream": L.W3_VAR_NO_SIDE_STREAM, "inject_lds_fault": L.W3_VAR_INJECT_LDS_FAULT}
         v = 0
         for nm in names:
             v |= bits[nm]
         self._chk(self.lib.w3_ctx_set_option(self.h, L.W3_OPT_VARIANT, v))
+
+    def set_verify(self, on=True):
+        """W3_OPT_VERIFY: sampled ballot-round re-prediction after every predict phase that used LDS-add rounds (default on)."""
+        self._chk(self.lib.w3_ctx_set_option(self.h, L.W3_OPT_VERIFY, int(on)))
 
     def set_slot_budget_mb(self, mb=0):
         self._chk(self.lib.w3_ctx_set_option(self.h, L.W3_OPT_SLOT_BUDGET_MB, int(mb)))

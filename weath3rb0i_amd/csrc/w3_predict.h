@@ -51,7 +51,8 @@ struct PredictArgs {
     uint32_t *job_counter;  // k_rank_sorted: next job (zeroed before the launch)
     uint32_t hbits;         // H = bits_in_context - 3
     uint32_t maxseg;        // k_rank_sorted: rounds with more groups than this take the ballot path (W3_ATOMIC_MAXSEG)
-    uint32_t dbg_flags;      // bit0 = skip the stream stores (timing experiments only); bit1 = ballot rounds only (no LDS atomics)
+    uint32_t dbg_flags;      // bit0 = skip the stream stores (timing experiments only); bit1 = ballot rounds only (no LDS atomics);
+                             // bit3 = FAULT INJECTION for the tests of the sampled verification: one returning add of every block hands two lanes each other's value
     unsigned long long *dbg; // optional: per-phase s_memtime sums (diagnostic builds/runs only; never read by kernels)
 };
 
@@ -348,6 +349,7 @@ __global__ void __launch_bounds__(64) k_predict_small(PredictArgs a) {
                 __asm__ volatile("" ::: "memory");
                 atomic_round(tbl, c0, key, valid, v);
                 __asm__ volatile("" ::: "memory");
+                if ((a.dbg_flags & 8u) && base == 64u) v[0] = (uint32_t)__shfl_xor((int)v[0], 1, 64);   // (test hook: a mis-ordered add)
 #pragma unroll
                 for (int j = 0; j < 8; j++) p[j] = counter_p_packed(v[j]);
                 exact = atomic_round_hot(v);
@@ -900,6 +902,27 @@ __global__ void __launch_bounds__(256) k_huffkeys(HuffKeyArgs a) {
         out[j >> 2] |= (h & a.hmask & 0xFFu) << (8 * (j & 3));
     }
     a.keys[g] = make_uint2(out[0], out[1]);
+}
+
+// ---------------------------------------------------------------------------
+// Sampled verification of the LDS-add rounds (w3_twophase.h, twophase_verify): S blocks of the input are gathered into a
+// compact buffer, predicted a second time with the ballot rounds (exact by construction), and the streams compared.
+// Sampled block s = block s * nb_full / S (full-length blocks only).
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_gather_blocks(const uint8_t *in, uint32_t bs, uint32_t nb_full, uint32_t S, uint8_t *out) {
+    const uint32_t s = blockIdx.y;
+    const uint64_t src = (uint64_t)((uint64_t)s * nb_full / S) * bs;
+    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < bs; i += gridDim.x * 256u) out[(uint64_t)s * bs + i] = in[src + i];
+}
+__global__ void __launch_bounds__(256) k_compare_blocks(const uint4 *main_p, const uint4 *ver_p, uint32_t bs, uint32_t nb_full, uint32_t S, uint32_t *mismatch) {
+    const uint32_t s = blockIdx.y;
+    const uint64_t src = (uint64_t)((uint64_t)s * nb_full / S) * bs;
+    uint32_t bad = 0;
+    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < bs; i += gridDim.x * 256u) {
+        const uint4 x = main_p[src + i], y = ver_p[(uint64_t)s * bs + i];
+        bad |= (x.x ^ y.x) | (x.y ^ y.y) | (x.z ^ y.z) | (x.w ^ y.w);
+    }
+    if (__ballot(bad != 0u) && (threadIdx.x & 63u) == 0u) atomicAdd(mismatch, 1u);
 }
 
 // ---------------------------------------------------------------------------

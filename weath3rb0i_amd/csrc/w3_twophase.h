@@ -31,7 +31,8 @@ static inline const char *w3_tune_env(const char *name) {
 }
 
 // W3_OPT_VARIANT bits: alternative (bit-exact) implementations that the tests cross-check against the default ones
-enum { W3_VAR_NO_LDS_ATOMICS = 1, W3_VAR_PARTITION4 = 2, W3_VAR_NO_CHAINED_PARTITION = 4, W3_VAR_CM_UNSTAGED = 8, W3_VAR_NO_SIDE_STREAM = 16 };
+enum { W3_VAR_NO_LDS_ATOMICS = 1, W3_VAR_PARTITION4 = 2, W3_VAR_NO_CHAINED_PARTITION = 4, W3_VAR_CM_UNSTAGED = 8, W3_VAR_NO_SIDE_STREAM = 16,
+       W3_VAR_INJECT_LDS_FAULT = 32 /* tests: corrupt one LDS-add round per block, the sampled verification must catch it */ };
 
 struct TwoPhaseWs {
     void *P = nullptr, *keys = nullptr, *perm = nullptr, *redo = nullptr, *streams = nullptr, *rec = nullptr, *splits = nullptr;
@@ -68,7 +69,19 @@ struct TwoPhaseWs {
     uint32_t acc_limit = 46;   // test hook: lower values force the fast coder's fallback
     uint32_t variant = 0;      // W3_VAR_* (W3_OPT_VARIANT)
     uint32_t slot_budget_mb = 0;   // W3_OPT_SLOT_BUDGET_MB: cap on the slot leaves' hash-map batch (0 = from the free device memory)
+    int verify = 1;            // W3_OPT_VERIFY: sampled re-prediction with ballot rounds after every predict phase that used LDS-add rounds
+    TwoPhaseWs *vws = nullptr; // workspace of that re-prediction (owned)
+    void *vin = nullptr; size_t vin_cap = 0;   // the sampled blocks, gathered
+    bool used_lds_atomics = false;              // the last predict ran LDS-add rounds in some kernel
+    hipStream_t vstream = nullptr; hipEvent_t ev_v0 = nullptr, ev_v1 = nullptr;   // the re-prediction runs beside the APM and coder kernels
     void release() {
+        if (vws) { vws->release(); delete vws; vws = nullptr; }
+        if (vin) (void)hipFree(vin);
+        vin = nullptr; vin_cap = 0;
+        if (vstream) (void)hipStreamDestroy(vstream);
+        if (ev_v0) (void)hipEventDestroy(ev_v0);
+        if (ev_v1) (void)hipEventDestroy(ev_v1);
+        vstream = nullptr; ev_v0 = ev_v1 = nullptr;
         if (P) (void)hipFree(P);
         if (keys) (void)hipFree(keys);
         if (perm) (void)hipFree(perm);
@@ -201,6 +214,7 @@ static inline int twophase_predict(TwoPhaseWs &ws, hipStream_t s, const ParsedSp
     ws.P_valid = false;
     ws.achash_timed = false;
     const bool lds_atomics = twophase_lds_order_ok(ws, s);
+    ws.used_lds_atomics = false;
     const uint32_t grid_small = std::min<uint32_t>(nb, 256 * 20);
     const uint32_t grid_wide = std::min<uint32_t>(nb, 256 * 16);
     bool need_keys = false, need_perm = false;
@@ -260,6 +274,7 @@ static inline int twophase_predict(TwoPhaseWs &ws, hipStream_t s, const ParsedSp
     for (int k = 0; k < n_live; k++) {
         const w3_node &nd = ps.leaf[live[k]];
         const int c = leaf_class(nd);
+        if (lds_atomics && c != LEAF_SLOT) ws.used_lds_atomics = true;   // every Counter leaf's kernels run LDS-add rounds
         w3::PredictArgs pa;
         memset(&pa, 0, sizeof pa);
         pa.in = d_in; pa.n = n; pa.block_size = (uint32_t)block_size; pa.nblocks = nb;
@@ -276,6 +291,7 @@ static inline int twophase_predict(TwoPhaseWs &ws, hipStream_t s, const ParsedSp
         pa.maxseg = W3_ATOMIC_MAXSEG;
         if (const char *ev_ = w3_tune_env("W3_ATOMIC_MAXSEG")) pa.maxseg = (uint32_t)std::max(0, atoi(ev_));   // tuning hook
         if (!lds_atomics) pa.dbg_flags |= 2u;
+        if (ws.variant & W3_VAR_INJECT_LDS_FAULT) pa.dbg_flags |= 8u;
         bytes += n * 17;
         if (c == LEAF_SMALL_AC) {
             w3::HashArgs ha;
@@ -408,6 +424,58 @@ static inline int twophase_predict(TwoPhaseWs &ws, hipStream_t s, const ParsedSp
     return W3_OK;
 }
 
+#define W3_VERIFY_BLOCKS 16u   // sampled blocks per call (64: +2.0 ms per step beside k_apm0 at 1e9 B, measured; the check looks for a systematic
+                               // change of hardware behaviour, which shows in any block)
+
+// Always-on insurance for the one undocumented hardware property the default predict kernels rely on (returning LDS adds of
+// one wavefront resolve in ascending lane order: atomic_round, k_partition8).  After a predict phase that used it, up to W3_VERIFY_BLOCKS
+// evenly spaced full-length blocks (at most 64 MiB) are predicted AGAIN with the ballot rounds and 4-bit partitions — exact
+// by construction, no lane-order assumption — and every leaf's stream is compared on the device.  The main phase ran
+// under the production load (all CUs, 8 waves per CU); that is the condition the per-context self-test cannot reproduce.
+// d_mismatch (device word, zeroed by the caller) counts differing waves; the caller reads it with its status flags
+// and, when it is not zero, re-encodes the whole call on the ballot path and keeps the context there.
+static inline int twophase_verify(TwoPhaseWs &ws, hipStream_t s, const ParsedSpec &ps, const uint8_t *d_in, size_t n, size_t block_size,
+                                  uint32_t nb, uint32_t *d_mismatch, std::string &err) {
+    if (!ws.verify || !ws.used_lds_atomics) return W3_OK;
+    const uint32_t nb_full = (uint32_t)(n / block_size);
+    uint32_t S = (uint32_t)std::min<uint64_t>(std::min<uint32_t>(nb_full, W3_VERIFY_BLOCKS), std::max<uint64_t>(1, (64ull << 20) / block_size));
+    size_t vn = (size_t)S * block_size;
+    const uint8_t *vsrc = nullptr;
+    int rc;
+    if (nb_full == 0) { S = 1; vn = n; vsrc = d_in; (void)nb; }   // a single short block: verify it whole, in place
+    else {
+        if ((rc = tp_ensure(ws.vin, ws.vin_cap, vn, err))) return rc;
+        hipLaunchKernelGGL(w3::k_gather_blocks, dim3(std::min<uint32_t>((uint32_t)((block_size + 255) / 256), 64u), S), dim3(256), 0, s,
+                           d_in, (uint32_t)block_size, nb_full, S, (uint8_t *)ws.vin);
+        vsrc = (const uint8_t *)ws.vin;
+    }
+    if (!ws.vws) ws.vws = new TwoPhaseWs();
+    TwoPhaseWs &v = *ws.vws;
+    v.variant = (ws.variant | W3_VAR_NO_LDS_ATOMICS | W3_VAR_PARTITION4) & ~(uint32_t)W3_VAR_INJECT_LDS_FAULT;
+    v.lds_order = 0; v.verify = 0;
+    v.stretch = ws.stretch; v.squash = ws.squash; v.st = ws.st; v.huff = ws.huff; v.slot_budget_mb = ws.slot_budget_mb;
+    // only the Counter leaves are re-predicted: slot-state leaves do not use the property
+    ParsedSpec vps;
+    int map[W3_MAX_LEAVES], nmap = 0;   // vps leaf -> index among ws.mix.src (the live leaves of ps, in order)
+    int live_idx = 0;
+    for (int l = 0; l < ps.n_leaves; l++) {
+        const int c = leaf_class(ps.leaf[l]);
+        if (c == LEAF_FROZEN) continue;
+        if (c != LEAF_SLOT) { vps.leaf[vps.n_leaves++] = ps.leaf[l]; map[nmap++] = live_idx; }
+        live_idx++;
+    }
+    vps.n_huff = ps.n_huff; vps.huff = ps.huff;
+    if (vps.n_leaves == 0) return W3_OK;
+    if ((rc = twophase_predict(v, s, vps, vsrc, vn, block_size, (uint32_t)((vn + block_size - 1) / block_size), false, nullptr, nullptr, nullptr, err))) return rc;
+    const uint32_t cmp_bs = nb_full ? (uint32_t)block_size : (uint32_t)n;
+    for (int k = 0; k < nmap; k++)
+        hipLaunchKernelGGL(w3::k_compare_blocks, dim3(std::min<uint32_t>((cmp_bs + 255u) / 256u, 64u), S), dim3(256), 0, s,
+                           ws.mix.src[map[k]], v.mix.src[k], cmp_bs, nb_full ? nb_full : 1u, S, d_mismatch);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { err = std::string("verify launch: ") + hipGetErrorString(e); return W3_E_HIP; }
+    return W3_OK;
+}
+
 // APM chain at the root (w3_apm.h): turns the leaves' streams into the final stream ws.P, stage by stage.
 static inline int twophase_apm(TwoPhaseWs &ws, hipStream_t s, const ParsedSpec &ps, const uint8_t *d_in, size_t n, size_t block_size,
                                uint32_t nb, hipEvent_t *ev, w3_timing *tm, std::string &err) {
@@ -485,6 +553,27 @@ static inline int twophase_encode(TwoPhaseWs &ws, hipStream_t s, const ParsedSpe
     for (int l = 0; l < ps.n_leaves; l++) n_live += leaf_class(ps.leaf[l]) != LEAF_FROZEN;
     const bool x3 = (ws.coder_mode == 0 || ws.coder_mode == 4) && (n_live <= 4 || ps.n_apm > 0);   // more leaves: merge with k_mix first, then k_coder_x2
     int rc = twophase_predict(ws, s, ps, d_in, n, block_size, nb, !x3 && ps.n_apm == 0, nullptr, ev, tm, err);
+    if (rc) return rc;
+    // flag word 2: mismatching waves.  The re-prediction only reads the leaves' streams, so it runs on its own stream beside the
+    // APM and coder kernels (2.8 ms of small launches otherwise) — unless an APM stage is about to rewrite the single leaf's stream in place.
+    bool verify_forked = false;
+    if (ws.verify && ws.used_lds_atomics) {
+        const bool in_place = n_live == 1 && ps.n_apm > 0;
+        if (!in_place && !ws.vstream) {
+            bool ok = hipStreamCreateWithFlags(&ws.vstream, hipStreamNonBlocking) == hipSuccess && hipEventCreateWithFlags(&ws.ev_v0, hipEventDisableTiming) == hipSuccess &&
+                      hipEventCreateWithFlags(&ws.ev_v1, hipEventDisableTiming) == hipSuccess;
+            if (!ok) { (void)hipGetLastError(); err = "verification stream creation failed"; return W3_E_HIP; }
+        }
+        if (!in_place) {
+            (void)hipEventRecord(ws.ev_v0, s); (void)hipStreamWaitEvent(ws.vstream, ws.ev_v0, 0);
+            rc = twophase_verify(ws, ws.vstream, ps, d_in, n, block_size, nb, d_flag + 2, err);
+            (void)hipEventRecord(ws.ev_v1, ws.vstream);
+            verify_forked = true;
+        } else rc = twophase_verify(ws, s, ps, d_in, n, block_size, nb, d_flag + 2, err);
+        if (rc && !verify_forked) return rc;
+    }
+    // join on every way out of this function: the caller reads the mismatch word (and may free buffers) next
+    struct Join { hipStream_t st; hipEvent_t ev; bool on; ~Join() { if (on) (void)hipStreamWaitEvent(st, ev, 0); } } join{s, ws.ev_v1, verify_forked};
     if (rc) return rc;
     if (ws.ev_pred_done) (void)hipEventRecord(ws.ev_pred_done, s);   // the next block range may start its predict kernels
     hipStream_t s_lo = s;

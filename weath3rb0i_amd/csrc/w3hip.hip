@@ -156,9 +156,12 @@ extern "C" int w3_ctx_set_option(w3_ctx *ctx, int opt, int64_t value) {
         ctx->tp.acc_limit = (uint32_t)value;
         return W3_OK;
     case W3_OPT_VARIANT:
-        if (value < 0 || value > 31) return W3_E_INVALID;
+        if (value < 0 || value > 63) return W3_E_INVALID;
         ctx->tp.variant = (uint32_t)value;
         ctx->tp.lds_order = -1;   // re-run the lane-order self-test under the new setting
+        return W3_OK;
+    case W3_OPT_VERIFY:
+        ctx->tp.verify = value ? 1 : 0;
         return W3_OK;
     case W3_OPT_SLOT_BUDGET_MB:
         if (value < 0 || value > (1 << 20)) return W3_E_INVALID;
@@ -583,7 +586,7 @@ static int ensure_ranges(w3_ctx *ctx, int parts, bool timing) {
             for (auto &e : r.ev)
                 if (!e) HIPCHK(ctx, hipEventCreate(&e));
         r.ws.coder_mode = ctx->tp.coder_mode; r.ws.acc_limit = ctx->tp.acc_limit; r.ws.debug_stamps = 0;
-        r.ws.variant = ctx->tp.variant; r.ws.slot_budget_mb = ctx->tp.slot_budget_mb;
+        r.ws.variant = ctx->tp.variant; r.ws.slot_budget_mb = ctx->tp.slot_budget_mb; r.ws.verify = ctx->tp.verify;
         r.ws.stretch = ctx->tp.stretch; r.ws.squash = ctx->tp.squash; r.ws.st = ctx->tp.st; r.ws.huff = ctx->tp.huff;
     }
     return W3_OK;
@@ -628,7 +631,9 @@ extern "C" int w3_encode_blocks_device(w3_ctx *ctx, const w3_model_spec *spec, c
     memset(ptm, 0, sizeof ptm);
     if (parts > 1 && (rc = ensure_ranges(ctx, parts, ctx->opt_timing != 0))) return rc;
     ENSURE(ctx, ctx->flag, 16 * W3_MAX_PARTS);
-    for (int attempt = 0; attempt < 2; attempt++) {
+    bool cap_raised = false, fault_seen = false;
+    uint32_t lds_faults = 0;
+    for (int attempt = 0; attempt < 4; attempt++) {
         ENSURE(ctx, ctx->stripes, (size_t)nb * cap);
         HIPCHK(ctx, hipMemsetAsync(ctx->flag.p, 0, 16 * W3_MAX_PARTS, s));
         tm.start(3);
@@ -668,6 +673,21 @@ extern "C" int w3_encode_blocks_device(w3_ctx *ctx, const w3_model_spec *spec, c
         }
         HIPCHK(ctx, hipMemcpyAsync(fl, ctx->flag.p, sizeof fl, hipMemcpyDeviceToHost, s));
         HIPCHK(ctx, hipStreamSynchronize(s));
+        {   // sampled verification of the LDS-add rounds (twophase_verify): a mismatch means the hardware did not resolve returning LDS
+            // adds in lane order under this load.  The streams just coded cannot be trusted: code the call again with the ballot
+            // rounds, and keep this context on them.
+            uint32_t mism = 0;
+            for (int p = 0; p < parts && two; p++) mism += fl[4 * p + 2];
+            if (mism) {
+                if (fault_seen) { ctx->err = "predict streams differ from their ballot-round re-prediction even without LDS-add rounds (internal error)"; return W3_E_HIP; }
+                fault_seen = true;
+                lds_faults += mism;
+                ctx->tp.variant |= W3_VAR_NO_LDS_ATOMICS; ctx->tp.lds_order = 0;
+                for (auto &r : ctx->ranges) { r.ws.variant |= W3_VAR_NO_LDS_ATOMICS; r.ws.lds_order = 0; }
+                ctx->timing.n_recoded_blocks = 0;
+                continue;
+            }
+        }
         bool recoded = false;
         for (int p = 0; p < parts && two; p++) {
             if (!fl[4 * p + 1]) continue;   // blocks the fast coder handed back (pending-bit run longer than its accumulator)
@@ -688,10 +708,12 @@ extern "C" int w3_encode_blocks_device(w3_ctx *ctx, const w3_model_spec *spec, c
         if (f0 & 2u) { ctx->err = "coder pipeline timeout (internal error)"; return W3_E_HIP; }
         const uint32_t ovf = f0 & 1u;
         if (!ovf) break;
-        if (attempt == 1) { ctx->err = "stripe overflow at the worst-case bound (internal error)"; return W3_E_HIP; }
+        if (cap_raised) { ctx->err = "stripe overflow at the worst-case bound (internal error)"; return W3_E_HIP; }
         cap = worst_stripe_cap(block_size);  // rare: a block expanded past 2N+64
+        cap_raised = true;
         ctx->timing.n_recoded_blocks = 0;
     }
+    ctx->timing.n_lds_faults = lds_faults;
     Timer tp{ctx, s, 0};
     tp.start(2);
     rc = run_pack(ctx, s, (const uint8_t *)ctx->stripes.p, cap, d_block_lens, nb, d_out, out_cap, total_p);
