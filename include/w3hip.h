@@ -175,6 +175,31 @@ int w3_decode_blocks_device(w3_ctx *ctx, const w3_model_spec *spec,
                             const uint8_t *d_in, size_t in_len, const uint32_t *d_block_lens, size_t nblocks,
                             size_t block_size, uint64_t orig_len, uint8_t *d_out, void *stream);
 
+/* ---- ACStats, the counting sink (helpers.rs:60-90) -------------------------------
+ * Every figure the reference publishes is `csize = bits / 8` from this sink (bin/ordern/main.rs:66-80): write_bit counts
+ * 1 + the pending parity bits it resolves, flush adds nothing (:87-89).  block_bits[b] = that count for block b coded
+ * alone (u32: blocks below 2^28 bytes); csize of a block = block_bits[b] / 8 (:70-73).  Same kernels as the encode,
+ * without the pack; nothing is copied out but the counts.                                                          */
+int w3_encode_stats(w3_ctx *ctx, const w3_model_spec *spec, const uint8_t *in, size_t n, size_t block_size, uint32_t *block_bits);
+int w3_encode_stats_device(w3_ctx *ctx, const w3_model_spec *spec, const uint8_t *d_in, size_t n, size_t block_size,
+                           uint32_t *d_block_bits, void *stream);
+
+/* ---- parameter sweep (bin/ordern/main.rs:9-80) ----------------------------------
+ * OrderN::new(bits[c], aligns[c]) for every configuration c, each through the counting sink on every block, ALL IN ONE
+ * LAUNCH (lanes = configurations x blocks; batches only when the Counter tables exceed the device memory).
+ * block_bits (host memory) = [ncfg][nblocks] bit counts, configuration-major.  The reference runs the configurations one
+ * after the other on one thread; the driver around this call (weath3rb0i_amd/sweep.py) prints its lines.            */
+int w3_sweep_ordern(w3_ctx *ctx, const uint8_t *in, size_t n, size_t block_size, const uint8_t *bits, const uint8_t *aligns,
+                    size_t ncfg, uint32_t *block_bits);
+int w3_sweep_ordern_device(w3_ctx *ctx, const uint8_t *d_in, size_t n, size_t block_size, const uint8_t *bits, const uint8_t *aligns,
+                           size_t ncfg, uint32_t *block_bits);
+
+/* ---- context statistics export (README.md:9: "output stats from contexts for use by external neural nets") --------
+ * The Counter table (`stats`, models/ordern.rs:5 / ordern_entropy.rs:6) of a one-leaf adaptive model after it has seen
+ * `in` as ONE stream, i.e. the state the reference's model is in when compress() returns: counters[ctx] = n0 | n1 << 16
+ * (models/counter.rs:4-6) for ctx in 0 .. 2^bits_in_context.  bits_in_context <= 28, n <= 2^28.                       */
+int w3_export_counters(w3_ctx *ctx, const w3_model_spec *spec, const uint8_t *in, size_t n, uint32_t *counters);
+
 /* ---- the reference's whole-file container ----------------------------------
  * compress()/decompress() of main.rs:89-144: b"w30i" + u64 BE length + ONE
  * stream.  One serial chain => one GPU lane; provided for format parity.     */

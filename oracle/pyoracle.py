@@ -47,6 +47,8 @@ def _load():
     lib.w3o_encode_stream.argtypes = [vp, vp, sz, C.POINTER(sz)]
     lib.w3o_encode_stats.restype = C.c_uint64
     lib.w3o_encode_stats.argtypes = [vp, vp, sz]
+    lib.w3o_encode_stats_bits.restype = C.c_uint64
+    lib.w3o_encode_stats_bits.argtypes = [vp, vp, sz]
     lib.w3o_decode_stream.argtypes = [vp, vp, sz, vp, sz]
     lib.w3o_predict_all.argtypes = [vp, vp, sz, vp]
     lib.w3o_compress_container.restype = C.POINTER(C.c_uint8)
@@ -415,6 +417,12 @@ def encode_stream(model, data):
 def encode_stats(model, data):
     a, p = _buf(data)
     return lib.w3o_encode_stats(model.ptr, p, len(a))
+
+
+def encode_stats_bits(model, data):
+    """ACStats::bit_count (helpers.rs:62): csize = bits // 8."""
+    a, p = _buf(data)
+    return lib.w3o_encode_stats_bits(model.ptr, p, len(a))
 
 
 def decode_stream(model, data, n):

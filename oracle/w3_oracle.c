@@ -618,6 +618,12 @@ uint64_t w3o_encode_stats(w3o_model *m, const uint8_t *in, size_t n) {
     encode_into(m, in, n, &w);
     return w3o_stats_result(&w);
 }
+uint64_t w3o_encode_stats_bits(w3o_model *m, const uint8_t *in, size_t n) { /* ACStats::bit_count itself (helpers.rs:62, :79-82) */
+    w3o_sink w;
+    w3o_sink_init_stats(&w);
+    encode_into(m, in, n, &w);
+    return w.bit_count;
+}
 
 void w3o_predict_all(w3o_model *m, const uint8_t *in, size_t n, uint16_t *p_out) {
     for (size_t k = 0; k < n; k++)

@@ -144,6 +144,7 @@ uint16_t   w3o_opinion_mix(uint16_t p1, uint16_t p2);          /* mixers/opinion
 uint8_t *w3o_encode_stream(w3o_model *m, const uint8_t *in, size_t n, size_t *out_len);
 /* Same loop into the counting sink (bin/order0/main.rs:13-25): returns csize = bits/8 */
 uint64_t w3o_encode_stats(w3o_model *m, const uint8_t *in, size_t n);
+uint64_t w3o_encode_stats_bits(w3o_model *m, const uint8_t *in, size_t n);   /* the raw bit count (csize = bits / 8) */
 /* decode loop  main.rs:131-140 */
 void w3o_decode_stream(w3o_model *m, const uint8_t *in, size_t in_len, uint8_t *out, size_t n);
 /* the per-step probabilities (debug aid for the two-phase GPU path) */

@@ -49,8 +49,53 @@ def test_sweep_csizes_match_the_oracle(oracle):
     finally:
         ctx.close()
     want = {}
-    for (b, a) in got:
-        _, lens = oracle.encode_blocks(oracle.OrderN(b, a), data, 4096, nthreads=8)
-        want[(b, a)] = int(lens.sum())
+    for (b, a) in got:   # csize = (sum of the blocks' ACStats bit counts) / 8 (helpers.rs:70-73)
+        want[(b, a)] = sum(oracle.encode_stats_bits(oracle.OrderN(b, a), data[o:o + 4096]) for o in range(0, len(data), 4096)) // 8
     assert got == want
     assert best == min(want.values()) and want[params] == best
+
+
+@pytest.mark.gpu
+def test_counting_sink_and_sweep_and_export_match_the_oracle(oracle):
+    """A14 (ACStats) on every coder kernel and both paths; the one-launch sweep per (configuration, block); the context
+    statistics export against the oracle's Counter table semantics."""
+    import weath3rb0i_amd as w3
+    from tests.synth import lcg_text
+    data = markov_text(5 * 8192 + 333, seed=52) + bytes(9000) + lcg_text(7000, seed=9)
+    bs = 8192
+    blocks = [data[o:o + bs] for o in range(0, len(data), bs)]
+    ctx = w3.Context(0)
+    try:
+        cases = [("order0", w3.Order0, oracle.Order0), ("best012", lambda: w3.BestOfTwoModel(w3.BestOfTwoModel(w3.Order0(), w3.Order1()), w3.OrderN(27, 3)),
+                                                        lambda: oracle.BestOfTwoModel(oracle.BestOfTwoModel(oracle.Order0(), oracle.Order1()), oracle.OrderN(27, 3))),
+                 ("ordern_14_4", lambda: w3.OrderN(14, 4), lambda: oracle.OrderN(14, 4)),
+                 ("o012apm", lambda: w3.APM(w3.BestOfTwoModel(w3.Order0(), w3.Order1())), lambda: oracle.APM(oracle.BestOfTwoModel(oracle.Order0(), oracle.Order1())))]
+        for name, dev, orc in cases:
+            want = [oracle.encode_stats_bits(orc(), blk) for blk in blocks]
+            for path in ("auto", "generic"):
+                ctx.set_path(path)
+                for coder in (("x4", "x3", "x2", "fast", "robust") if path == "auto" else ("x4",)):
+                    ctx.set_coder(coder)
+                    got = ctx.encode_stats(dev(), data, bs)
+                    assert got.tolist() == want, (name, path, coder)
+        ctx.set_path("auto"); ctx.set_coder("x4")
+        configs = [(8, 0), (11, 3), (12, 4), (19, 3), (22, 2), (27, 3), (30, 1)]
+        got = ctx.sweep_ordern(data, bs, configs)
+        for c, row in zip(configs, got):
+            assert row.tolist() == [oracle.encode_stats_bits(oracle.OrderN(*c), blk) for blk in blocks], c
+        # export: Counter (n0, n1) per context after the whole input as one stream == a direct replay of Counter::update
+        n0, n1 = ctx.export_counters(w3.OrderN(11, 3), data[:20000])
+        c0 = np.zeros(1 << 11, dtype=np.int64); c1 = np.zeros(1 << 11, dtype=np.int64)
+        hist = t = 0
+        for byte in data[:20000]:
+            for j in range(8):
+                bit = (byte >> (7 - j)) & 1
+                cx = (((hist & 0xFF) << 3) | (t & 7)) if t else 0
+                if bit: c1[cx] += 1
+                else: c0[cx] += 1
+                if (c1[cx] if bit else c0[cx]) == 65535:
+                    c0[cx] = (c0[cx] >> 1) + (c0[cx] & 1); c1[cx] = (c1[cx] >> 1) + (c1[cx] & 1)
+                hist = (hist << 1) | bit; t += 1
+        assert n0.astype(np.int64).tolist() == c0.tolist() and n1.astype(np.int64).tolist() == c1.tolist()
+    finally:
+        ctx.close()

@@ -109,6 +109,37 @@ class Context:
         self._chk(rc)
         return out[:orig_len]
 
+    def encode_stats(self, model, data, block_size):
+        """ACStats (helpers.rs:60-90) per block: the bit counts the reference's `csize = bits / 8` comes from.  -> np.uint32[nb]"""
+        spec = model.spec() if isinstance(model, Model) else model
+        a = _u8(data)
+        nb = (len(a) + block_size - 1) // block_size if block_size else 0
+        bits = np.zeros(max(nb, 1), dtype=np.uint32)
+        self._chk(self.lib.w3_encode_stats(self.h, C.byref(spec), a.ctypes.data_as(C.c_void_p), len(a), block_size, bits.ctypes.data_as(C.c_void_p)))
+        return bits[:nb]
+
+    def sweep_ordern(self, data, block_size, configs):
+        """OrderN(bits, align) for every (bits, align) in `configs`, all in one device launch (bin/ordern/main.rs:9-80).
+        -> np.uint32[len(configs)][nb] ACStats bit counts."""
+        a = _u8(data)
+        nb = (len(a) + block_size - 1) // block_size if block_size else 0
+        cb = np.array([c[0] for c in configs], dtype=np.uint8)
+        ca = np.array([c[1] for c in configs], dtype=np.uint8)
+        out = np.zeros((len(configs), max(nb, 1)), dtype=np.uint32)
+        self._chk(self.lib.w3_sweep_ordern(self.h, a.ctypes.data_as(C.c_void_p), len(a), block_size, cb.ctypes.data_as(C.c_void_p),
+                                           ca.ctypes.data_as(C.c_void_p), len(configs), out.ctypes.data_as(C.c_void_p)))
+        return out[:, :nb]
+
+    def export_counters(self, model, data):
+        """Context statistics export (README.md:9): the model's Counter table after `data` as one stream.
+        -> (n0: np.uint16[2^bits], n1: np.uint16[2^bits])"""
+        spec = model.spec()
+        a = _u8(data)
+        bits = spec.nodes[0].bits
+        t = np.zeros(1 << bits, dtype=np.uint32)
+        self._chk(self.lib.w3_export_counters(self.h, C.byref(spec), a.ctypes.data_as(C.c_void_p), len(a), t.ctypes.data_as(C.c_void_p)))
+        return (t & 0xFFFF).astype(np.uint16), (t >> 16).astype(np.uint16)
+
     def predict_blocks(self, model, data, block_size):
         spec = model.spec()
         a = _u8(data)

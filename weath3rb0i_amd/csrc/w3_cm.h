@@ -208,6 +208,7 @@ __global__ void __launch_bounds__(64) k_cm(CmArgs a) {
         if (DECODE) g.dout[off + i] = (uint8_t)byte;
     }
     if (!DECODE) {
+        if (g.out_bits) g.out_bits[b] = enc.stats_bits();
         const uint32_t produced = enc.flush();
         g.out_len[b] = produced;
         if (produced > g.stripe_cap) atomicOr(g.overflow, 1u);
@@ -411,6 +412,7 @@ __global__ void __launch_bounds__(64) k_cm_staged(CmArgs a) {
         if (DECODE) g.dout[off + i] = (uint8_t)byte;
     }
     if (!DECODE) {
+        if (g.out_bits) g.out_bits[b] = enc.stats_bits();
         const uint32_t produced = enc.flush();
         g.out_len[b] = produced;
         if (produced > g.stripe_cap) atomicOr(g.overflow, 1u);
@@ -510,6 +512,7 @@ __global__ void __launch_bounds__(64) k_cm_nl(CmArgs a) {
         if (DECODE) g.dout[off + i] = (uint8_t)byte;
     }
     if (!DECODE) {
+        if (g.out_bits) g.out_bits[b] = enc.stats_bits();
         const uint32_t produced = enc.flush();
         g.out_len[b] = produced;
         if (produced > g.stripe_cap) atomicOr(g.overflow, 1u);

@@ -36,6 +36,7 @@ struct CoderArgs {
     uint32_t *redo;        // fast coder: blocks to re-code; safe coder: list to process (or null = all)
     uint32_t n_redo;
     uint32_t acc_limit;    // fast coder: max bits held before a step (46 = 64 - 18)
+    uint32_t *out_bits;    // [nblocks] ACStats bit count of each block (helpers.rs:60-90: written bits before the flush), or null
 };
 
 // Robust coder: counted pending bits (Encoder in w3_device.h).  Codes the
@@ -63,6 +64,7 @@ __global__ void __launch_bounds__(64) k_coder(CoderArgs a) {
         enc.encode((byte >> 1) & 1u, pv.w & 0xFFFFu);
         enc.encode(byte & 1u, pv.w >> 16);
     }
+    if (a.out_bits) a.out_bits[b] = enc.stats_bits();
     const uint32_t produced = enc.flush();
     a.out_len[b] = produced;
     if (produced > a.stripe_cap) atomicOr(&a.flags[0], 1u);
@@ -164,6 +166,7 @@ __global__ void __launch_bounds__(64) k_coder_fast(CoderArgs a) {
     }
     // ArithmeticCoder::flush -> ACWriter::flush(x2) (arithmetic_coder.rs:67-71, io.rs:91-100):
     // first bit x2>>31 (= 1) resolves the slot and the pending bits, then x2's next bits pad to a byte
+    if (a.out_bits && !failed) a.out_bits[b] = 8u * e.pos + e.nb - (trailing_ones64(e.acc) + 1u);   // ACStats: all bits but the slot and the pending ones
     e.acc += 1ull;
     const uint32_t idx = e.nb & 7u;
     if (idx) {
@@ -342,6 +345,7 @@ __global__ void __launch_bounds__(128) k_coder_x2(CoderArgs a) {
     if (!act) return;
     // ACWriter::flush(x2) (io.rs:91-100)
     const uint32_t x2f = fin_x2[lane];
+    if (a.out_bits && !failed) a.out_bits[b] = 8u * pos + nb - (trailing_ones64(acc) + 1u);   // ACStats: all bits but the slot and the pending ones
     acc += 1ull;
     const uint32_t idx = nb & 7u;
     if (idx) { const uint32_t k = 8u - idx; acc = (acc << k) | ((x2f << 1) >> (32u - k)); nb += k; }
@@ -395,6 +399,7 @@ struct Coder3Args {
     uint32_t *flags;       // [0] bit0 stripe overflow, bit1 pipeline timeout; [1] blocks in redo
     uint32_t *redo;
     uint32_t acc_limit;
+    uint32_t *out_bits;    // [nblocks] ACStats bit count of each block (helpers.rs:60-90), or null
 };
 
 // SLEEP: s_sleep units (64 clocks) between polls.  The recurrence wave polls eagerly (it is the critical path); the mix and
@@ -619,6 +624,7 @@ __global__ void __launch_bounds__(192) k_coder_x3(Coder3Args a) {
     if (dead) { if (lane == 0) atomicOr(&a.flags[0], 2u); return; }
     if (!act) return;
     const uint32_t x2f = fin_x2[lane];
+    if (a.out_bits && !failed) a.out_bits[b] = 8u * pos + nb - (trailing_ones64(acc) + 1u);   // ACStats: all bits but the slot and the pending ones
     acc += 1ull;
     const uint32_t idx = nb & 7u;
     if (idx) { const uint32_t k = 8u - idx; acc = (acc << k) | ((x2f << 1) >> (32u - k)); nb += k; }

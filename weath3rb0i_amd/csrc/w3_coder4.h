@@ -539,6 +539,7 @@ __global__ void __launch_bounds__(L > 1 ? 256 : 192) k_coder_x4(Coder3Args a) {
     auto finish = [&]() {
         const uint2 f = fin[lane];
         const uint32_t x2f = ((f.x & 0x7FFFFFFFu) + f.y) | 0x80000000u;
+        if (a.out_bits && !failed && cap) a.out_bits[b] = 8u * pos + nb - (trailing_ones64(acc) + 1u);   // ACStats (helpers.rs:60-90): all bits but the slot and the pending ones
         uint64_t fa = acc + 1ull; uint32_t fnb = nb, fpos = pos;
         const uint32_t idx = fnb & 7u;
         if (idx) { const uint32_t kk = 8u - idx; fa = (fa << kk) | ((x2f << 1) >> (32u - kk)); fnb += kk; }

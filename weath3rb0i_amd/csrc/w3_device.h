@@ -130,6 +130,10 @@ struct Encoder {
         rev += m;
     }
 
+    // ACStats (helpers.rs:60-90), the counting sink: bits written so far (write_bit adds 1 + rev_bits; pending parity bits not
+    // yet resolved do not count; flush adds nothing, :87-89).  Valid before flush().
+    __device__ __forceinline__ uint32_t stats_bits() const { return 8u * out.pos + out.nb; }
+
     // ArithmeticCoder::flush -> ACWriter::flush(x2)  (arithmetic_coder.rs:67-71, io.rs:91-100)
     __device__ __forceinline__ uint32_t flush() {
         emit(x2 >> 31, 1u);

@@ -37,6 +37,7 @@ struct GenericArgs {
     uint8_t  *stripes;       // lane-major output stripes (encode)
     uint32_t  stripe_cap;
     uint32_t *out_len;       // [nblocks] bytes produced
+    uint32_t *out_bits;      // [nblocks] ACStats bit count of each block (helpers.rs:60-90), or null
     uint32_t *overflow;      // set to 1 if any stripe overflowed
     // decode
     const uint8_t  *cin;     // concatenated block streams
@@ -175,6 +176,7 @@ __global__ void __launch_bounds__(64) k_generic(GenericArgs a) {
         if (DECODE) a.dout[off + i] = (uint8_t)byte;
     }
     if (!DECODE) {
+        if (a.out_bits) a.out_bits[b] = enc.stats_bits();
         uint32_t produced = enc.flush();
         a.out_len[b] = produced;
         if (produced > a.stripe_cap) atomicOr(a.overflow, 1u);
@@ -259,6 +261,7 @@ __global__ void __launch_bounds__(64) k_generic_nl(GenericArgs a) {
         if (DECODE) a.dout[off + i] = (uint8_t)byte;
     }
     if (!DECODE) {
+        if (a.out_bits) a.out_bits[b] = enc.stats_bits();
         uint32_t produced = enc.flush();
         a.out_len[b] = produced;
         if (produced > a.stripe_cap) atomicOr(a.overflow, 1u);

@@ -48,6 +48,7 @@ struct TwoPhaseWs {
     const uint16_t *squash = nullptr;
     const uint2 *st = nullptr;          // NaiveStateTable rows for the slot-state leaves (device; owned by the ctx)
     const w3_huff_table *huff = nullptr;   // HuffHistory table sets of the current call's spec (device; owned by the ctx)
+    uint32_t *out_bits = nullptr;          // [nb of this range] ACStats bit counts (device; owned by the ctx), or null
     // wide Counter leaves: their k_partition passes run on a side stream beside the time-ordered leaves' kernels
     void *rec_w[4] = {nullptr, nullptr, nullptr, nullptr}, *perm_w[4] = {nullptr, nullptr, nullptr, nullptr}, *splits_w[4] = {nullptr, nullptr, nullptr, nullptr};
     size_t rec_w_cap[4] = {0, 0, 0, 0}, perm_w_cap[4] = {0, 0, 0, 0}, splits_w_cap[4] = {0, 0, 0, 0};
@@ -600,6 +601,7 @@ static inline int twophase_encode(TwoPhaseWs &ws, hipStream_t s, const ParsedSpe
         for (int l = 0; l < ws.mix.n_src; l++) c3.src[l] = ws.mix.src[l];
         c3.stripes = stripes; c3.stripe_cap = stripe_cap; c3.out_len = d_lens; c3.flags = d_flag; c3.redo = (uint32_t *)ws.redo;
         c3.acc_limit = limit;
+        c3.out_bits = ws.out_bits;
         const dim3 grid((nb + 63) / 64), blk(192);
         if (ws.coder_mode == 4) {
             switch (ws.mix.n_src) {
@@ -624,6 +626,7 @@ static inline int twophase_encode(TwoPhaseWs &ws, hipStream_t s, const ParsedSpe
         ca.in = d_in; ca.n = n; ca.block_size = (uint32_t)block_size; ca.nblocks = nb; ca.P = (const uint4 *)ws.P;
         ca.stripes = stripes; ca.stripe_cap = stripe_cap; ca.out_len = d_lens; ca.flags = d_flag;
         ca.acc_limit = limit;
+        ca.out_bits = ws.out_bits;
         if (ws.coder_mode == 2) {
             ca.redo = nullptr;
             hipLaunchKernelGGL(w3::k_coder, dim3((nb + 63) / 64), dim3(64), 0, s, ca);
@@ -652,6 +655,7 @@ static inline int twophase_recode(TwoPhaseWs &ws, hipStream_t s, const uint8_t *
     ca.in = d_in; ca.n = n; ca.block_size = (uint32_t)block_size; ca.nblocks = nb; ca.P = (const uint4 *)ws.P;
     ca.stripes = stripes; ca.stripe_cap = stripe_cap; ca.out_len = d_lens; ca.flags = d_flag;
     ca.redo = (uint32_t *)ws.redo; ca.n_redo = n_redo;
+    ca.out_bits = ws.out_bits;
     hipLaunchKernelGGL(w3::k_coder, dim3((n_redo + 63) / 64), dim3(64), 0, s, ca);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { err = std::string("recode launch: ") + hipGetErrorString(e); return W3_E_HIP; }

@@ -18,6 +18,7 @@
 #include "w3_pack.h"
 #include "w3_twophase.h"
 #include "w3_selftest.h"
+#include "w3_sweep.h"
 
 using namespace w3;
 
@@ -42,7 +43,7 @@ struct w3_ctx {
     w3_timing timing{};
     hipEvent_t ev[14]{};
     // workspace
-    DevBuf tables, stripes, lens, offs, total, flag, io_in, io_out, coffs, misc, cm_luts, achash_luts, huff;
+    DevBuf tables, stripes, lens, offs, total, flag, io_in, io_out, coffs, misc, cm_luts, achash_luts, huff, bits, sweep;
     TwoPhaseWs tp;
     // block ranges 1..3 of a pipelined two-phase encode (range 0 uses tp, ev and the caller's stream)
     struct Range { TwoPhaseWs ws; hipStream_t stream = nullptr; hipEvent_t ev[14]{}; hipEvent_t ev_done = nullptr; };
@@ -116,7 +117,7 @@ extern "C" void w3_ctx_destroy(w3_ctx *ctx) {
     (void)hipSetDevice(ctx->device);
     (void)hipDeviceSynchronize();
     DevBuf *bufs[] = {&ctx->tables, &ctx->stripes, &ctx->lens, &ctx->offs, &ctx->total, &ctx->flag,
-                      &ctx->io_in, &ctx->io_out, &ctx->coffs, &ctx->misc, &ctx->cm_luts, &ctx->achash_luts, &ctx->huff};
+                      &ctx->io_in, &ctx->io_out, &ctx->coffs, &ctx->misc, &ctx->cm_luts, &ctx->achash_luts, &ctx->huff, &ctx->bits, &ctx->sweep};
     for (DevBuf *b : bufs)
         if (b->p) (void)hipFree(b->p);
     ctx->tp.release();
@@ -375,6 +376,7 @@ static int generic_encode(w3_ctx *ctx, hipStream_t s, const ParsedSpec &ps, cons
     ga.huff = ctx->tp.huff; ga.n_huff = (int)ps.n_huff;
     ga.tables = (uint8_t *)ctx->tables.p; ga.lane_stride = lane_stride;
     ga.in = d_in; ga.stripe_cap = stripe_cap; ga.out_len = d_lens; ga.overflow = (uint32_t *)ctx->flag.p;
+    ga.out_bits = (uint32_t *)ctx->bits.p;
     for (uint32_t first = 0; first < nb; first += lanes) {
         uint32_t cnt = std::min(lanes, nb - first);
         ga.first_block = first; ga.n_lanes = cnt;
@@ -513,6 +515,7 @@ static int cm_encode(w3_ctx *ctx, hipStream_t s, const ParsedSpec &ps, const uin
     ca.g.n = n; ca.g.block_size = (uint32_t)block_size;
     ca.g.huff = ctx->tp.huff; ca.g.n_huff = (int)ps.n_huff;
     ca.g.in = d_in; ca.g.stripe_cap = stripe_cap; ca.g.out_len = d_lens; ca.g.overflow = (uint32_t *)ctx->flag.p;
+    ca.g.out_bits = (uint32_t *)ctx->bits.p;
     return cm_run<false>(ctx, s, ca, lane_stride, nb, stripe_cap);
 }
 
@@ -592,8 +595,10 @@ static int ensure_ranges(w3_ctx *ctx, int parts, bool timing) {
     return W3_OK;
 }
 
-extern "C" int w3_encode_blocks_device(w3_ctx *ctx, const w3_model_spec *spec, const uint8_t *d_in, size_t n, size_t block_size,
-                                       uint8_t *d_out, size_t out_cap, uint32_t *d_block_lens, uint64_t *d_total, void *stream) {
+// d_out == nullptr: counting-sink mode (ACStats, helpers.rs:60-90) — the streams are coded into the stripes as usual, the
+// pack is skipped and only ctx->bits (per-block bit counts) is of interest; d_block_lens may then be a scratch buffer.
+static int encode_core(w3_ctx *ctx, const w3_model_spec *spec, const uint8_t *d_in, size_t n, size_t block_size,
+                       uint8_t *d_out, size_t out_cap, uint32_t *d_block_lens, uint64_t *d_total, void *stream) {
     int rc = check_args(ctx, n, block_size);
     if (rc) return rc;
     ParsedSpec ps;
@@ -609,8 +614,9 @@ extern "C" int w3_encode_blocks_device(w3_ctx *ctx, const w3_model_spec *spec, c
         HIPCHK(ctx, hipStreamSynchronize(s));
         return W3_OK;
     }
-    if (!d_in || !d_out || !d_block_lens) return W3_E_INVALID;
+    if (!d_in || !d_block_lens) return W3_E_INVALID;
     ENSURE(ctx, ctx->flag, 16);
+    ENSURE(ctx, ctx->bits, (size_t)nb * 4);
     if ((rc = stage_huff(ctx, s, ps))) return rc;
 
     bool two = twophase_supported(ps, block_size, n);   // Counter and slot-state leaves + APM chain (decode: k_generic / k_cm)
@@ -652,6 +658,7 @@ extern "C" int w3_encode_blocks_device(w3_ctx *ctx, const w3_model_spec *spec, c
                 }
                 ws.use_hi = parts > 1 && !w3_tune_env("W3_NO_HI_STREAM");
                 ws.ev_pred_done = parts > 1 ? ctx->ev_pred[p] : nullptr;
+                ws.out_bits = (uint32_t *)ctx->bits.p + pb[p];
                 if (p && ctx->tp.lds_order >= 0) ws.lds_order = ctx->tp.lds_order;   // (range 0 has run the self-test)
                 rc = twophase_encode(ws, sp, ps, d_in + o, np, block_size, pb[p + 1] - pb[p], (uint8_t *)ctx->stripes.p + (size_t)pb[p] * cap, cap,
                                      d_block_lens + pb[p], (uint32_t *)ctx->flag.p + 4 * p, evp, &ptm[p], ctx->err);
@@ -715,14 +722,16 @@ extern "C" int w3_encode_blocks_device(w3_ctx *ctx, const w3_model_spec *spec, c
     }
     ctx->timing.n_lds_faults = lds_faults;
     Timer tp{ctx, s, 0};
-    tp.start(2);
-    rc = run_pack(ctx, s, (const uint8_t *)ctx->stripes.p, cap, d_block_lens, nb, d_out, out_cap, total_p);
-    tp.stop();
-    tm.i = 3; tm.stop();
-    if (rc) return rc;
     uint64_t total = 0;
-    HIPCHK(ctx, hipMemcpyAsync(&total, total_p, 8, hipMemcpyDeviceToHost, s));
-    HIPCHK(ctx, hipStreamSynchronize(s));
+    if (d_out) {
+        tp.start(2);
+        rc = run_pack(ctx, s, (const uint8_t *)ctx->stripes.p, cap, d_block_lens, nb, d_out, out_cap, total_p);
+        tp.stop();
+        tm.i = 3; tm.stop();
+        if (rc) return rc;
+        HIPCHK(ctx, hipMemcpyAsync(&total, total_p, 8, hipMemcpyDeviceToHost, s));
+        HIPCHK(ctx, hipStreamSynchronize(s));
+    } else { tm.i = 3; tm.stop(); HIPCHK(ctx, hipStreamSynchronize(s)); }
     if (two) {
         for (int p = 0; p < parts; p++) {
             ctx->timing.coder_bytes += ptm[p].coder_bytes; ctx->timing.predict_bytes += ptm[p].predict_bytes;
@@ -742,11 +751,53 @@ extern "C" int w3_encode_blocks_device(w3_ctx *ctx, const w3_model_spec *spec, c
                 if (ws.achash_timed) ctx->timing.achash_ms += elapsed_ev(evp, 6);
             }
         }
-        ctx->timing.pack_ms = elapsed(ctx, 2);
+        ctx->timing.pack_ms = d_out ? elapsed(ctx, 2) : 0.f;
         ctx->timing.total_ms = elapsed(ctx, 3);
     }
     ctx->timing.n_parts = (uint32_t)parts;
-    if (total > out_cap) { ctx->err = "out_cap too small"; return W3_E_NOSPACE; }
+    if (d_out && total > out_cap) { ctx->err = "out_cap too small"; return W3_E_NOSPACE; }
+    return W3_OK;
+}
+
+extern "C" int w3_encode_blocks_device(w3_ctx *ctx, const w3_model_spec *spec, const uint8_t *d_in, size_t n, size_t block_size,
+                                       uint8_t *d_out, size_t out_cap, uint32_t *d_block_lens, uint64_t *d_total, void *stream) {
+    if (n && !d_out) return W3_E_INVALID;
+    return encode_core(ctx, spec, d_in, n, block_size, d_out, out_cap, d_block_lens, d_total, stream);
+}
+
+// ---------------------------------------------------------------------------
+// ACStats (helpers.rs:60-90): the counting sink every published figure of the reference comes from
+// ---------------------------------------------------------------------------
+extern "C" int w3_encode_stats_device(w3_ctx *ctx, const w3_model_spec *spec, const uint8_t *d_in, size_t n, size_t block_size,
+                                      uint32_t *d_block_bits, void *stream) {
+    int rc = check_args(ctx, n, block_size);
+    if (rc) return rc;
+    const size_t nb = (n + block_size - 1) / block_size;
+    if (nb == 0) return w3_spec_validate(spec);
+    if (!d_in || !d_block_bits) return W3_E_INVALID;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    ENSURE(ctx, ctx->lens, nb * 4);
+    rc = encode_core(ctx, spec, d_in, n, block_size, nullptr, 0, (uint32_t *)ctx->lens.p, nullptr, stream);
+    if (rc) return rc;
+    hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
+    HIPCHK(ctx, hipMemcpyAsync(d_block_bits, ctx->bits.p, nb * 4, hipMemcpyDeviceToDevice, s));
+    HIPCHK(ctx, hipStreamSynchronize(s));
+    return W3_OK;
+}
+
+extern "C" int w3_encode_stats(w3_ctx *ctx, const w3_model_spec *spec, const uint8_t *in, size_t n, size_t block_size, uint32_t *block_bits) {
+    int rc = check_args(ctx, n, block_size);
+    if (rc) return rc;
+    const size_t nb = (n + block_size - 1) / block_size;
+    if (nb == 0) return w3_spec_validate(spec);
+    if (!in || !block_bits) return W3_E_INVALID;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    ENSURE(ctx, ctx->io_in, n);
+    ENSURE(ctx, ctx->lens, nb * 4);
+    HIPCHK(ctx, hipMemcpyAsync(ctx->io_in.p, in, n, hipMemcpyHostToDevice, ctx->stream));
+    rc = encode_core(ctx, spec, (const uint8_t *)ctx->io_in.p, n, block_size, nullptr, 0, (uint32_t *)ctx->lens.p, nullptr, ctx->stream);
+    if (rc) return rc;
+    HIPCHK(ctx, hipMemcpy(block_bits, ctx->bits.p, nb * 4, hipMemcpyDeviceToHost));
     return W3_OK;
 }
 
@@ -901,6 +952,119 @@ extern "C" int w3_stationary_table(const uint8_t *buf, size_t n, uint16_t table[
         uint64_t p = (1ull << 17) * ((uint64_t)c1[i] + 1) / ((uint64_t)c0[i] + c1[i] + 2);
         table[i] = (uint16_t)((p >> 1) + (p & 1));
     }
+    return W3_OK;
+}
+
+// ---------------------------------------------------------------------------
+// OrderN(bits, align) parameter sweep, configurations x blocks in one launch (w3_sweep.h; bin/ordern/main.rs:9-80)
+// ---------------------------------------------------------------------------
+extern "C" int w3_sweep_ordern_device(w3_ctx *ctx, const uint8_t *d_in, size_t n, size_t block_size, const uint8_t *bits, const uint8_t *aligns,
+                                      size_t ncfg, uint32_t *block_bits) {
+    int rc = check_args(ctx, n, block_size);
+    if (rc) return rc;
+    const uint32_t nb = (uint32_t)((n + block_size - 1) / block_size);
+    if (nb == 0 || ncfg == 0) return W3_OK;
+    if (!d_in || !bits || !aligns || !block_bits || ncfg > 4096) return W3_E_INVALID;
+    for (size_t c = 0; c < ncfg; c++)   // OrderN::new allocates 1 << bits counters; masks are u32 (ordern.rs:35-43)
+        if (bits[c] < 1 || bits[c] > 32 || aligns[c] > 7 || aligns[c] > bits[c] || (int)bits[c] - (int)aligns[c] > 31) return W3_E_INVALID;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    const uint64_t steps = (uint64_t)block_size * 8;
+    const uint64_t hash_slots = std::max<uint64_t>(1024, next_pow2(2 * steps)), hash_bytes = hash_slots * 8;
+    std::vector<SweepCfg> cfg(ncfg);
+    size_t free_b = 0, total_b = 0;
+    HIPCHK(ctx, hipMemGetInfo(&free_b, &total_b));
+    const uint64_t budget = std::min<uint64_t>((uint64_t)(free_b + ctx->tables.cap) * 3 / 4, 200ull << 30);
+    ENSURE(ctx, ctx->sweep, ncfg * sizeof(SweepCfg) + (size_t)ncfg * nb * 4);
+    SweepCfg *d_cfg = (SweepCfg *)ctx->sweep.p;
+    uint32_t *d_bits = (uint32_t *)((uint8_t *)ctx->sweep.p + ncfg * sizeof(SweepCfg));
+    SweepArgs a;
+    memset(&a, 0, sizeof a);
+    a.in = d_in; a.n = n; a.block_size = (uint32_t)block_size; a.nblocks = nb; a.waves_per_cfg = (nb + 63) / 64; a.ncfg = (uint32_t)ncfg;
+    a.cfg = d_cfg; a.out_bits = d_bits;
+    size_t c0 = 0;
+    while (c0 < ncfg) {   // as many configurations per launch as their tables fit the budget
+        uint64_t used = 0;
+        size_t c1 = c0;
+        for (; c1 < ncfg; c1++) {
+            const uint64_t direct = 4ull << bits[c1];
+            const bool hashed = direct > hash_bytes;
+            const uint64_t stride = hashed ? hash_bytes : std::max<uint64_t>(direct, 16);
+            if (c1 > c0 && used + stride * nb > budget) break;
+            SweepCfg &cf = cfg[c1];
+            cf.bits = bits[c1]; cf.align = aligns[c1]; cf.use_hash = hashed; cf.pad = 0;
+            cf.hash_mask = (uint32_t)(hash_slots - 1); cf.hist_mask = (uint32_t)((1ull << (bits[c1] - aligns[c1])) - 1ull);
+            cf.base = used; cf.stride = stride;
+            used += stride * nb;
+        }
+        if (used > (uint64_t)(free_b + ctx->tables.cap)) { ctx->err = "sweep tables of one configuration do not fit the device"; return W3_E_NOMEM; }
+        ENSURE(ctx, ctx->tables, (size_t)used);
+        HIPCHK(ctx, hipMemsetAsync(ctx->tables.p, 0, (size_t)used, s));
+        HIPCHK(ctx, hipMemcpyAsync(d_cfg + c0, cfg.data() + c0, (c1 - c0) * sizeof(SweepCfg), hipMemcpyHostToDevice, s));
+        a.tables = (uint8_t *)ctx->tables.p; a.first_cfg = (uint32_t)c0;
+        hipLaunchKernelGGL(k_sweep_ordern, dim3((unsigned)((c1 - c0) * a.waves_per_cfg)), dim3(64), 0, s, a);
+        HIPCHK(ctx, hipGetLastError());
+        HIPCHK(ctx, hipStreamSynchronize(s));   // (cfg is host memory reused by the next batch; the tables are re-zeroed)
+        c0 = c1;
+    }
+    HIPCHK(ctx, hipMemcpy(block_bits, d_bits, (size_t)ncfg * nb * 4, hipMemcpyDeviceToHost));
+    return W3_OK;
+}
+
+extern "C" int w3_sweep_ordern(w3_ctx *ctx, const uint8_t *in, size_t n, size_t block_size, const uint8_t *bits, const uint8_t *aligns,
+                               size_t ncfg, uint32_t *block_bits) {
+    int rc = check_args(ctx, n, block_size);
+    if (rc) return rc;
+    if (n == 0 || ncfg == 0) return W3_OK;
+    if (!in) return W3_E_INVALID;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    ENSURE(ctx, ctx->io_in, n);
+    HIPCHK(ctx, hipMemcpy(ctx->io_in.p, in, n, hipMemcpyHostToDevice));
+    return w3_sweep_ordern_device(ctx, (const uint8_t *)ctx->io_in.p, n, block_size, bits, aligns, ncfg, block_bits);
+}
+
+// ---------------------------------------------------------------------------
+// Context statistics export (README.md:9 "output stats from contexts for use by external neural nets"): the Counter table of a
+// Counter-table model after it has seen the whole input as ONE stream — what `stats` of models/ordern.rs:5 holds when the
+// reference's compress() returns.  One serial chain (one lane, as w3_compress_stream).
+// ---------------------------------------------------------------------------
+extern "C" int w3_export_counters(w3_ctx *ctx, const w3_model_spec *spec, const uint8_t *in, size_t n, uint32_t *counters) {
+    if (!ctx || !counters) return W3_E_INVALID;
+    ParsedSpec ps;
+    int rc = parse_spec(spec, ps);
+    if (rc) return rc;
+    if (ps.n_leaves != 1 || ps.n_apm || ps.has_slot || ps.leaf[0].frozen) { ctx->err = "w3_export_counters takes ONE adaptive Counter-table leaf"; return W3_E_UNSUPPORTED; }
+    const w3_node &nd = ps.leaf[0];
+    if (nd.bits > 28) { ctx->err = "tables above 2^28 counters are not exported"; return W3_E_UNSUPPORTED; }
+    if (n > (1u << 28)) { ctx->err = "single-stream export limited to 2^28 bytes"; return W3_E_UNSUPPORTED; }
+    const size_t entries = (size_t)1 << nd.bits;
+    if (n == 0) { memset(counters, 0, entries * 4); return W3_OK; }
+    if (!in) return W3_E_INVALID;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    if ((rc = stage_huff(ctx, s, ps))) return rc;
+    GenericArgs ga;
+    memset(&ga, 0, sizeof ga);
+    (void)layout_generic(ps, n, ga);
+    ga.leaf[0].use_hash = 0; ga.leaf[0].tbl_off = 0;            // direct-indexed, like the reference's Vec<Counter>
+    if ((rc = prepare_achash_luts(ctx, s, ga))) return rc;
+    const uint32_t cap = default_stripe_cap(n);
+    ENSURE(ctx, ctx->tables, entries * 4);
+    ENSURE(ctx, ctx->io_in, n);
+    ENSURE(ctx, ctx->stripes, cap);
+    ENSURE(ctx, ctx->lens, 4);
+    ENSURE(ctx, ctx->flag, 16 * W3_MAX_PARTS);
+    HIPCHK(ctx, hipMemcpyAsync(ctx->io_in.p, in, n, hipMemcpyHostToDevice, s));
+    HIPCHK(ctx, hipMemsetAsync(ctx->tables.p, 0, entries * 4, s));
+    ga.n = n; ga.block_size = (uint32_t)n; ga.first_block = 0; ga.n_lanes = 1;
+    ga.huff = ctx->tp.huff; ga.n_huff = (int)ps.n_huff;
+    ga.tables = (uint8_t *)ctx->tables.p; ga.lane_stride = entries * 4;
+    ga.in = (const uint8_t *)ctx->io_in.p; ga.stripes = (uint8_t *)ctx->stripes.p; ga.stripe_cap = cap;
+    ga.out_len = (uint32_t *)ctx->lens.p; ga.overflow = (uint32_t *)ctx->flag.p; ga.out_bits = nullptr;
+    hipLaunchKernelGGL((k_generic_nl<false, 1>), dim3(1), dim3(64), 0, s, ga);
+    HIPCHK(ctx, hipGetLastError());
+    HIPCHK(ctx, hipMemcpyAsync(counters, ctx->tables.p, entries * 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(ctx, hipStreamSynchronize(s));
     return W3_OK;
 }
 

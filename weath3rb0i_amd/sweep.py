@@ -2,10 +2,11 @@
 
 The reference runs `OrderN::new(ctx_bits, alignment_bits)` over one file for ctx_bits 8..=30 x alignment_bits 0..=4,
 three times each, prints `[ordern] [ctx: B, align: A] csize: N (ratio: r), ctime: t (t/bit per bit)` for the fastest run
-and tracks the best parameters per ctx_bits and overall (`best`/`params`, levels = 2).  Here every configuration is one
-`w3_encode_blocks_device` call on the block container: csize = the sum of the block streams, each of
-which is the reference's stream for that block alone — so the figures are those of the reference run per block, not of
-its single whole-file stream.  Same line format, same tie rule (a later configuration replaces the best on equality,
+and tracks the best parameters per ctx_bits and overall (`best`/`params`, levels = 2).  Here ALL configurations run in one
+device launch (`w3_sweep_ordern`: lanes = configurations x blocks, counting sink ACStats as in the reference's `compress`,
+`main.rs:66-80`) on the block container: csize = (sum of the blocks' bit counts) / 8, each block
+coded alone with a fresh model — so the figures are those of the reference run per block, not of its single
+whole-file stream; ctime is the launch's time divided by the number of configurations.  Same line format, same tie rule (a later configuration replaces the best on equality,
 `main.rs:21-26`: `if res > best[i] { continue }`).
 """
 import sys
@@ -38,13 +39,29 @@ def sweep_ordern(ctx, data, block_size=65536, ctx_bits=range(8, 31), alignment_b
     best = [len(data)] * levels
     params = [(0, 0)] * levels
     table = {}
+    pre = {}
+    configs = [(b, a) for b in ctx_bits for a in alignment_bits if a <= b]
+    if hasattr(ctx, "sweep_ordern") and configs:   # every configuration x block in ONE launch, fastest of `repeats`
+        dt_best = None
+        for _ in range(repeats):
+            t0 = time.perf_counter()
+            bits = ctx.sweep_ordern(data, block_size, configs)
+            dt = time.perf_counter() - t0
+            dt_best = dt if dt_best is None else min(dt_best, dt)
+        for c, row in zip(configs, bits):
+            pre[c] = (int(row.astype("uint64").sum()) // 8, dt_best / len(configs))   # ACStats::result(): bits / 8 (helpers.rs:70-73)
     for b in ctx_bits:
         best[1] = len(data)
         params[1] = (0, 0)
         for a in alignment_bits:
             if a > b:          # OrderN needs alignment_bits <= bits_in_context (the crate would underflow `bits - align`)
                 continue
-            res, _ = exec_one(ctx, data, block_size, b, a, repeats, out)
+            if (b, a) in pre:
+                res, dt = pre[(b, a)]
+                out("[ordern] [ctx: %2d, align: %d] csize: %d (ratio: %.3f), ctime: %.3fms (%.3fns per bit)"
+                    % (b, a, res, res / max(1, len(data)), dt * 1e3, dt * 1e9 / max(1, len(data) * 8)))
+            else:
+                res, _ = exec_one(ctx, data, block_size, b, a, repeats, out)
             table[(b, a)] = res
             for i in range(levels):
                 if res > best[i]:
