@@ -175,6 +175,18 @@ int w3_decode_blocks_device(w3_ctx *ctx, const w3_model_spec *spec,
                             const uint8_t *d_in, size_t in_len, const uint32_t *d_block_lens, size_t nblocks,
                             size_t block_size, uint64_t orig_len, uint8_t *d_out, void *stream);
 
+/* ---- sharding over several GPUs from ONE process (C, C++ or Rust hosts) ---------------------------
+ * Blocks are independent (fresh model + coder each), so they shard with no data-path collective: context r codes the
+ * contiguous block range w3_shard_range gives it (block b -> rank floor(b * world / nblocks): rank order = stream
+ * order) on its own GPU and host thread; the streams land in `out` at the exclusive scan of the ranks' totals, the
+ * length table is the concatenation.  Output identical to w3_encode_blocks on one context.  ctxs[] may name the same
+ * device more than once (that is how the path is tested on a 1-GPU box).  Multi-PROCESS jobs (one rank per GPU,
+ * bench.py) gather over RCCL instead: weath3rb0i_amd/shard.py.                                                       */
+int w3_shard_range(size_t nblocks, int world, int rank, size_t *first_block, size_t *end_block);
+int w3_encode_blocks_sharded(w3_ctx *const *ctxs, int n_ctx, const w3_model_spec *spec,
+                             const uint8_t *in, size_t n, size_t block_size,
+                             uint8_t *out, size_t out_cap, size_t *out_len, uint32_t *block_lens);
+
 /* ---- ACStats, the counting sink (helpers.rs:60-90) -------------------------------
  * Every figure the reference publishes is `csize = bits / 8` from this sink (bin/ordern/main.rs:66-80): write_bit counts
  * 1 + the pending parity bits it resolves, flush adds nothing (:87-89).  block_bits[b] = that count for block b coded

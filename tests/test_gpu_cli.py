@@ -61,6 +61,18 @@ def test_cli_test_action_block_container(cli, tmp_path, model):
     assert lens == wl.tolist() and body == out.tobytes()
 
 
+def test_cli_sharded_compress_gives_the_same_container(cli, tmp_path):
+    """W3_SHARDS=3: the C++ host cuts the blocks over three contexts (w3_encode_blocks_sharded, one process): same file bytes."""
+    data = markov_text(9 * 65536 + 1234, seed=41)
+    f = tmp_path / "corpus.txt"
+    f.write_bytes(data)
+    assert run(cli, tmp_path, "c", str(f), W3_MODEL="order012apm").returncode == 0
+    one = (tmp_path / "corpus.bin").read_bytes()
+    r = run(cli, tmp_path, "t", str(f), W3_MODEL="order012apm", W3_SHARDS="3")
+    assert r.returncode == 0, r.stderr
+    assert (tmp_path / "corpus.bin").read_bytes() == one and (tmp_path / "corpus.orig").read_bytes() == data
+
+
 def test_cli_reference_container_and_directory(cli, tmp_path, oracle):
     d = tmp_path / "dir"
     d.mkdir()

@@ -145,3 +145,15 @@ def test_huff_spec_validation(lib):
     assert s2.n_huff == 2 and [s2.nodes[0].reserved, s2.nodes[1].reserved] == [0, 1]
     s.n_huff = 0                                           # a HUFF leaf without its tables is malformed
     assert lib.w3_spec_validate(s) == L.W3_E_INVALID
+
+
+def test_shard_range_matches_the_python_sharding(lib):
+    """w3_shard_range (C hosts) and weath3rb0i_amd.shard.block_range (torch.distributed hosts) cut the same ranges."""
+    from weath3rb0i_amd import shard
+    for world in (1, 2, 3, 8):
+        for nb in (0, 1, 7, 8, 9, 1526, 15259, 2**33 + 5):
+            for rank in range(world):
+                lo, hi = C.c_size_t(), C.c_size_t()
+                assert lib.w3_shard_range(nb, world, rank, C.byref(lo), C.byref(hi)) == 0
+                assert (lo.value, hi.value) == shard.block_range(rank, world, nb)
+    assert lib.w3_shard_range(10, 0, 0, C.byref(C.c_size_t()), C.byref(C.c_size_t())) == L.W3_E_INVALID

@@ -103,9 +103,28 @@ static int compress(w3_ctx *ctx, const std::string &in, const std::string &out) 
     std::vector<uint8_t> body(2 * data.size() + 64 * nb + 64);
     std::vector<uint32_t> lens(nb ? nb : 1);
     size_t blen = 0;
-    int rc = w3_encode_blocks(ctx, &spec, data.data(), data.size(), kBlock, body.data(), body.size(), &blen, lens.data());
-    if (rc == W3_E_NOSPACE) { body.resize(blen); rc = w3_encode_blocks(ctx, &spec, data.data(), data.size(), kBlock, body.data(), body.size(), &blen, lens.data()); }
-    if (rc) return die(ctx, rc, "w3_encode_blocks");
+    int rc;
+    // W3_SHARDS=k: the blocks as k contiguous ranges on k contexts, one per GPU (round robin over the devices present) —
+    // w3_encode_blocks_sharded, the single-process form of BASELINE configs[3]; same container bytes as one context
+    const char *sh = getenv("W3_SHARDS");
+    const int k = sh ? atoi(sh) : 1;
+    if (k > 1 && k <= 64) {
+        int ndev = 1;
+        const char *nd = getenv("W3_NDEV");
+        if (nd && atoi(nd) > 0) ndev = atoi(nd);
+        std::vector<w3_ctx *> cs((size_t)k, nullptr);
+        cs[0] = ctx;
+        for (int r = 1; r < k; r++)
+            if (w3_ctx_create(r % ndev, &cs[r]) != W3_OK) { fprintf(stderr, "w3_ctx_create(device %d) failed\n", r % ndev); return 1; }
+        rc = w3_encode_blocks_sharded(cs.data(), k, &spec, data.data(), data.size(), kBlock, body.data(), body.size(), &blen, lens.data());
+        if (rc == W3_E_NOSPACE) { body.resize(blen); rc = w3_encode_blocks_sharded(cs.data(), k, &spec, data.data(), data.size(), kBlock, body.data(), body.size(), &blen, lens.data()); }
+        for (int r = 1; r < k; r++) w3_ctx_destroy(cs[r]);
+        if (rc) return die(ctx, rc, "w3_encode_blocks_sharded");
+    } else {
+        rc = w3_encode_blocks(ctx, &spec, data.data(), data.size(), kBlock, body.data(), body.size(), &blen, lens.data());
+        if (rc == W3_E_NOSPACE) { body.resize(blen); rc = w3_encode_blocks(ctx, &spec, data.data(), data.size(), kBlock, body.data(), body.size(), &blen, lens.data()); }
+        if (rc) return die(ctx, rc, "w3_encode_blocks");
+    }
     std::vector<uint8_t> file = {'w', '3', 'b', 'k', 1};
     put_be(file, data.size(), 8); put_be(file, kBlock, 4); put_be(file, nb, 4);
     for (size_t b = 0; b < nb; b++) put_be(file, lens[b], 4);

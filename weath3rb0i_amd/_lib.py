@@ -44,7 +44,7 @@ EXPORTS = [
     "w3_ctx_set_option", "w3_max_compressed_size", "w3_encode_blocks", "w3_decode_blocks", "w3_encode_blocks_device",
     "w3_decode_blocks_device", "w3_compress_stream", "w3_decompress_stream", "w3_predict_blocks", "w3_stationary_table",
     "w3_get_timing", "w3_selftest_counter_p", "w3_debug_get_stamps", "w3_state_table", "w3_stretch_squash", "w3_huff_tables",
-    "w3_encode_stats", "w3_encode_stats_device", "w3_sweep_ordern", "w3_sweep_ordern_device", "w3_export_counters",
+    "w3_shard_range", "w3_encode_blocks_sharded", "w3_encode_stats", "w3_encode_stats_device", "w3_sweep_ordern", "w3_sweep_ordern_device", "w3_export_counters",
 ]
 
 _lib = None
@@ -93,6 +93,8 @@ def load():
     lib.w3_state_table.argtypes = [vp]
     lib.w3_stretch_squash.argtypes = [vp, vp]
     lib.w3_huff_tables.argtypes = [vp, sz, C.c_uint8, C.c_uint8, C.POINTER(HuffTable)]
+    lib.w3_shard_range.argtypes = [sz, C.c_int, C.c_int, C.POINTER(sz), C.POINTER(sz)]
+    lib.w3_encode_blocks_sharded.argtypes = [C.POINTER(vp), C.c_int, C.POINTER(ModelSpec), vp, sz, sz, vp, sz, C.POINTER(sz), vp]
     lib.w3_encode_stats.argtypes = [vp, C.POINTER(ModelSpec), vp, sz, sz, vp]
     lib.w3_encode_stats_device.argtypes = [vp, C.POINTER(ModelSpec), vp, sz, sz, vp, vp]
     lib.w3_sweep_ordern.argtypes = [vp, vp, sz, sz, vp, vp, sz, vp]

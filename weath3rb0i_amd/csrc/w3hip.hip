@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "w3_spec.h"
@@ -881,6 +882,59 @@ extern "C" int w3_decode_blocks(w3_ctx *ctx, const w3_model_spec *spec, const ui
                                  (uint8_t *)ctx->io_out.p, ctx->stream);
     if (rc) return rc;
     HIPCHK(ctx, hipMemcpy(out, ctx->io_out.p, (size_t)orig_len, hipMemcpyDeviceToHost));
+    return W3_OK;
+}
+
+// ---------------------------------------------------------------------------
+// one process, several GPUs: contiguous block ranges, one host thread and context per device
+// ---------------------------------------------------------------------------
+extern "C" int w3_shard_range(size_t nblocks, int world, int rank, size_t *first_block, size_t *end_block) {
+    if (world <= 0 || rank < 0 || rank >= world || !first_block || !end_block) return W3_E_INVALID;
+    *first_block = (size_t)((unsigned __int128)nblocks * (unsigned)rank / (unsigned)world);
+    *end_block = (size_t)((unsigned __int128)nblocks * (unsigned)(rank + 1) / (unsigned)world);
+    return W3_OK;
+}
+
+extern "C" int w3_encode_blocks_sharded(w3_ctx *const *ctxs, int n_ctx, const w3_model_spec *spec, const uint8_t *in, size_t n, size_t block_size,
+                                        uint8_t *out, size_t out_cap, size_t *out_len, uint32_t *block_lens) {
+    if (!ctxs || n_ctx <= 0 || !out_len) return W3_E_INVALID;
+    for (int r = 0; r < n_ctx; r++) if (!ctxs[r]) return W3_E_INVALID;
+    *out_len = 0;
+    int rc = check_args(ctxs[0], n, block_size);
+    if (rc) return rc;
+    const size_t nb = (n + block_size - 1) / block_size;
+    if (nb == 0) return w3_spec_validate(spec);
+    if (!in || !block_lens) return W3_E_INVALID;
+    struct Shard { size_t lo = 0, hi = 0, b0 = 0; std::vector<uint8_t> buf; size_t len = 0; int rc = W3_OK; };
+    std::vector<Shard> sh(n_ctx);
+    std::vector<std::thread> th;
+    for (int r = 0; r < n_ctx; r++) {
+        size_t b0, b1;
+        (void)w3_shard_range(nb, n_ctx, r, &b0, &b1);
+        sh[r].b0 = b0; sh[r].lo = std::min(b0 * block_size, n); sh[r].hi = std::min(b1 * block_size, n);
+        if (sh[r].hi == sh[r].lo) continue;
+        th.emplace_back([&, r]() {
+            Shard &x = sh[r];
+            const size_t m = x.hi - x.lo;
+            size_t cap = 2 * m + 64 * ((m + block_size - 1) / block_size) + 64;   // realistic bound; grown to the reported need on W3_E_NOSPACE
+            for (int attempt = 0; attempt < 2; attempt++) {
+                x.buf.resize(cap);
+                x.rc = w3_encode_blocks(ctxs[r], spec, in + x.lo, m, block_size, x.buf.data(), cap, &x.len, block_lens + x.b0);
+                if (x.rc != W3_E_NOSPACE || x.len <= cap) break;
+                cap = x.len;
+            }
+        });
+    }
+    for (auto &t : th) t.join();
+    size_t total = 0;
+    for (int r = 0; r < n_ctx; r++) {
+        if (sh[r].rc) { ctxs[0]->err = "shard " + std::to_string(r) + ": " + (ctxs[r]->err.empty() ? w3_strerror(sh[r].rc) : ctxs[r]->err); return sh[r].rc; }
+        total += sh[r].len;
+    }
+    *out_len = total;
+    if (total > out_cap || !out) return W3_E_NOSPACE;
+    size_t o = 0;
+    for (int r = 0; r < n_ctx; r++) { if (sh[r].len) memcpy(out + o, sh[r].buf.data(), sh[r].len); o += sh[r].len; }
     return W3_OK;
 }
 
