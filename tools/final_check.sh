@@ -1,9 +1,18 @@
 #!/bin/bash
-# Round-end validation on the GPU box: GPU test suite, smoke(), bench lines of every model (gpurun_out/final/).
-mkdir -p gpurun_out/final
-timeout -k 10 900 python -m pytest tests -m gpu -x -q > gpurun_out/final/pytest_gpu.log 2>&1; echo "pytest rc=$?"; tail -2 gpurun_out/final/pytest_gpu.log
-timeout -k 10 200 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > gpurun_out/final/smoke.log 2>&1; tail -1 gpurun_out/final/smoke.log
-for m in order012apm order012 default order0 fullcm; do
-  timeout -k 10 300 python bench.py --model $m > gpurun_out/final/bench_$m.json.log 2>&1
-  tail -1 gpurun_out/final/bench_$m.json.log | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['config']['model'][:40], d['value'], d['ms_per_step'], d['roofline']['kernel'][:12], d['roofline']['frac'], d['kernel_ms_per_step'], d.get('cpu_baseline',{}).get('value'), d.get('cpu_baseline',{}).get('bit_exact_vs_gpu'))"
+# end-of-round evidence (run through gpurun): bench lines of every model (with the CPU legs), rocprofv3 stats + PMC passes of the
+# default model and of order012.  Results under gpurun_out/final_<tag>/ ; copy into profiles/<round>/.
+TAG=${1:-r2}
+DST=$PWD/gpurun_out/final_$TAG
+mkdir -p "$DST"
+export TMPDIR=/tmp
+for m in order012apm order012 default order0; do
+  timeout -k 10 300 python3 bench.py --model $m --steps 10 --warmup 2 > "$DST/bench_$m.json" 2> "$DST/bench_$m.err" || echo "bench $m failed"
+  echo "bench $m done"
 done
+timeout -k 10 300 python3 bench.py --model fullcm --steps 3 --warmup 1 --no-ref-model > "$DST/bench_fullcm.json" 2> "$DST/bench_fullcm.err" || echo "bench fullcm failed"
+timeout -k 10 300 python3 bench.py --data mixed --block-size 262144 --size 211938580 --steps 10 --warmup 2 > "$DST/bench_mixed_256k.json" 2> "$DST/bench_mixed.err" || echo "bench mixed failed"
+timeout -k 10 300 python3 bench.py --scaling strong --force-exchange --steps 5 --no-cpu-baseline --no-ref-model > "$DST/bench_strong_1gpu_exchange_rehearsal.json" 2> "$DST/bench_strong.err" || echo "bench strong failed"
+timeout -k 10 600 bash tools/profile_round.sh $TAG order012apm order012 2>&1 | tail -3
+cp -r gpurun_out/round_$TAG/* "$DST/" 2>/dev/null
+timeout -k 10 200 python3 tools/sweep_bench.py > "$DST/sweep_115_configs_20MB.txt" 2>&1
+ls "$DST"

@@ -214,11 +214,15 @@ __global__ void __launch_bounds__(64) k_coder_fast(CoderArgs a) {
 #define W3_X3_LAZY 8            // s_sleep units between polls of the mix / output waves of k_coder_x3
 #endif
 
+// Progress words of the wave pipelines: release on the producer's store (everything it wrote to the ring is visible first),
+// acquire on the consumer's poll (its ring reads come after).  On gfx950 both cost one s_waitcnt lgkmcnt on LDS — the LDS
+// executes a wave's operations in order anyway — but the ordering no longer rests on that plus compiler barriers
+// (ADVICE r1).  The assembly loops of k_coder_x4 order their own LDS operations explicitly (in-order DS + s_waitcnt).
 __device__ __forceinline__ uint32_t lds_load_u32(const volatile uint32_t *p) {
-    return __hip_atomic_load(const_cast<const uint32_t *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    return __hip_atomic_load(const_cast<const uint32_t *>(p), __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 __device__ __forceinline__ void lds_store_u32(volatile uint32_t *p, uint32_t v) {
-    __hip_atomic_store(const_cast<uint32_t *>(p), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    __hip_atomic_store(const_cast<uint32_t *>(p), v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
 __global__ void __launch_bounds__(128) k_coder_x2(CoderArgs a) {
