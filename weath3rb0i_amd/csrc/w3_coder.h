@@ -380,18 +380,6 @@ namespace w3 {
 //   O-wave: accumulator, flushes, final ACWriter::flush (see k_coder_x2).
 // Two LDS rings of 16 input bytes each (M->X operands, X->O tokens): 128 KiB.
 // ---------------------------------------------------------------------------
-typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
-typedef short i16x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ u16x2 as_u16x2(uint32_t v) { return __builtin_bit_cast(u16x2, v); }
-__device__ __forceinline__ i16x2 as_i16x2(u16x2 v) { return __builtin_bit_cast(i16x2, v); }
-__device__ __forceinline__ uint32_t as_u32(u16x2 v) { return __builtin_bit_cast(uint32_t, v); }
-__device__ __forceinline__ uint32_t as_u32(i16x2 v) { return __builtin_bit_cast(uint32_t, v); }
-// |p - 32768| of two u16 probabilities at once (mixers/opinion_mixer2.rs:5-10)
-__device__ __forceinline__ u16x2 pk_opinion_dist(u16x2 p) {
-    const u16x2 half = {32768, 32768};
-    return __builtin_elementwise_max(p, half) - __builtin_elementwise_min(p, half);
-}
-
 struct Coder3Args {
     const uint8_t *in;
     uint64_t n;

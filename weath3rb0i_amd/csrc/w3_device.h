@@ -45,6 +45,19 @@ __device__ __forceinline__ uint32_t counter_update_packed(uint32_t c, uint32_t b
 // tree of any shape returns the LEFTMOST leaf (in-order) of maximal distance,
 // because mix() keeps p1 on ties; callers scan leaves left to right with '>'.
 __device__ __forceinline__ uint32_t opinion_dist(uint32_t p) { return p >= 32768u ? p - 32768u : 32768u - p; }
+// the same for two u16 probabilities per dword (packed 16-bit VALU)
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+typedef short i16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ u16x2 as_u16x2(uint32_t v) { return __builtin_bit_cast(u16x2, v); }
+__device__ __forceinline__ i16x2 as_i16x2(u16x2 v) { return __builtin_bit_cast(i16x2, v); }
+__device__ __forceinline__ uint32_t as_u32(u16x2 v) { return __builtin_bit_cast(uint32_t, v); }
+__device__ __forceinline__ uint32_t as_u32(i16x2 v) { return __builtin_bit_cast(uint32_t, v); }
+// |p - 32768| of two u16 probabilities at once (mixers/opinion_mixer2.rs:5-10)
+__device__ __forceinline__ u16x2 pk_opinion_dist(u16x2 p) {
+    const u16x2 half = {32768, 32768};
+    return __builtin_elementwise_max(p, half) - __builtin_elementwise_min(p, half);
+}
+
 
 // ---------------------------------------------------------------------------
 // Bit sink of one lane: ACWriter (entropy_coding/io.rs:52-101) with the

@@ -555,27 +555,32 @@ static inline int twophase_encode(TwoPhaseWs &ws, hipStream_t s, const ParsedSpe
     const bool x3 = (ws.coder_mode == 0 || ws.coder_mode == 4) && (n_live <= 4 || ps.n_apm > 0);   // more leaves: merge with k_mix first, then k_coder_x2
     int rc = twophase_predict(ws, s, ps, d_in, n, block_size, nb, !x3 && ps.n_apm == 0, nullptr, ev, tm, err);
     if (rc) return rc;
-    // flag word 2: mismatching waves.  The re-prediction only reads the leaves' streams, so it runs on its own stream beside the
-    // APM and coder kernels (2.8 ms of small launches otherwise) — unless an APM stage is about to rewrite the single leaf's stream in place.
+    // flag word 2: mismatching waves.  The re-prediction only reads the leaves' streams, so it runs on its own stream (2.8 ms of
+    // small launches otherwise) beside the CODER kernel, which leaves the chip's memory system and most of its issue slots
+    // idle (beside k_apm0 its workgroups displaced some of that kernel's for ~1.4 ms per step, measured) — unless an APM stage
+    // is about to rewrite the single leaf's stream in place: then it runs first, on the main stream.
     bool verify_forked = false;
-    if (ws.verify && ws.used_lds_atomics) {
-        const bool in_place = n_live == 1 && ps.n_apm > 0;
-        if (!in_place && !ws.vstream) {
-            bool ok = hipStreamCreateWithFlags(&ws.vstream, hipStreamNonBlocking) == hipSuccess && hipEventCreateWithFlags(&ws.ev_v0, hipEventDisableTiming) == hipSuccess &&
-                      hipEventCreateWithFlags(&ws.ev_v1, hipEventDisableTiming) == hipSuccess;
-            if (!ok) { (void)hipGetLastError(); err = "verification stream creation failed"; return W3_E_HIP; }
-        }
-        if (!in_place) {
-            (void)hipEventRecord(ws.ev_v0, s); (void)hipStreamWaitEvent(ws.vstream, ws.ev_v0, 0);
-            rc = twophase_verify(ws, ws.vstream, ps, d_in, n, block_size, nb, d_flag + 2, err);
-            (void)hipEventRecord(ws.ev_v1, ws.vstream);
-            verify_forked = true;
-        } else rc = twophase_verify(ws, s, ps, d_in, n, block_size, nb, d_flag + 2, err);
-        if (rc && !verify_forked) return rc;
+    const bool verify_on = ws.verify && ws.used_lds_atomics;
+    const bool verify_in_place = verify_on && n_live == 1 && ps.n_apm > 0;
+    if (verify_in_place && (rc = twophase_verify(ws, s, ps, d_in, n, block_size, nb, d_flag + 2, err))) return rc;
+    if (verify_on && !verify_in_place && !ws.vstream) {
+        bool ok = hipStreamCreateWithFlags(&ws.vstream, hipStreamNonBlocking) == hipSuccess && hipEventCreateWithFlags(&ws.ev_v0, hipEventDisableTiming) == hipSuccess &&
+                  hipEventCreateWithFlags(&ws.ev_v1, hipEventDisableTiming) == hipSuccess;
+        if (!ok) { (void)hipGetLastError(); err = "verification stream creation failed"; return W3_E_HIP; }
     }
     // join on every way out of this function: the caller reads the mismatch word (and may free buffers) next
-    struct Join { hipStream_t st; hipEvent_t ev; bool on; ~Join() { if (on) (void)hipStreamWaitEvent(st, ev, 0); } } join{s, ws.ev_v1, verify_forked};
-    if (rc) return rc;
+    struct Join { hipStream_t st; hipEvent_t ev; const bool &on; ~Join() { if (on) (void)hipStreamWaitEvent(st, ev, 0); } } join{s, ws.ev_v1, verify_forked};
+    const auto leaf_streams = ws.mix;   // (the APM stages below replace ws.mix by their one output stream)
+    auto fork_verify = [&](hipStream_t from) -> int {
+        (void)hipEventRecord(ws.ev_v0, from); (void)hipStreamWaitEvent(ws.vstream, ws.ev_v0, 0);
+        const auto after_apm = ws.mix;
+        ws.mix = leaf_streams;
+        const int vr = twophase_verify(ws, ws.vstream, ps, d_in, n, block_size, nb, d_flag + 2, err);
+        ws.mix = after_apm;
+        (void)hipEventRecord(ws.ev_v1, ws.vstream);
+        verify_forked = true;
+        return vr;
+    };
     if (ws.ev_pred_done) (void)hipEventRecord(ws.ev_pred_done, s);   // the next block range may start its predict kernels
     hipStream_t s_lo = s;
     if (ws.use_hi) {
@@ -590,6 +595,7 @@ static inline int twophase_encode(TwoPhaseWs &ws, hipStream_t s, const ParsedSpe
         s = ws.hi;
     }
     if ((rc = twophase_apm(ws, s, ps, d_in, n, block_size, nb, ev, tm, err))) return rc;   // leaves ws.P as the one source stream
+    if (verify_on && !verify_in_place && (rc = fork_verify(s))) return rc;
     if (w3_tune_env("W3_DEBUG_NOSTORE")) { err = "W3_DEBUG_NOSTORE: predict-only timing experiment"; return W3_E_UNSUPPORTED; }
     if ((rc = tp_ensure(ws.redo, ws.redo_cap, (size_t)nb * 4, err))) return rc;
     const uint32_t limit = std::min<uint32_t>(ws.acc_limit, 46u);
