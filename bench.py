@@ -240,7 +240,7 @@ def main():
     def timed(mdl, steps):
         ctx.set_timing(True)
         kern = {"predict_ms": 0.0, "achash_ms": 0.0, "slot_ms": 0.0, "apm_ms": 0.0, "coder_ms": 0.0, "pack_ms": 0.0, "generic_ms": 0.0}
-        extra = {"coder_bytes": 0, "launches": 0, "parts": 1, "path": 0}
+        extra = {"coder_bytes": 0, "predict_bytes": 0, "launches": 0, "parts": 1, "path": 0}
         sync()
         t0 = time.perf_counter()
         for _ in range(steps):
@@ -249,6 +249,7 @@ def main():
             for k in kern:
                 kern[k] += tm[k]
             extra["coder_bytes"] += tm["coder_bytes"]
+            extra["predict_bytes"] += tm["predict_bytes"]
             extra["launches"] += max(1, tm["n_coder_launches"])
             extra["path"] = tm["path"]
             extra["parts"] = max(1, tm["n_parts"])
@@ -340,6 +341,12 @@ def main():
                          "avg_launch_ms": round(dom_ms, 4), "algorithmic_bytes_per_launch": int(dom_bytes),
                          "launches_per_step": parts if path == 2 else 1},
             "kernel_ms_per_step": {k: round(v / args.steps, 3) for k, v in kern_ms.items()},
+            # the predict phase is several kernels on two streams (their launch durations overlap); as a whole: algorithmic bytes
+            # (per leaf input + 16-byte stream, plus 8 B written + 8 B read per record pass of a wide leaf) over the phase's time
+            "predict_phase": ({"algorithmic_bytes_per_step": int(ex["predict_bytes"] / args.steps),
+                               "achieved_GBps": round(ex["predict_bytes"] / max(kern_ms["predict_ms"], 1e-9) / 1e6, 1),
+                               "frac_of_hbm_peak": round(ex["predict_bytes"] / max(kern_ms["predict_ms"], 1e-9) / 1e6 / HBM_PEAK_GBPS, 4)}
+                              if path == 2 and kern_ms["predict_ms"] > 0 else None),
             # the coder is ONE dependent chain of 8 x block_size bit-steps per lane: its time does not shrink with the block count,
             # so it is the floor of a strong-scaled run (predict / APM / pack scale with the bytes per GPU)
             "floors": {"coder_floor_ms": round(coder_ms, 3) if path == 2 else None, "bit_steps_per_lane": steps_per_lane,

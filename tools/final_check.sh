@@ -15,4 +15,5 @@ timeout -k 10 300 python3 bench.py --scaling strong --force-exchange --steps 5 -
 timeout -k 10 600 bash tools/profile_round.sh $TAG order012apm order012 2>&1 | tail -3
 cp -r gpurun_out/round_$TAG/* "$DST/" 2>/dev/null
 timeout -k 10 200 python3 tools/sweep_bench.py > "$DST/sweep_115_configs_20MB.txt" 2>&1
+timeout -k 10 300 python3 tools/host_api_rate.py 2>&1 | grep -v amdgpu.ids > "$DST/host_api_rate.txt"
 ls "$DST"

@@ -59,7 +59,7 @@ struct TwoPhaseWs {
     bool use_hi = false;
     hipStream_t hi = nullptr;
     hipEvent_t ev_hi_start = nullptr, ev_hi_done = nullptr;
-    hipEvent_t ev_fork = nullptr, ev_join[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev_fork = nullptr, ev_join[4] = {nullptr, nullptr, nullptr, nullptr}, ev_small = nullptr;
     void *achash_lut = nullptr;         // k_achash_lut: [65536][8] coder states (8 MiB)
     size_t achash_lut_cap = 0;
     void *dummy = nullptr;              // 256-byte sink for predicated-off stores (w3_apm.h)
@@ -96,6 +96,8 @@ struct TwoPhaseWs {
         if (side) (void)hipStreamDestroy(side);
         if (ev_fork) (void)hipEventDestroy(ev_fork);
         for (int w = 0; w < 4; w++) { if (ev_join[w]) (void)hipEventDestroy(ev_join[w]); ev_join[w] = nullptr; }
+        if (ev_small) (void)hipEventDestroy(ev_small);
+        ev_small = nullptr;
         side = nullptr; ev_fork = nullptr;
         if (hi) (void)hipStreamDestroy(hi);
         if (ev_hi_start) (void)hipEventDestroy(ev_hi_start);
@@ -237,6 +239,7 @@ static inline int twophase_predict(TwoPhaseWs &ws, hipStream_t s, const ParsedSp
         if (!ws.side) {
             bool ok = hipStreamCreateWithFlags(&ws.side, hipStreamNonBlocking) == hipSuccess && hipEventCreateWithFlags(&ws.ev_fork, hipEventDisableTiming) == hipSuccess;
             for (int w = 0; w < 4 && ok; w++) ok = hipEventCreateWithFlags(&ws.ev_join[w], hipEventDisableTiming) == hipSuccess;
+            ok = ok && hipEventCreateWithFlags(&ws.ev_small, hipEventDisableTiming) == hipSuccess;
             if (!ok) { (void)hipGetLastError(); err = "side stream creation failed"; return W3_E_HIP; }
         }
     }
@@ -259,6 +262,8 @@ static inline int twophase_predict(TwoPhaseWs &ws, hipStream_t s, const ParsedSp
     ws.wide1_slot = -1;
     struct Deferred { w3::PredictArgs pa; int cls; uint32_t grid_rank; } deferred[4];
     int n_def = 0;
+    w3::PredictArgs small_def[8];   // time-ordered table leaves held back until the partition passes are queued
+    int n_small_def = 0;
     uint64_t bytes = 0;
     w3::MixArgs &ma = ws.mix;
     memset(&ma, 0, sizeof ma);
@@ -320,7 +325,9 @@ static inline int twophase_predict(TwoPhaseWs &ws, hipStream_t s, const ParsedSp
             launch_small<true>(nd.bits - 3, dim3(grid_small), s, pa);
             bytes += n * 17;
         } else if (c == LEAF_SMALL) {
-            launch_small<false>(nd.bits - 3, dim3(grid_small), s, pa);
+            // beside a wide leaf's rank kernel (bound by its scattered stores) instead of beside the partition passes: see below
+            if (forked && n_small_def < 8) small_def[n_small_def++] = pa;
+            else launch_small<false>(nd.bits - 3, dim3(grid_small), s, pa);
         } else {
             const int w = n_def;
             pa.perm = (uint32_t *)ws.perm_w[w];
@@ -358,6 +365,16 @@ static inline int twophase_predict(TwoPhaseWs &ws, hipStream_t s, const ParsedSp
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) { err = std::string("predict launch: ") + hipGetErrorString(e); return W3_E_HIP; }
     }
+    // The time-ordered leaves (VALU-bound, coalesced stores) go to the side stream BEHIND the partition passes, so they run
+    // beside the LAST rank kernel, which leaves VALU and most of the LDS free (2048 waves of 12 KiB); beside the first
+    // partition pass — where they used to start — they only delayed it: k_partition8<1> took 14.4 ms instead of 7.2
+    // (timeline, profiles/r2_final/timeline_before_reorder.txt) because k_predict_small's 5120 waves filled the CUs first.
+    if (n_small_def) {
+        for (int k = 0; k < n_small_def; k++) launch_small<false>(small_def[k].hbits, dim3(grid_small), sp, small_def[k]);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) { err = std::string("predict launch: ") + hipGetErrorString(e); return W3_E_HIP; }
+        (void)hipEventRecord(ws.ev_small, ws.side);
+    }
     // join, then rank inside the sorted groups (main stream: these kernels want the Infinity Cache to themselves)
     // (measured, no gain: the later leaves' rank kernels on the side stream beside the first one — 35 + 28 ms together against
     // 17.7 + 15.8 ms one after the other: they saturate the same scattered-store path — and the time-ordered leaves last)
@@ -368,6 +385,7 @@ static inline int twophase_predict(TwoPhaseWs &ws, hipStream_t s, const ParsedSp
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) { err = std::string("rank launch: ") + hipGetErrorString(e); return W3_E_HIP; }
     }
+    if (n_small_def) (void)hipStreamWaitEvent(s, ws.ev_small, 0);
     if (sa.n_leaves) {
         // HashMaps in HBM, one per (block, leaf), zeroed per batch of blocks; as many blocks at once as the budget allows
         if (!ws.st) { err = "state table not staged"; return W3_E_HIP; }
