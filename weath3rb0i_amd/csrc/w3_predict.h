@@ -598,6 +598,7 @@ __global__ void __launch_bounds__(64) k_partition8(PredictArgs a) {
         uint2 *out = a.rec + off;
         const bool first = off == 0;
         const uint32_t last = len - 1u;
+        unsigned long long t_prev = a.dbg ? __builtin_amdgcn_s_memtime() : 0ull;   // W3_OPT_DEBUG_STAMPS: slots 0 histogram, 1 tile load + count + scan, 2 scatter into the tile, 5 copy out, 4 splits
         // digit counts of the whole block.  digit(pos) = byte[pos - K] (K = 1: c1, 2: c2; zeros before the block start), so
         // this is the byte histogram of bytes [0, len - K) plus K zeros: 16 input bytes per lane and load
         constexpr uint32_t K = MODE == 1 ? 1u : 2u;
@@ -644,9 +645,10 @@ __global__ void __launch_bounds__(64) k_partition8(PredictArgs a) {
         wave_excl_scan_256(tcnt, gcur, nullptr);
         __asm__ volatile("" ::: "memory");
         __builtin_amdgcn_wave_barrier();
+        W3_STAMP(0);
         for (uint32_t t0 = 0; t0 < len; t0 += W3_P8_TILE) {
             const uint32_t tlen = min(W3_P8_TILE, len - t0);
-            uint2 rec[W3_P8_ROUNDS];
+            uint2 rec[W3_P8_ROUNDS];   // (loading a tile ahead, while the one before is sorted and copied out, changes nothing: measured)
 #pragma unroll
             for (uint32_t r = 0; r < W3_P8_ROUNDS; r++) {
                 const uint32_t e = min(t0 + r * 64u + lane, last);
@@ -664,6 +666,7 @@ __global__ void __launch_bounds__(64) k_partition8(PredictArgs a) {
             wave_excl_scan_256(tcnt, tstart, tcur);
             __asm__ volatile("" ::: "memory");
             __builtin_amdgcn_wave_barrier();
+            W3_STAMP(1);
             // stable scatter into the tile: rounds in time order, lanes in order inside the returning add
 #pragma unroll
             for (uint32_t r = 0; r < W3_P8_ROUNDS; r++) {
@@ -674,6 +677,7 @@ __global__ void __launch_bounds__(64) k_partition8(PredictArgs a) {
             }
             __asm__ volatile("" ::: "memory");
             __builtin_amdgcn_wave_barrier();
+            W3_STAMP(2);
             // copy out: element k of the sorted tile belongs to bin d at run offset k - tstart[d]
 #pragma unroll
             for (uint32_t r = 0; r < W3_P8_ROUNDS; r++) {
@@ -690,28 +694,57 @@ __global__ void __launch_bounds__(64) k_partition8(PredictArgs a) {
             for (int k = 0; k < 4; k++) gcur[k * 64 + lane] += tcnt[k * 64 + lane];
             __asm__ volatile("" ::: "memory");
             __builtin_amdgcn_wave_barrier();
+            W3_STAMP(5);
         }
         __threadfence_block();
-        // slice boundaries: the first group start at or after s*len/W3_SLICES
+        // slice boundaries: the first group start at or after s*len/W3_SLICES (lane sl finds boundary sl; W3_SLICES == 64)
         uint32_t *sp = a.splits + (uint64_t)b * (W3_SLICES + 1u);
-        uint32_t prev = 0u;
-        if (lane == 0) { sp[0] = 0u; sp[W3_SLICES] = len; }
-        for (uint32_t sl = 1; sl < W3_SLICES; sl++) {
-            uint32_t start = max((uint32_t)((uint64_t)sl * len / W3_SLICES), prev), found = len;
-            for (uint32_t base = start; base < len; base += 64) {
-                const uint32_t e = base + lane;
-                bool head = false;
-                if (e < len) {
-                    const uint32_t g = MODE == 1 ? ((out[e].y >> 8) & 0xFFu) : ((out[e].y >> 8) & 0xFFFFu);
-                    const uint32_t gp = e ? (MODE == 1 ? ((out[e - 1].y >> 8) & 0xFFu) : ((out[e - 1].y >> 8) & 0xFFFFu)) : 0xFFFFFFFFu;
-                    head = g != gp;
-                }
-                const uint64_t hm = __ballot(head);
-                if (hm) { found = base + (uint32_t)(__ffsll((long long)hm) - 1); break; }
+        static_assert(W3_SLICES == 64u, "one lane per slice boundary");
+        const uint32_t ideal = (uint32_t)((uint64_t)lane * len / W3_SLICES);
+        uint32_t found;
+        if constexpr (MODE == 1) {
+            // groups = the digit's bins, and after the last tile gcur[d] is the END of bin d = the start of the next group: no
+            // record has to be read back (the 63 serial searches through the block's own output, two dependent global loads
+            // each, were a quarter of this kernel's time: W3_OPT_DEBUG_STAMPS)
+            uint32_t lo = 0u, hi = 256u;   // smallest d in [0, 256] with start(d) >= ideal, start(0) = 0, start(d) = gcur[d - 1]
+            while (lo < hi) {
+                const uint32_t mid = (lo + hi) >> 1;
+                const uint32_t st = mid == 0u ? 0u : gcur[mid - 1u];
+                if (st >= ideal) hi = mid; else lo = mid + 1u;
             }
-            if (lane == 0) sp[sl] = found;
-            prev = found;
+            found = lo == 0u ? 0u : (lo <= 256u ? gcur[min(lo, 256u) - 1u] : len);
+            if (found < ideal) found = len;   // (ideal beyond the last group start)
+        } else {
+            // groups = (c2, c1) pairs inside the c2 bins: every lane probes the records at its own ideal boundary first (all 63
+            // searches' loads in flight together); a lane inside a long group then walks on 64 records at a time, wave-wide
+            const uint32_t e0 = min(ideal, last);
+            const uint32_t g0 = (out[e0].y >> 8) & 0xFFFFu, gp0 = e0 ? ((out[e0 - 1u].y >> 8) & 0xFFFFu) : 0xFFFFFFFFu;
+            found = (ideal < len && g0 != gp0) ? ideal : 0xFFFFFFFFu;
+            if (lane == 0) found = 0u;
+            uint64_t todo = __ballot(found == 0xFFFFFFFFu);
+            while (todo) {   // ascending boundaries: the one before is final
+                const int sl = __ffsll((long long)todo) - 1;
+                todo &= todo - 1ull;
+                const uint32_t start = readlane_u32(ideal, sl) + 1u;
+                const uint32_t before = readlane_u32(found, sl - 1);
+                uint32_t f = len;
+                if (before >= start - 1u) f = before;   // still inside the group the previous boundary skipped (one scan per long group)
+                else for (uint32_t base = start; base < len; base += 64u) {
+                    const uint32_t e = base + lane;
+                    bool head = false;
+                    if (e < len) head = ((out[e].y >> 8) & 0xFFFFu) != ((out[e - 1u].y >> 8) & 0xFFFFu);
+                    const uint64_t hm = __ballot(head);
+                    if (hm) { f = base + (uint32_t)(__ffsll((long long)hm) - 1); break; }
+                }
+                if (lane == sl) found = f;
+            }
         }
+        if (lane == 0) found = 0u;
+        // boundaries never decrease (a later ideal point lies in the same or a later group)
+        sp[lane] = found;
+        if (lane == 0) sp[W3_SLICES] = len;
+        W3_STAMP(4);
+        if (a.dbg && lane == 0) atomicAdd(&a.dbg[6], 1ull);
     }
 }
 
