@@ -704,39 +704,52 @@ __global__ void __launch_bounds__(64) k_partition8(PredictArgs a) {
         uint32_t found;
         if constexpr (MODE == 1) {
             // groups = the digit's bins, and after the last tile gcur[d] is the END of bin d = the start of the next group: no
-            // record has to be read back (the 63 serial searches through the block's own output, two dependent global loads
-            // each, were a quarter of this kernel's time: W3_OPT_DEBUG_STAMPS)
-            uint32_t lo = 0u, hi = 256u;   // smallest d in [0, 256] with start(d) >= ideal, start(0) = 0, start(d) = gcur[d - 1]
+            // record has to be read back.  (The 63 serial searches through the block's own output for the first group head — two
+            // dependent global loads each — were more than half of this kernel's time: W3_OPT_DEBUG_STAMPS.)
+            uint32_t lo = 0u, hi = 256u;   // smallest d in [0, 256] with start(d) >= ideal; start(0) = 0, start(d) = gcur[d - 1]
             while (lo < hi) {
                 const uint32_t mid = (lo + hi) >> 1;
                 const uint32_t st = mid == 0u ? 0u : gcur[mid - 1u];
                 if (st >= ideal) hi = mid; else lo = mid + 1u;
             }
-            found = lo == 0u ? 0u : (lo <= 256u ? gcur[min(lo, 256u) - 1u] : len);
-            if (found < ideal) found = len;   // (ideal beyond the last group start)
+            found = lo == 0u ? 0u : gcur[lo - 1u];
         } else {
-            // groups = (c2, c1) pairs inside the c2 bins: every lane probes the records at its own ideal boundary first (all 63
-            // searches' loads in flight together); a lane inside a long group then walks on 64 records at a time, wave-wide
-            const uint32_t e0 = min(ideal, last);
-            const uint32_t g0 = (out[e0].y >> 8) & 0xFFFFu, gp0 = e0 ? ((out[e0 - 1u].y >> 8) & 0xFFFFu) : 0xFFFFFFFFu;
-            found = (ideal < len && g0 != gp0) ? ideal : 0xFFFFFFFFu;
-            if (lane == 0) found = 0u;
-            uint64_t todo = __ballot(found == 0xFFFFFFFFu);
-            while (todo) {   // ascending boundaries: the one before is final
-                const int sl = __ffsll((long long)todo) - 1;
-                todo &= todo - 1ull;
-                const uint32_t start = readlane_u32(ideal, sl) + 1u;
-                const uint32_t before = readlane_u32(found, sl - 1);
-                uint32_t f = len;
-                if (before >= start - 1u) f = before;   // still inside the group the previous boundary skipped (one scan per long group)
-                else for (uint32_t base = start; base < len; base += 64u) {
-                    const uint32_t e = base + lane;
-                    bool head = false;
-                    if (e < len) head = ((out[e].y >> 8) & 0xFFFFu) != ((out[e - 1u].y >> 8) & 0xFFFFu);
-                    const uint64_t hm = __ballot(head);
-                    if (hm) { f = base + (uint32_t)(__ffsll((long long)hm) - 1); break; }
+            // groups = (c2, c1) pairs inside the c2 bins (bin-aligned slices are too coarse here: k_rank_sorted<2> 13 -> 17 ms,
+            // measured).  The searches run EIGHT AT A TIME: the 64 records from each of eight ideal points are loaded together,
+            // then looked through; a group longer than that is walked on 64 records at a time (once: the boundaries behind it
+            // inside the same group take the same answer).
+            found = 0xFFFFFFFFu;
+            for (uint32_t s0 = 1; s0 < W3_SLICES; s0 += 8u) {
+                uint32_t gy[8], gpy[8];
+#pragma unroll
+                for (int k = 0; k < 8; k++) {
+                    const uint32_t st = readlane_u32(ideal, (int)min(s0 + (uint32_t)k, W3_SLICES - 1u));
+                    const uint32_t e = min(st + lane, last);
+                    gy[k] = out[e].y; gpy[k] = out[e ? e - 1u : 0u].y;
                 }
-                if (lane == sl) found = f;
+#pragma unroll
+                for (int k = 0; k < 8; k++) {
+                    const uint32_t sl = s0 + (uint32_t)k;
+                    if (sl >= W3_SLICES) break;
+                    const uint32_t st = readlane_u32(ideal, (int)sl);
+                    const uint32_t e = st + lane;
+                    const bool head = e < len && (e == 0u || ((gy[k] >> 8) & 0xFFFFu) != ((gpy[k] >> 8) & 0xFFFFu));
+                    const uint64_t hm = __ballot(head);
+                    uint32_t f;
+                    if (hm) f = st + (uint32_t)(__ffsll((long long)hm) - 1);
+                    else {
+                        const uint32_t before = readlane_u32(found, (int)sl - 1);
+                        f = len;
+                        if (sl > 1u && before != 0xFFFFFFFFu && before >= st) f = before;   // still inside the group the boundary before skipped
+                        else for (uint32_t base = st + 64u; base < len; base += 64u) {
+                            const uint32_t e2 = base + lane;
+                            const bool h2 = e2 < len && ((out[e2].y >> 8) & 0xFFFFu) != ((out[e2 - 1u].y >> 8) & 0xFFFFu);
+                            const uint64_t hm2 = __ballot(h2);
+                            if (hm2) { f = base + (uint32_t)(__ffsll((long long)hm2) - 1); break; }
+                        }
+                    }
+                    if (lane == sl) found = f;
+                }
             }
         }
         if (lane == 0) found = 0u;

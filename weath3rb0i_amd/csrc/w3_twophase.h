@@ -370,6 +370,8 @@ static inline int twophase_predict(TwoPhaseWs &ws, hipStream_t s, const ParsedSp
     // partition pass — where they used to start — they only delayed it: k_partition8<1> took 14.4 ms instead of 7.2
     // (timeline, profiles/r2_final/timeline_before_reorder.txt) because k_predict_small's 5120 waves filled the CUs first.
     if (n_small_def) {
+        // (Measured: with 3 .. 8 instead of 20 waves per CU, so that it fits beside the rank kernel's 8 from the start, the phase
+        // takes the same 43-44 ms — the two kernels' times add up either way.)
         for (int k = 0; k < n_small_def; k++) launch_small<false>(small_def[k].hbits, dim3(grid_small), sp, small_def[k]);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) { err = std::string("predict launch: ") + hipGetErrorString(e); return W3_E_HIP; }
@@ -378,8 +380,10 @@ static inline int twophase_predict(TwoPhaseWs &ws, hipStream_t s, const ParsedSp
     // join, then rank inside the sorted groups (main stream: these kernels want the Infinity Cache to themselves)
     // (measured, no gain: the later leaves' rank kernels on the side stream beside the first one — 35 + 28 ms together against
     // 17.7 + 15.8 ms one after the other: they saturate the same scattered-store path — and the time-ordered leaves last)
+    // (The first rank kernel used to start as soon as ITS records were sorted, beside the next leaf's partition pass: two kernels
+    // bound by the same non-coalesced store path — together 21.5 ms, one after the other 3.5 + 14: timeline_after_reorder.txt.)
     for (int w = 0; w < n_def; w++) {
-        if (forked) (void)hipStreamWaitEvent(s, ws.ev_join[w], 0);   // this leaf's records are sorted (later leaves may still be partitioning)
+        if (forked) (void)hipStreamWaitEvent(s, ws.ev_join[n_def - 1], 0);   // every leaf's records are sorted
         if (deferred[w].cls == LEAF_WIDE1) hipLaunchKernelGGL(w3::k_rank_sorted<1>, dim3(deferred[w].grid_rank), dim3(64), 0, s, deferred[w].pa);
         else hipLaunchKernelGGL(w3::k_rank_sorted<2>, dim3(deferred[w].grid_rank), dim3(64), 0, s, deferred[w].pa);
         hipError_t e = hipGetLastError();
