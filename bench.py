@@ -153,6 +153,7 @@ def main():
     ap.add_argument("--path", default="auto", help="auto | generic | twophase")
     ap.add_argument("--parts", type=int, default=0, help="EXPERIMENTAL block ranges pipelined inside one encode call (W3_OPT_PARTS): 0 = auto, 1..4")
     ap.add_argument("--coder", default="x4", help="two-phase coder kernel: x4 (default) | x3 | x2 | fast | robust")
+    ap.add_argument("--variant", default="", help="experiments: comma-separated W3_OPT_VARIANT names (Context.set_variant), e.g. no_side_stream")
     ap.add_argument("--no-verify", action="store_true", help="switch W3_OPT_VERIFY off (sampled ballot-round re-prediction of every predict phase; on by default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ref-model", action="store_true", help="skip the extra order012 measurement (the largest model whose streams are entirely the reference's)")
@@ -206,6 +207,8 @@ def main():
     ctx.set_parts(args.parts)
     ctx.set_coder(args.coder)
     ctx.set_verify(not args.no_verify)
+    if args.variant:
+        ctx.set_variant(*args.variant.split(","))
 
     d_in = torch.from_numpy(np.ascontiguousarray(host)).cuda()
     # output buffers are double-buffered: the exchange of step k (RCCL, its own stream) overlaps the encode of step k+1
