@@ -330,6 +330,14 @@ def main():
                     % ("enwik9-shaped text" if args.data == "text" else "Silesia-shaped mix", args.seed, args.scaling,
                        ("%d bytes per GPU (%d in all)" % (n, n_global)) if args.scaling == "weak" else ("ONE stream of %d bytes cut over %d GPU(s)" % (n_global, world)),
                        bs, model_name))
+        # w3_timing.predict_bytes also carries the APM stages' bytes: take the single ORDER0 stage's out again; models with slot
+        # leaves or several stages get no predict-phase figure
+        predict_phase = None
+        if path == 2 and kern_ms["predict_ms"] > 0 and nslot == 0 and napm <= 1:
+            pb = ex["predict_bytes"] / args.steps - (n * (16 * ncnt + 17) if napm == 1 else 0)
+            pms = kern_ms["predict_ms"] / args.steps
+            predict_phase = {"algorithmic_bytes_per_step": int(pb), "achieved_GBps": round(pb / pms / 1e6, 1),
+                             "frac_of_hbm_peak": round(pb / pms / 1e6 / HBM_PEAK_GBPS, 4)}
         res = {
             "metric": "encode MiB/s, %d KiB blocks, bit-exact vs CPU ref" % (bs >> 10),
             "value": round(value, 2), "unit": "MiB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -346,10 +354,7 @@ def main():
             "kernel_ms_per_step": {k: round(v / args.steps, 3) for k, v in kern_ms.items()},
             # the predict phase is several kernels on two streams (their launch durations overlap); as a whole: algorithmic bytes
             # (per leaf input + 16-byte stream, plus 8 B written + 8 B read per record pass of a wide leaf) over the phase's time
-            "predict_phase": ({"algorithmic_bytes_per_step": int(ex["predict_bytes"] / args.steps),
-                               "achieved_GBps": round(ex["predict_bytes"] / max(kern_ms["predict_ms"], 1e-9) / 1e6, 1),
-                               "frac_of_hbm_peak": round(ex["predict_bytes"] / max(kern_ms["predict_ms"], 1e-9) / 1e6 / HBM_PEAK_GBPS, 4)}
-                              if path == 2 and kern_ms["predict_ms"] > 0 else None),
+            "predict_phase": predict_phase,
             # the coder is ONE dependent chain of 8 x block_size bit-steps per lane: its time does not shrink with the block count,
             # so it is the floor of a strong-scaled run (predict / APM / pack scale with the bytes per GPU)
             "floors": {"coder_floor_ms": round(coder_ms, 3) if path == 2 else None, "bit_steps_per_lane": steps_per_lane,
