@@ -296,9 +296,7 @@ __device__ __forceinline__ void apm0_block(const ApmArgs &a, const Apm0Ctx &c) {
             for (int l = 1; l < L; l++) {
                 const uint32_t q0 = pc[l].x, q1 = pc[l].y;
                 const uint32_t e0 = as_u32(pk_opinion_dist(as_u16x2(q0))), e1 = as_u32(pk_opinion_dist(as_u16x2(q1)));
-                uint32_t m0, m1;   // 0xFFFF in the halves where the new leaf is farther from 1/2 (kept as asm: hipcc unpacks the C form into halves)
-                asm("v_pk_sub_i16 %0, %1, %2\n\tv_pk_ashrrev_i16 %0, 15, %0 op_sel_hi:[0,1]" : "=&v"(m0) : "v"(d0), "v"(e0));
-                asm("v_pk_sub_i16 %0, %1, %2\n\tv_pk_ashrrev_i16 %0, 15, %0 op_sel_hi:[0,1]" : "=&v"(m1) : "v"(d1), "v"(e1));
+                const uint32_t m0 = pk_farther_mask(as_u16x2(d0), as_u16x2(e0)), m1 = pk_farther_mask(as_u16x2(d1), as_u16x2(e1));   // 0xFFFF where the new leaf is farther from 1/2
                 w0 = (q0 & m0) | (w0 & ~m0); w1 = (q1 & m1) | (w1 & ~m1);
                 d0 = as_u32(__builtin_elementwise_max(as_u16x2(d0), as_u16x2(e0))); d1 = as_u32(__builtin_elementwise_max(as_u16x2(d1), as_u16x2(e1)));
             }

@@ -477,8 +477,7 @@ __global__ void __launch_bounds__(192) k_coder_x3(Coder3Args a) {
                             for (int l = 1; l < L; l++) {
                                 const uint32_t w = q == 0 ? cur[l][k].x : q == 1 ? cur[l][k].y : q == 2 ? cur[l][k].z : cur[l][k].w;
                                 const u16x2 Q = as_u16x2(w), E = pk_opinion_dist(Q);
-                                const i16x2 farther = as_i16x2(D - E) >> (short)15;          // 0xFFFF where E > D
-                                const uint32_t mask = as_u32(farther);
+                                const uint32_t mask = pk_farther_mask(D, E);                   // 0xFFFF where E > D
                                 P = as_u16x2((as_u32(Q) & mask) | (as_u32(P) & ~mask));
                                 D = __builtin_elementwise_max(D, E);
                             }

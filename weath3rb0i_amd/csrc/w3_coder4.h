@@ -389,8 +389,7 @@ __global__ void __launch_bounds__(L > 1 ? 256 : 192) k_coder_x4(Coder3Args a) {
                         for (int l = 1; l < L; l++) {
                             const uint32_t w = q == 0 ? bf.p[l][k].x : q == 1 ? bf.p[l][k].y : q == 2 ? bf.p[l][k].z : bf.p[l][k].w;
                             const u16x2 Q = as_u16x2(w), E = pk_opinion_dist(Q);
-                            const i16x2 farther = as_i16x2(D - E) >> (short)15;          // 0xFFFF where E > D
-                            const uint32_t mask = as_u32(farther);
+                            const uint32_t mask = pk_farther_mask(D, E);                   // 0xFFFF where E > D
                             P = as_u16x2((as_u32(Q) & mask) | (as_u32(P) & ~mask));
                             D = __builtin_elementwise_max(D, E);
                         }
