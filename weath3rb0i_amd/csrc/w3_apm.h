@@ -67,102 +67,25 @@ __device__ __forceinline__ void apm_table_init(lds_u16 *tab, const lds_u16 *s_ro
     W3_LDS_FENCE();
 }
 
-// lane i receives the value of lane i - 8 / i + 8 of its 16-lane DPP row (lanes without a source get 0)
+// lane i receives the value of lane i - 8 of its 16-lane DPP row (lanes without a source get 0)
 __device__ __forceinline__ uint32_t dpp_from_lane_minus8(uint32_t v) {
     return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118 /* row_shr:8 */, 0xF, 0xF, true);
 }
-__device__ __forceinline__ uint32_t dpp_from_lane_plus8(uint32_t v) {
-    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x108 /* row_shl:8 */, 0xF, 0xF, true);
-}
 
-// One round: 64 steps = 8 positions (k) x 8 bit positions (j), lane = 8 k + j.  The 8 lanes of one position touch 8
-// different rows (no conflicts); the 8 positions are committed in time order, in PAIRS (2m, 2m+1) = one 16-lane DPP row per
-// sub-step, under an EXEC mask of that row (an idle lane executes nothing):
+// One round: 64 steps = 8 positions (k) x 8 bit positions (j), lane = 8 k + j.  The 8 lanes of one position touch 8 different
+// rows (no conflicts); the 8 positions are committed in time order, in PAIRS (2m, 2m+1) = one 16-lane DPP row per sub-step,
+// under an EXEC mask of that row (an idle lane executes nothing):
 //     read the entry to update and its neighbour
 //     nv = (old * (2^rate - 1) + 65535 * bit) >> rate          == old + ((65535 * bit - old) >> rate), arithmetic shift
-//     the later position takes the earlier one's nv over DPP row_shr:8 where it reads the entry the earlier one updates,
-//     and recomputes; the earlier one leaves the store to the later one when both update the same entry
+//     the later position takes the earlier one's nv (DPP row_shr:8) where it reads the entry the earlier one updates, and
+//     recomputes; the earlier one leaves the store to the later one when both update the same entry
 //     write
 // Round 1 had every lane execute every sub-step (selects for "is this my pair", dummy slots for idle lanes, the update as
 // sub / shift / add): 100 VALU instructions per round in the sub-steps, 138 in all, VALU-bound at 84 %.  A sub-step is now
-// 7 VALU + 3 LDS + 4 SALU instructions.  (Committing one position per sub-step needs only 2 VALU each, but 8 serial LDS round
+// 6 VALU + 3 LDS + 5 SALU instructions.  (Committing one position per sub-step needs only 2 VALU each, but 8 serial LDS round
 // trips per round instead of 4, and a CU holds only 8 tables = 8 chains: 35.7 ms against 29.7, measured.)
-// The round is split in three so that a batch's LUT look-ups and address arithmetic run together, ahead of its sub-steps.
-struct ApmPrep {
-    uint32_t a_upd, a_oth, tgt, w, hi, p;
-    uint64_t vm, fu, fo, sh;
-};
-
-__device__ __forceinline__ ApmPrep apm_prep(lds_u16 *tab, const lds_i16 *s_str, uint32_t p, uint32_t row, uint32_t bit, bool valid) {
-    ApmPrep q;
-    const uint32_t pos = (uint32_t)((int)s_str[p >> 4] + 2048) * 32u;
-    q.p = p;
-    q.w = pos & 4095u; q.hi = q.w >> 11;
-    const uint32_t e = row * 33u + (pos >> 12);
-    // LDS byte addresses of the entry this step updates (the nearer one) and of the other one of its pair
-    q.a_upd = (uint32_t)(uintptr_t)(tab + e + q.hi); q.a_oth = (uint32_t)(uintptr_t)(tab + e + 1u - q.hi);
-    q.tgt = bit ? 65535u : 0u;
-    // hazards inside a pair: lanes 0-7 of a DPP row are the earlier position (E), lanes 8-15 the later one (L)
-    const bool is_l = (threadIdx.x & 8u) != 0u;
-    const uint32_t e_upd = dpp_from_lane_minus8(q.a_upd);                       // L lanes: the entry E updates
-    const uint32_t l_upd = dpp_from_lane_plus8(q.a_upd);                        // E lanes: the entry L updates
-    const uint32_t l_valid = dpp_from_lane_plus8(valid ? 1u : 0u);
-    q.vm = __ballot(valid);                                                     // lanes past the block end take no part
-    q.fu = __ballot(valid && is_l && e_upd == q.a_upd);                         // L updates the entry E updates: start from E's new value
-    q.fo = __ballot(valid && is_l && e_upd == q.a_oth);                         // L's other entry is the one E updates
-    q.sh = __ballot(valid && !is_l && l_valid != 0u && l_upd == q.a_upd);       // E leaves the store to L
-    return q;
-}
-
-__device__ __forceinline__ void apm_commit(const ApmPrep &q, uint32_t rate, uint32_t &au, uint32_t &ao) {
-    const uint32_t mult = (uint32_t)__builtin_amdgcn_readfirstlane((int)((1u << rate) - 1u));
-    const uint32_t rate_s = (uint32_t)__builtin_amdgcn_readfirstlane((int)rate);
-    uint32_t tmp, fwd;
-    uint64_t save, m;
-#define W3_APM_SUBSTEP                                            \
-    "s_and_b64 exec, %[m], %[vm]\n"                               \
-    "ds_read_u16 %[au], %[aupd]\n"                                \
-    "ds_read_u16 %[ao], %[aoth]\n"                                \
-    "s_waitcnt lgkmcnt(0)\n"                                      \
-    "v_mad_u32_u24 %[t], %[au], %[mult], %[tgt]\n"                \
-    "v_lshrrev_b32 %[t], %[rate], %[t]\n"                         \
-    "s_nop 1\n"                                                   \
-    "v_mov_b32_dpp %[f], %[t] row_shr:8 row_mask:0xf bank_mask:0xf\n" \
-    "v_cndmask_b32 %[au], %[au], %[f], %[fu]\n"                   \
-    "v_cndmask_b32 %[ao], %[ao], %[f], %[fo]\n"                   \
-    "v_mad_u32_u24 %[t], %[au], %[mult], %[tgt]\n"                \
-    "v_lshrrev_b32 %[t], %[rate], %[t]\n"                         \
-    "s_andn2_b64 exec, exec, %[sh]\n"                             \
-    "ds_write_b16 %[aupd], %[t]\n"                                \
-    "s_lshl_b64 %[m], %[m], 16\n"
-    asm volatile("s_mov_b64 %[save], exec\n"
-                 "s_mov_b64 %[m], 0xffff\n"
-                 "v_mov_b32 %[f], 0\n"
-                 W3_APM_SUBSTEP W3_APM_SUBSTEP W3_APM_SUBSTEP W3_APM_SUBSTEP
-                 "s_mov_b64 exec, %[save]\n"
-                 : [au] "=&v"(au), [ao] "=&v"(ao), [t] "=&v"(tmp), [f] "=&v"(fwd), [save] "=&s"(save), [m] "=&s"(m)
-                 : [aupd] "v"(q.a_upd), [aoth] "v"(q.a_oth), [tgt] "v"(q.tgt), [mult] "s"(mult), [rate] "s"(rate_s), [vm] "s"(q.vm),
-                   [fu] "s"(q.fu), [fo] "s"(q.fo), [sh] "s"(q.sh)
-                 : "memory", "scc");
-#undef W3_APM_SUBSTEP
-}
-
-__device__ __forceinline__ uint32_t apm_finish(const ApmPrep &q, uint32_t au, uint32_t ao) {
-    const uint32_t t0 = q.hi ? ao : au, t1 = q.hi ? au : ao;
-    const uint32_t pa = (t0 * (4096u - q.w) + t1 * q.w) >> 12;
-    const uint32_t o = (q.p + 3u * pa + 2u) >> 2;
-    return o < 1u ? 1u : o > 65535u ? 65535u : o;
-}
-
-// the three stages of one round in one call (k_apm1)
-__device__ __forceinline__ uint32_t apm_round(lds_u16 *tab, const lds_i16 *s_str, uint32_t p, uint32_t row, uint32_t bit,
-                                              bool valid, uint32_t rate, int k) {
-    (void)k;
-    const ApmPrep q = apm_prep(tab, s_str, p, row, bit, valid);
-    uint32_t au, ao;
-    apm_commit(q, rate, au, ao);
-    return apm_finish(q, au, ao);
-}
+// The round is split in three (apm0_prep / apm0_commit / apm0_finish below) so that a batch's LUT look-ups and address
+// arithmetic run together, ahead of its sub-steps.
 
 // ---------------------------------------------------------------------------
 // k_apm0, second form (round 2).  TWO wavefronts per block take alternate batches of W3_APM_PF rounds: only the sub-steps
@@ -189,6 +112,13 @@ __device__ __forceinline__ uint32_t apm_round(lds_u16 *tab, const lds_i16 *s_str
 #define W3_APM0_ROW_B   (W3_APM0_STAGE_B + 2u * W3_APM_WAVES * 512u)      // [33] u16 (identity row), padded to 80 B
 #define W3_APM0_TURN_B  (W3_APM0_ROW_B + 80u)                   // [W3_APM_WAVES] u32
 #define W3_APM0_LDS     (W3_APM0_TURN_B + 4u * W3_APM_WAVES)
+
+// LUT entry of one stretch(p) bucket: (stretch + 2048) * 32 = j << 12 | w;  + 64 rounds to the nearer entry: t >> 7 = j + hi
+__device__ __forceinline__ uint16_t apm_lut_entry(int stretch) {
+    const uint32_t t = (uint32_t)(stretch + 2048 + 64);
+    const uint32_t u = t & 127u, x = u < 64u ? 64u - u : u - 64u;    // w >> 5 = u ^ 64;  x = weight (in 1/128) of the entry that is not updated
+    return (uint16_t)(((t >> 7) << 1) | (x << 7) | (((t >> 6) & 1u) << 15));   // bit 15 = 1 - hi: the other entry is the one above
+}
 
 struct Apm0Prep {
     uint32_t X;       // LDS byte address of the entry this step updates, MINUS 2 (the ds instructions carry offset:2)
@@ -370,9 +300,7 @@ __global__ void __launch_bounds__(128 * W3_APM_WAVES) k_apm0(ApmArgs a) {
     {
         lds_u16 *lut = (lds_u16 *)(uintptr_t)(lds0 + W3_APM0_LUT_B);
         for (uint32_t i = threadIdx.x; i < 4096u; i += blockDim.x) {
-            const uint32_t t = (uint32_t)((int)a.stretch[i] + 2048 + 64);   // (stretch + 2048) * 32 = j << 12 | w;  + 64 rounds to the nearer entry: t >> 7 = j + hi
-            const uint32_t u = t & 127u, x = u < 64u ? 64u - u : u - 64u;    // w >> 5 = u ^ 64;  x = weight (in 1/128) of the entry that is not updated
-            lut[i] = (uint16_t)(((t >> 7) << 1) | (x << 7) | (((t >> 6) & 1u) << 15));   // bit 15 = 1 - hi: the other entry is the one above
+            lut[i] = apm_lut_entry((int)a.stretch[i]);
         }
         lds_u16 *row = (lds_u16 *)(uintptr_t)(lds0 + W3_APM0_ROW_B);
         if (threadIdx.x < 33u) {
@@ -410,10 +338,10 @@ __global__ void __launch_bounds__(128 * W3_APM_WAVES) k_apm0(ApmArgs a) {
 }
 
 __global__ void __launch_bounds__(64 * W3_APM_WAVES) k_apm1(ApmArgs a) {
-    __shared__ uint16_t s_tab[W3_APM_WAVES][W3_APM_TBL + 128];   // + 64 dummy u16 pairs (apm_round)
-    __shared__ int16_t s_str[4096];
+    __shared__ uint16_t s_lut[4096];                              // first: its LDS address is the `lds0` of apm0_prep
+    __shared__ uint16_t s_tab[W3_APM_WAVES][W3_APM_TBL + 2];
     __shared__ uint16_t s_row[34];
-    for (uint32_t i = threadIdx.x; i < 4096u; i += blockDim.x) s_str[i] = a.stretch[i];
+    for (uint32_t i = threadIdx.x; i < 4096u; i += blockDim.x) s_lut[i] = apm_lut_entry((int)a.stretch[i]);
     if (threadIdx.x < 33u) {
         int d = ((int)threadIdx.x - 16) * 128;
         d = d < -2047 ? -2047 : d > 2047 ? 2047 : d;
@@ -422,8 +350,12 @@ __global__ void __launch_bounds__(64 * W3_APM_WAVES) k_apm1(ApmArgs a) {
     __syncthreads();
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, k = lane >> 3, j = lane & 7;
     lds_u16 *tab = (lds_u16 *)&s_tab[wave][0];
-    const lds_i16 *l_str = (const lds_i16 *)&s_str[0];
+    const lds_u16 *l_lut = (const lds_u16 *)&s_lut[0];
     const lds_u16 *l_row = (const lds_u16 *)&s_row[0];
+    const uint32_t lut0 = (uint32_t)(uintptr_t)l_lut - W3_APM0_LUT_B, tabm2 = (uint32_t)(uintptr_t)tab - 2u;
+    const uint32_t onej = 1u << j;
+    const uint32_t mult = (uint32_t)__builtin_amdgcn_readfirstlane((int)((1u << a.rate) - 1u));
+    const uint32_t rate_s = (uint32_t)__builtin_amdgcn_readfirstlane((int)a.rate);
     const uint32_t njobs = a.nblocks * W3_SLICES;
     for (;;) {
         uint32_t job = 0;
@@ -464,37 +396,40 @@ __global__ void __launch_bounds__(64 * W3_APM_WAVES) k_apm1(ApmArgs a) {
                 const uint32_t e = base + (uint32_t)(r * 8 + k);
                 const bool valid = e < len;
                 const uint32_t wv = rc[r].y, byte = wv & 0xFFu, g = (wv >> 8) & 0xFFu;
-                const uint32_t c0 = (1u << j) | (byte >> (8 - j));
-                const uint32_t bit = (byte >> (7 - j)) & 1u;
                 const uint32_t p = pc[r];
                 // groups (previous byte c1) are contiguous and time ordered; each starts from a fresh table
                 const uint64_t vm = __ballot(valid);
                 const uint64_t same = __ballot(valid && g == open_g);
                 uint32_t o;
                 if (same == vm) {
-                    o = apm_round(tab, l_str, p, c0, bit, valid, a.rate, k);
+                    const uint64_t lm = vm & 0xFF00FF00FF00FF00ull, em = vm & (vm >> 8) & 0x00FF00FF00FF00FFull;
+                    const Apm0Prep q = apm0_prep(tabm2, lut0, p, byte, (uint32_t)j, onej, lm, em);
+                    uint32_t au, ao;
+                    apm0_commit(q, mult, rate_s, vm, au, ao);
+                    o = apm0_finish(q, au, ao);
                 } else {
                     // a group boundary inside the round: commit position by position, re-initialising between groups
-                    const uint32_t pos = (uint32_t)((int)l_str[p >> 4] + 2048) * 32u;
-                    const uint32_t w = pos & 4095u, hi = w >> 11;
-                    const uint32_t ent = c0 * 33u + (pos >> 12);
+                    const uint32_t lut = l_lut[p >> 4];
+                    const uint32_t c0 = (1u << j) | (byte >> (8 - j));
+                    const uint32_t bit = (byte >> (7 - j)) & 1u;
+                    const uint32_t upd = c0 * 33u + ((lut & 0x7Eu) >> 1), oth = upd - 1u + ((lut >> 15) << 1);   // the entry trained, and the other one of its pair
+                    const uint32_t x = (lut >> 7) & 127u;
                     const int target = bit ? 65535 : 0;
-                    uint32_t t0 = 0u, t1 = 0u;
+                    int tu = 0, to = 0;
 #pragma unroll 1
                     for (int kk = 0; kk < 8; kk++) {
                         if (!((vm >> (kk * 8)) & 1ull)) break;
                         const uint32_t gk = readlane_u32(g, kk * 8);
                         if (gk != open_g) { apm_table_init(tab, l_row, lane); open_g = gk; }
                         if (k == kk) {
-                            t0 = tab[ent]; t1 = tab[ent + 1u];
-                            const int tv = (int)(hi ? t1 : t0);
-                            tab[ent + hi] = (uint16_t)(tv + ((target - tv) >> a.rate));
+                            tu = (int)tab[upd]; to = (int)tab[oth];
+                            tab[upd] = (uint16_t)(tu + ((target - tu) >> a.rate));
                         }
                         W3_LDS_FENCE();
                     }
-                    const uint32_t pa = (t0 * (4096u - w) + t1 * w) >> 12;
+                    const uint32_t pa = (uint32_t)(tu + (((to - tu) * (int)x) >> 7));
                     o = (p + 3u * pa + 2u) >> 2;
-                    o = o < 1u ? 1u : o > 65535u ? 65535u : o;
+                    o = o < 1u ? 1u : o;
                 }
                 uint16_t *dst = valid ? P + ((uint64_t)rc[r].x * 8u + (uint32_t)j) : a.dummy + lane;
                 *dst = (uint16_t)o;
