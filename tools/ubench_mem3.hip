@@ -61,6 +61,30 @@ int run(uint4 *P, uint32_t nb, uint32_t *cnt, const char *name) {
     printf("%-28s %8.3f ms  (%.2f TB/s payload)\n", name, best, (double)nb * 65536 * 16 / (best * 1e-3) / 1e12);
     return 0;
 }
+// coalesced fill of one 1 MiB region per wave-iteration (k_predict_small's store shape), few waves per CU so that it fits beside k_scatter
+__global__ void __launch_bounds__(64) k_fill_blocks(uint4 *p, uint32_t nblocks) {
+    for (uint32_t b = blockIdx.x; b < nblocks; b += gridDim.x) {
+        uint4 *dst = p + (size_t)b * 65536u;
+        for (uint32_t i = threadIdx.x; i < 65536u; i += 64u) dst[i] = make_uint4(i, b, 2, 3);
+    }
+}
+int concurrent(uint4 *P, uint4 *Q, uint32_t nb, uint32_t *cnt, int fill_waves_per_cu) {
+    hipStream_t sa, sb; CHECK(hipStreamCreateWithFlags(&sa, hipStreamNonBlocking)); CHECK(hipStreamCreateWithFlags(&sb, hipStreamNonBlocking));
+    hipEvent_t e0, e1, f1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1)); CHECK(hipEventCreate(&f1));
+    float best = 1e9f, bestf = 0.f;
+    for (int it = 0; it < 3; it++) {
+        CHECK(hipMemset(cnt, 0, 4)); CHECK(hipDeviceSynchronize());
+        CHECK(hipEventRecord(e0, sa)); CHECK(hipStreamWaitEvent(sb, e0, 0));
+        hipLaunchKernelGGL(k_fill_blocks, dim3(256 * fill_waves_per_cu), dim3(64), 0, sb, Q, nb);
+        hipLaunchKernelGGL((k_scatter<0, 0>), dim3(2048), dim3(64), 0, sa, P, nb, cnt);
+        CHECK(hipEventRecord(f1, sb)); CHECK(hipStreamWaitEvent(sa, f1, 0));
+        CHECK(hipEventRecord(e1, sa)); CHECK(hipEventSynchronize(e1));
+        float ms, msf; CHECK(hipEventElapsedTime(&ms, e0, e1)); CHECK(hipEventElapsedTime(&msf, e0, f1));
+        if (ms < best) { best = ms; bestf = msf; }
+    }
+    printf("scatter 1e9 x 16 B  ||  fill 16 GB with %2d waves per CU: both done after %7.3f ms (the fill after %7.3f ms)\n", fill_waves_per_cu, best, bestf);
+    return 0;
+}
 int main() {
     const uint32_t nb = 15259;
     uint4 *P; uint32_t *cnt;
@@ -78,5 +102,9 @@ int main() {
     run<0, 2>(P, nb, cnt, "ascending ~6 apart");
     run<0, 3>(P, nb, cnt, "ascending ~6 apart, rotated");
     run<0, 4>(P, nb, cnt, "ascending ~37 apart");
+    uint4 *Q; CHECK(hipMalloc(&Q, (size_t)nb * 65536 * 16));
+    concurrent(P, Q, nb, cnt, 4);
+    concurrent(P, Q, nb, cnt, 8);
+    concurrent(P, Q, nb, cnt, 16);
     return 0;
 }
