@@ -344,7 +344,7 @@ def main():
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": "u32", "data": "synthetic",
             "config": {"workload": workload, "bytes_per_gpu": n, "bytes_total": n_global, "block_size": bs, "blocks_per_gpu": nb,
-                       "model": model_name, "path": {1: "generic", 2: "twophase"}.get(path, str(path)), "compressed_ratio": round(ratio, 4),
+                       "context_model": model_name, "path": {1: "generic", 2: "twophase"}.get(path, str(path)), "compressed_ratio": round(ratio, 4),
                        "ranges_per_call": parts,
                        "exchange": "all_gather sizes + grouped send/recv to rank 0 (RCCL), overlapped with the next step's encode" if exchange else "none (1 GPU)"},
             "roofline": {"bound": "hbm", "kernel": dom_name, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
