@@ -450,3 +450,21 @@ def test_device_resident_api(ctx, oracle):
     d_back = torch.empty(len(data), dtype=torch.uint8, device="cuda")
     ctx.decode_blocks_device(w3.Order0(), d_out, d_lens, bs, len(data), d_back)
     assert d_back.cpu().numpy().tobytes() == data
+
+
+@pytest.mark.parametrize("bs", [1 << 20, (1 << 22) + 12345])
+def test_large_blocks_twophase(ctx, oracle, bs):
+    """Blocks far longer than the bench's 64 KiB (the two-phase path takes up to 16 MiB): positions beyond 16 bits in the records,
+    Counter saturation inside long groups, slice boundaries from the bin table, APM batches — against the oracle, with a ragged
+    last block; and the decoder's round trip."""
+    from tests.synth import mixed_bytes
+    data = markov_text(bs + bs // 3, seed=41) + mixed_bytes(bs // 2 + 777, seed=42)
+    for name in ("best012", "order1"):
+        out, lens = check_blocks(ctx, oracle, name, data, bs, "twophase")
+        assert ctx.timing()["path"] == 2
+    dev = lambda: w3.APM(w3.BestOfTwoModel(w3.BestOfTwoModel(w3.Order0(), w3.Order1()), w3.OrderN(27, 3)))
+    orc = lambda: oracle.APM(oracle.BestOfTwoModel(oracle.BestOfTwoModel(oracle.Order0(), oracle.Order1()), oracle.OrderN(27, 3)))
+    out, lens = ctx.encode_blocks(dev(), data, bs)
+    want, wlens = oracle.encode_blocks(orc(), data, bs, nthreads=8)
+    assert lens.tolist() == wlens.tolist() and out.tobytes() == want.tobytes()
+    assert ctx.decode_blocks(dev(), out, lens, bs, len(data)).tobytes() == data
