@@ -12,9 +12,10 @@ def _run(np, torch):
     import weath3rb0i_amd as w3
     from tools import synth
     import bench
-    n = 1_000_000_000; bs = 65536; nb = (n + bs - 1) // bs
+    n = int(float(sys.argv[2])) if len(sys.argv) > 2 else 1_000_000_000
+    bs = 65536; nb = (n + bs - 1) // bs
     name = sys.argv[1] if len(sys.argv) > 1 else "order012apm"
-    K = 6
+    K = 6 if n >= 500_000_000 else 24
     host = synth.text(n, seed=1)
     d_in = torch.from_numpy(host).cuda()
     def mk():
@@ -25,21 +26,25 @@ def _run(np, torch):
         d_lens = torch.zeros(nb, dtype=torch.int32, device="cuda")
         d_total = torch.zeros(1, dtype=torch.int64, device="cuda")
         return model, ctx, st, d_out, d_lens, d_total
-    A = mk(); B = mk()
-    def run(X, k):
-        model, ctx, st, d_out, d_lens, d_total = X
+    nctx = int(sys.argv[3]) if len(sys.argv) > 3 else 2
+    X = [mk() for _ in range(nctx)]
+    def run(x, k):
+        model, ctx, st, d_out, d_lens, d_total = x
         for _ in range(k):
             ctx.encode_blocks_device(model, d_in, bs, d_out, d_lens, d_total, stream=st.cuda_stream)
-    run(A, 1); run(B, 1); torch.cuda.synchronize()
-    t0 = time.perf_counter(); run(A, K); torch.cuda.synchronize(); t1 = time.perf_counter()
+    for x in X: run(x, 1)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter(); run(X[0], K); torch.cuda.synchronize(); t1 = time.perf_counter()
     print("sequential: %.1f ms/step" % ((t1 - t0) / K * 1e3))
     t0 = time.perf_counter()
-    ta = threading.Thread(target=run, args=(A, K // 2)); tb = threading.Thread(target=run, args=(B, K // 2))
-    ta.start(); tb.start(); ta.join(); tb.join(); torch.cuda.synchronize(); t1 = time.perf_counter()
-    print("two in flight: %.1f ms/step  -> %.0f MiB/s" % ((t1 - t0) / K * 1e3, n * K / (t1 - t0) / 2**20))
-    same = bool(torch.equal(A[3][:int(A[5].item())], B[3][:int(B[5].item())]))
+    ths = [threading.Thread(target=run, args=(x, K // nctx)) for x in X]
+    for t in ths: t.start()
+    for t in ths: t.join()
+    torch.cuda.synchronize(); t1 = time.perf_counter()
+    steps = K // nctx * nctx
+    print("%d in flight: %.1f ms/step  -> %.0f MiB/s" % (nctx, (t1 - t0) / steps * 1e3, n * steps / (t1 - t0) / 2**20))
+    same = all(bool(torch.equal(X[0][3][:int(X[0][5].item())], x[3][:int(x[5].item())])) for x in X[1:])
     print("outputs equal:", same)
-
 
 if __name__ == "__main__":
     main()
