@@ -9,16 +9,16 @@
 //
 // In the two-phase encoder the stage's INPUT p is known for every step before the stage runs (the predict
 // kernels produced it), and so are the row (a function of the input bits) and the coded bit.  What stays
-// serial is only the history of each table entry.  One wavefront owns one table in LDS (256 rows x 33 x u16 =
-// 16.5 KiB; four waves share the 8 KiB stretch LUT: two workgroups per CU) and walks its positions in time
-// order, 8 positions x 8 bit positions per round:  lane = (k = position in the round, j = bit position).
+// serial is only the history of each table entry.  A block's table lives in LDS (256 rows x 33 x u16 = 16.5 KiB; the
+// four tables of a workgroup share one 8 KiB LUT: two workgroups = eight tables per CU) and its positions are walked in
+// time order, 8 positions x 8 bit positions per round:  lane = (k = position in the round, j = bit position).
 // The 8 lanes of one position touch 8 different rows (the partial byte c0 has a different length per j), so they
 // are conflict free; the 8 positions of a round are committed one after another (LDS executes one wave's
 // instructions in order), everything else — loads, OpinionMixer2 over the leaf streams, stretch, interpolation,
 // the output store — is done for the 64 steps at once.
 //
-//   k_apm0<L> : row = c0 (W3_APM_ORDER0).  One wave per block, time order; reads the L leaf streams (mixing them
-//               on the fly) or the previous stage's stream, writes the stage's stream.  Coalesced 128-B accesses.
+//   k_apm0<L> : row = c0 (W3_APM_ORDER0).  Two waves per block take alternate batches of 4 rounds, time order; reads the L
+//               leaf streams (mixing them on the fly) or the previous stage's stream, writes the stage's stream, 8 bytes per lane.
 //   k_apm1    : row = c0 | c1 << 8 (W3_APM_ORDER1) = 256 independent order-0 tables keyed by the previous byte.
 //               Walks the block's records sorted by c1 (k_partition<1>): each group is a contiguous, time-ordered
 //               run that starts from a fresh table.  Jobs = (block, slice) handed out block-major (as in
