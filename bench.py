@@ -1,30 +1,43 @@
 #!/usr/bin/env python3
 """bench.py — encode throughput of the weath3rb0i hot path on MI355X.
 
-A "step" is one pass of the hot path (predict + arithmetic-code + pack every
-block of the rank's shard; for N>1 also the RCCL gather of the per-GPU streams
-to rank 0) over one batch of synthetic input already resident in HBM.  One
-process per GPU; for N>1 launch with torch.distributed.run.
+A "step" is one pass of the hot path (predict + APM + arithmetic-code + pack every block of the rank's shard; for N>1 also the
+RCCL gather of the per-GPU streams to rank 0) over one batch of synthetic input already resident in HBM.  One process per GPU.
 
---scaling weak   (default) every GPU gets --size bytes of its own: N x 1e9 bytes in aggregate.
---scaling strong ONE global stream of --size bytes is cut into contiguous block ranges
-                 (shard.byte_range), BASELINE.json configs[3]: "enwik9 sharded across 8 GPUs".
-At N = 1 the two are the same run.
+    python3 bench.py --gpus N --steps K --warmup W
 
-Prints ONE JSON line on rank 0 (contract in the task statement): metric /
-value (whole-job MiB/s) / roofline (dominant kernel vs the HBM roof) /
-cpu_baseline (the CPU oracle = C restatement of the reference, timed on the
-host cores over a bounded sample of the same workload, two legs) / floors (the
-block-count-independent coder chain that bounds strong scaling).
+N > 1 with WORLD_SIZE unset: this process starts the N ranks itself (`python -m torch.distributed.run`, as a child process,
+before anything here touches the GPU), relays rank 0's JSON line and exits with the child's code.  Under a launcher
+(WORLD_SIZE set) it is one rank.
+
+Steps are PIPELINED (--pipeline 2, default): w3_encode_submit / w3_encode_wait keep two encodes in flight, so step k+1's predict
+phase runs beside step k's APM and coder kernels; the timed region holds exactly K steps, bracketed by barrier + synchronize
+(nothing of the warm-up is still running when it starts, everything of step K has landed when it ends).  --pipeline 1: one
+synchronous call per step.
+
+--scaling both (default)  value = the STRONG reading: ONE stream of --size bytes cut into contiguous block ranges over the N GPUs
+                          (BASELINE.json configs[3]: "enwik9 sharded across 8"); for N > 1 the WEAK reading (--size bytes per GPU)
+                          is timed too and attached as "weak".  At N = 1 the two are the same run.
+--scaling strong | weak   that reading only.
+
+Prints ONE JSON line on rank 0 (contract in the task statement): metric / value (whole-job MiB/s) / roofline (the kernel with
+the longest launch vs the HBM roof, every kernel's figure in roofline_kernels) / cpu_baseline (the CPU oracle = C restatement of
+the reference, -O3 -march=native, timed on the host cores over a bounded sample, two legs) / decode (device round trip of EVERY
+block of the last step's output) / other_configs (BASELINE configs[2] and configs[4] shapes, 3 steps each) / floors.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# more hardware queues than HIP's default 4 per priority level, so that the streams of one context (launch, side, verification,
+# the two pipeline stages) do not share one and serialise; must be in the environment before the HIP runtime initialises
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
 SHADER_GHZ = 2.4        # MI355X_MICROARCH.md: max clock; the lone coder waves run at it (profiles/r2_xstep_bench.txt)
@@ -64,9 +77,9 @@ def make_oracle_model(orc, name):
     return orc.OrderNEntropy(11, 3, orc.ACHistory(8, orc.StationaryModel.for_book1()))
 
 
-# per input byte, (Counter leaves, slot-state leaves, APM stages) of each bench model
-MODEL_SHAPE = {"order0": (1, 0, 0), "order01": (2, 0, 0), "order012": (3, 0, 0), "default": (1, 0, 0), "order012apm": (3, 0, 1),
-               "fullcm": (3, 4, 2)}
+# per input byte, (time-ordered Counter leaves, wide Counter leaves, slot-state leaves, APM stages) of each bench model
+MODEL_SHAPE = {"order0": (1, 0, 0, 0), "order01": (1, 1, 0, 0), "order012": (1, 2, 0, 0), "default": (1, 0, 0, 0), "order012apm": (1, 2, 0, 1),
+               "fullcm": (1, 2, 4, 2)}
 
 
 def host_cores():
@@ -99,10 +112,15 @@ def host_cores():
 
 
 def cpu_baseline(name, sample, block_size, budget_s=8.0):
-    """Oracle (kind="port": C restatement of the reference CPU path) on a bounded sample of rank 0's shard, two legs:
+    """Oracle (kind="port": C restatement of the reference CPU path, built -O3 -march=native on this host) on a bounded sample of
+    rank 0's shard, two legs:
     (i) ONE thread, the sample as ONE stream — the reference's actual mode (Cargo.toml:14-15, main.rs:89-113);
     (ii) block-parallel over every host core this process may use (one block per task, fresh model + coder each).
     `value` is leg (ii), the stronger baseline.  Returns (dict, leg-ii streams, lens, bytes covered)."""
+    from oracle import native
+    so = native.build_native()   # before pyoracle's first import: it loads W3_ORACLE_SO
+    if so:
+        os.environ["W3_ORACLE_SO"] = so
     from oracle import pyoracle as orc
     cores, cores_why = host_cores()
 
@@ -136,30 +154,261 @@ def cpu_baseline(name, sample, block_size, budget_s=8.0):
             {"mode": "block-parallel, one %d-byte block per task" % block_size, "value": round(n2 / dt2 / 2**20, 3), "unit": "MiB/s",
              "cores": cores, "sample_bytes": n2, "seconds": round(dt2, 2)}]
     return {"value": legs[1]["value"], "unit": "MiB/s", "cores": cores, "cores_chosen_by": cores_why, "kind": "port",
+            "build": "gcc -O3 -march=native on this host" if so else "gcc -O3 (portable build; the native one could not be made here)",
             "sample": "first %d bytes (%d blocks) of rank 0's shard, %d threads, %.1f s" % (n2, len(lens), cores, dt2),
             "legs": legs}, out, lens, n2
 
 
-def main():
+def launcher_command(n_gpus, argv, port):
+    """The command that starts the N ranks of this bench (what the driver runs itself for N > 1)."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n_gpus), "--master-addr", "127.0.0.1",
+            "--master-port", str(port), os.path.join(ROOT, "bench.py")] + list(argv)
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def self_launch(n_gpus, argv):
+    """WORLD_SIZE unset and --gpus N > 1: start the ranks as a CHILD process (never exec: this process must not touch the GPU, and a
+    GPU process must not be replaced) and relay their output."""
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    p = subprocess.run(launcher_command(n_gpus, argv, free_port()), env=env, stdout=subprocess.PIPE, text=True)
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    for ln in p.stdout.splitlines():
+        if not ln.startswith("{"):
+            print(ln, file=sys.stderr)
+    if p.returncode != 0 or len(lines) != 1:
+        print("bench.py: the %d-rank run failed (exit code %d, %d JSON lines)" % (n_gpus, p.returncode, len(lines)), file=sys.stderr)
+        raise SystemExit(p.returncode or 1)
+    print(lines[0], flush=True)
+    raise SystemExit(0)
+
+
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=6)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--model", default="order012apm", help="order0 | order01 | order012 | default | order012apm (BASELINE configs[1]) | fullcm (configs[2])")
-    ap.add_argument("--size", type=int, default=1_000_000_000, help="input bytes: per GPU (weak) or in all (strong); enwik9-class = 1e9")
-    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
+    ap.add_argument("--size", type=int, default=1_000_000_000, help="input bytes: of the one stream (strong) / per GPU (weak); enwik9-class = 1e9")
+    ap.add_argument("--scaling", default="both", choices=["both", "weak", "strong"])
     ap.add_argument("--data", default="text", choices=["text", "mixed"], help="text = enwik-shaped, mixed = Silesia-shaped (BASELINE configs[4] with --block-size 262144 --size 211938580)")
     ap.add_argument("--block-size", type=int, default=65536)
     ap.add_argument("--path", default="auto", help="auto | generic | twophase")
-    ap.add_argument("--parts", type=int, default=0, help="EXPERIMENTAL block ranges pipelined inside one encode call (W3_OPT_PARTS): 0 = auto, 1..4")
-    ap.add_argument("--coder", default="x4", help="two-phase coder kernel: x4 (default) | x3 | x2 | fast | robust")
-    ap.add_argument("--variant", default="", help="experiments: comma-separated W3_OPT_VARIANT names (Context.set_variant), e.g. no_side_stream")
+    ap.add_argument("--pipeline", type=int, default=2, choices=[1, 2], help="encodes in flight: 2 = w3_encode_submit / w3_encode_wait (default), 1 = one synchronous call per step")
+    ap.add_argument("--coder", default="x4", help="two-phase coder kernel: x4 (default; pipelined and half-CU runs use x5 in its place) | x5 | x3 | x2 | fast | robust")
+    ap.add_argument("--variant", default="", help="experiments: comma-separated W3_OPT_VARIANT names (Context.set_variant), e.g. no_side_stream, half_cu, full_cu")
+    ap.add_argument("--tune", type=int, default=0, help="W3_OPT_TUNE bit mask (scheduling experiments)")
     ap.add_argument("--no-verify", action="store_true", help="switch W3_OPT_VERIFY off (sampled ballot-round re-prediction of every predict phase; on by default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ref-model", action="store_true", help="skip the extra order012 measurement (the largest model whose streams are entirely the reference's)")
+    ap.add_argument("--no-decode", action="store_true", help="skip the device round trip of the last step's whole output")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the 3-step runs of BASELINE configs[2] / configs[4]")
+    ap.add_argument("--quick", action="store_true", help="= --no-cpu-baseline --no-ref-model --no-decode --no-other-configs (profiling runs)")
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--force-exchange", action="store_true", help="run the RCCL exchange step even with 1 rank (rehearsal)")
-    args = ap.parse_args()
+    a = ap.parse_args(argv)
+    if a.quick:
+        a.no_cpu_baseline = a.no_ref_model = a.no_decode = a.no_other_configs = True
+    return a
+
+
+class Regime:
+    """One reading (strong or weak) on this rank: the shard, its device buffers and the step loop."""
+
+    def __init__(self, env, scaling, size, data_kind, block_size, seed):
+        import numpy as np
+        import torch
+        from tools import synth
+        from weath3rb0i_amd import shard
+        self.env, self.scaling, self.bs = env, scaling, block_size
+        rank, world = env["rank"], env["world"]
+        gen = synth.text if data_kind == "text" else synth.mixed
+        nthreads = max(1, min(16, (os.cpu_count() or 8) // max(1, world)))
+        if scaling == "strong":
+            # one global stream of --size bytes; rank r codes the contiguous block range shard.byte_range gives it.
+            # The generator works in 1 MiB chunks from a chunk index: generate the covering chunks, slice the range out.
+            self.n_global = size
+            lo, hi = shard.byte_range(rank, world, size, block_size)
+            c0 = lo >> 20
+            self.host = gen(max(hi - (c0 << 20), 1), seed=seed, chunk0=c0, nthreads=nthreads)[lo - (c0 << 20): hi - (c0 << 20)]
+            self.n = hi - lo
+        else:
+            # rank r owns chunks [r*chunks, (r+1)*chunks) of one global seeded stream (weak scaling: n bytes per GPU)
+            self.n = size
+            self.n_global = size * world
+            chunks_per_rank = (size + (1 << 20) - 1) >> 20
+            self.host = gen(size, seed=seed, chunk0=rank * chunks_per_rank, nthreads=nthreads)
+        n = self.n
+        self.nb = (n + block_size - 1) // block_size
+        self.d_in = torch.from_numpy(np.ascontiguousarray(self.host)).cuda()
+        # two output buffer sets: two encodes in flight, and the exchange of step k (RCCL, its own stream) overlaps step k+1
+        self.d_outs = [torch.empty(n + n // 4 + 64 * self.nb + 1024, dtype=torch.uint8, device="cuda") for _ in range(2)]
+        self.d_lenss = [torch.zeros(max(self.nb, 1), dtype=torch.int32, device="cuda") for _ in range(2)]
+        self.d_totals = [torch.zeros(1, dtype=torch.int64, device="cuda") for _ in range(2)]
+        self.gather_buf = torch.empty(int(self.n_global * 0.75) + 4096, dtype=torch.uint8, device="cuda") if (env["exchange"] and rank == 0) else None
+        self.reqs = [[], []]         # outstanding exchange requests per buffer set
+        self.gathered = None         # (rank totals) of the last exchange
+        self.last_buf = 0
+        self.stream = torch.cuda.current_stream().cuda_stream
+
+    def release(self):
+        import torch
+        self.d_in = self.d_outs = self.d_lenss = self.d_totals = self.gather_buf = None
+        torch.cuda.empty_cache()
+
+    def _exchange(self, k):
+        """the one exchange step: sizes all-gather + grouped send/recv of the packed streams to rank 0 (RCCL), asynchronous"""
+        from weath3rb0i_amd import shard
+        other = k ^ 1
+        shard.wait_all(self.reqs[other])   # rank 0's gather buffer is reused: the previous step's transfers must have landed
+        self.reqs[other] = []
+        _, _, totals, reqs = shard.gather_streams(self.d_outs[k], int(self.d_totals[k].item()), self.d_lenss[k][:self.nb], dst=0,
+                                                   out=self.gather_buf, async_op=True)
+        self.reqs[k] = reqs
+        self.gathered = totals
+
+    def run_steps(self, ctx, model, steps, pipeline, acc=None):
+        """`steps` encodes of this shard (+ exchange), at most `pipeline` in flight; acc: dict that sums w3_timing fields"""
+        from weath3rb0i_amd import shard
+        pending = None
+        for i in range(steps):
+            k = i % 2
+            if self.reqs[k]:
+                shard.wait_all(self.reqs[k])   # buffer set k is about to be overwritten
+                self.reqs[k] = []
+            if pipeline == 1:
+                ctx.encode_blocks_device(model, self.d_in, self.bs, self.d_outs[k], self.d_lenss[k], self.d_totals[k], stream=self.stream)
+                self._done(ctx, k, acc)
+            else:
+                job = ctx.encode_submit(model, self.d_in, self.bs, self.d_outs[k], self.d_lenss[k], self.d_totals[k], stream=self.stream)
+                if pending is not None:
+                    ctx.encode_wait(pending[0])
+                    self._done(ctx, pending[1], acc)
+                pending = (job, k)
+        if pending is not None:
+            ctx.encode_wait(pending[0])
+            self._done(ctx, pending[1], acc)
+
+    def _done(self, ctx, k, acc):
+        self.last_buf = k
+        if acc is not None:
+            tm = ctx.timing()
+            for key, v in tm.items():
+                if isinstance(v, list):
+                    acc[key] = [a + b for a, b in zip(acc.get(key, [0.0] * len(v)), v)]
+                elif key in ("path", "n_wide", "n_parts"):
+                    acc[key] = v
+                else:
+                    acc[key] = acc.get(key, 0) + v
+        if self.env["exchange"]:
+            self._exchange(k)
+
+    def sync(self):
+        import torch
+        import torch.distributed as dist
+        from weath3rb0i_amd import shard
+        if self.env["exchange"]:
+            for k in (0, 1):
+                shard.wait_all(self.reqs[k])
+                self.reqs[k] = []
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def timed(self, ctx, model, steps, warmup, pipeline):
+        """W untimed steps, then exactly K steps between barrier + synchronize on both sides; MAX over ranks.  -> (seconds, timing sums)"""
+        import torch
+        import torch.distributed as dist
+        if warmup:
+            self.run_steps(ctx, model, warmup, pipeline)
+        ctx.set_timing(True)
+        acc = {}
+        self.sync()
+        t0 = time.perf_counter()
+        self.run_steps(ctx, model, steps, pipeline, acc)
+        self.sync()
+        dt = time.perf_counter() - t0
+        ctx.set_timing(False)
+        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        if self.env["world"] > 1:
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        return float(tt.item()), acc
+
+
+def kernel_table(model, n, bs, steps, acc, coder_name):
+    """Every two-phase kernel of the model: (name, average launch ms, ALGORITHMIC bytes per launch) — DESIGN.md §4.
+    Launch durations come from hipEvents on each kernel's own launch stream (w3_timing); kernels of different streams (or of
+    the other encode in flight) overlap, so the durations add up to more than the step."""
+    nsmall, nwide, nslot, napm = MODEL_SHAPE[model]
+    rows = []
+    L = nsmall + nwide + nslot
+    per = lambda key: acc.get(key, 0.0) / steps
+    rows.append(("k_coder_%s (mix + recurrence + output wavefronts)" % coder_name, per("coder_ms") / max(1, acc.get("n_coder_launches", steps) / steps),
+                 acc.get("coder_bytes", 0) / max(1, acc.get("n_coder_launches", steps))))
+    if napm >= 1:
+        rows.append(("k_apm0<%d> (APM stage: two wavefronts per block, table in LDS)%s" % (L, "" if napm == 1 else " + k_apm1 (ORDER1 stage) + k_mix"),
+                     per("apm_ms"), n * (16 * L + 1 + 16) + (napm - 1) * n * (8 + 16 + 16)))
+    if nslot:
+        rows.append(("k_slot (slot-state leaves: lane per block, hash map in HBM; all batches of a step)", per("slot_ms"), nslot * n * (1 + 16 + 2 * 192)))
+    if acc.get("achash_ms", 0) > 0:   # ACHistory leaves: one byte read + 8 key bytes written per input byte (+ the 8 MiB prefix table)
+        rows.append(("k_achash (ACHistory keys of every step, 16-bit prefix table)", per("achash_ms"), n * 9 + (8 << 20)))
+    for w in range(int(acc.get("n_wide", 0))):
+        # wide leaf w: leaf order = Order1-shaped first in every bench model; the order-2 leaf refines the Order1 leaf's records
+        o2 = w >= 1
+        rows.append(("k_rank_sorted<%d> (Counter rounds inside sorted groups, 16-byte scatter)" % (2 if o2 else 1), acc["rank_ms"][w] / steps, n * (8 + 16)))
+        rows.append(("k_partition8<%d> (stable 8-bit partition through LDS tiles)" % (3 if o2 else 1), acc["part_ms"][w] / steps, n * (1 + (8 if o2 else 1) + 8)))
+    if acc.get("small_ms", 0) > 0 and nsmall:
+        rows.append(("k_predict_small<8> (time-ordered Counter leaf, table in LDS)", per("small_ms") / nsmall, n * 17))
+    rows.append(("k_scan_lens + k_pack (wave prefix scan + compaction copy)", per("pack_ms"), 2 * (acc.get("coder_bytes", 0) / steps - n * (16 * (1 if napm else L) + 1))))
+    return [r for r in rows if r[1] > 0]
+
+
+def lookup_traffic(model, n, bs, kernel_name):
+    """PMC-measured HBM bytes per launch of this kernel for this exact config: NOT measured in this run — separate rocprofv3 --pmc
+    passes (FETCH_SIZE doubled per the gfx950 note + WRITE_SIZE), kept under profiles/ and looked up here."""
+    for fn in ("r3_traffic.json", "r2_traffic.json", "r1_traffic.json"):
+        try:
+            for tj in json.load(open(os.path.join(ROOT, "profiles", fn)))["entries"]:
+                if tj["config"] == {"model": model, "bytes_per_gpu": n, "block_size": bs} and kernel_name.startswith(tj["kernel"]):
+                    return int(tj["traffic_bytes_per_step"]), "profiles/" + fn + " (rocprofv3 --pmc passes of this config; a constant looked up, not measured in this run)"
+        except (OSError, KeyError, ValueError):
+            pass
+    return None, None
+
+
+def short_run(w3, model_name, data_kind, size, bs, seed, steps, env):
+    """3-step line of another BASELINE configuration (fresh context; after the main run has released its memory)."""
+    import torch
+    rg = Regime(env, "weak", size, data_kind, bs, seed)
+    ctx = w3.Context(env["local_rank"])
+    try:
+        model, mname = make_model(w3, model_name)
+        pipeline = 1 if model_name == "fullcm" else 2   # (slot-state leaves run synchronously inside submit anyway)
+        dt, acc = rg.timed(ctx, model, steps, 1, pipeline)
+        rows = kernel_table(model_name, rg.n, bs, steps, acc, "x4" if pipeline == 1 else "x5")
+        dom = max(rows, key=lambda r: r[1])
+        res = {"context_model": mname, "data": "enwik9-shaped text" if data_kind == "text" else "Silesia-shaped mix", "bytes": rg.n, "block_size": bs,
+               "blocks": rg.nb, "steps": steps, "pipeline": pipeline, "value": round(rg.n * steps / dt / 2**20, 2), "unit": "MiB/s",
+               "ms_per_step": round(dt / steps * 1e3, 3), "compressed_ratio": round(int(rg.d_totals[rg.last_buf].item()) / max(rg.n, 1), 4),
+               "dominant_kernel": dom[0], "dominant_ms": round(dom[1], 3), "dominant_frac_of_hbm_peak": round(dom[2] / (dom[1] * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+               "kernel_ms_per_step": {k: round(acc.get(k, 0.0) / steps, 3) for k in ("predict_ms", "slot_ms", "apm_ms", "coder_ms", "pack_ms")}}
+    finally:
+        ctx.close()
+        rg.release()
+        torch.cuda.empty_cache()
+    return res
+
+
+def main():
+    args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args.gpus, sys.argv[1:])   # (does not return)
 
     import numpy as np
     import torch
@@ -169,8 +418,6 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus %d needs `python -m torch.distributed.run --nproc-per-node %d bench.py ...`" % (args.gpus, args.gpus))
         raise SystemExit("WORLD_SIZE=%d does not match --gpus %d" % (world, args.gpus))
     torch.cuda.set_device(local_rank)
     exchange = world > 1 or args.force_exchange
@@ -178,209 +425,190 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29517")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    env = {"rank": rank, "world": world, "local_rank": local_rank, "exchange": exchange}
 
     import weath3rb0i_amd as w3
-    from tools import synth
-    from weath3rb0i_amd import shard
 
     bs = args.block_size
-    gen = synth.text if args.data == "text" else synth.mixed
-    nthreads = max(1, min(16, (os.cpu_count() or 8) // max(1, world)))
-    if args.scaling == "strong":
-        # one global stream of --size bytes; rank r codes the contiguous block range shard.byte_range gives it.
-        # The generator works in 1 MiB chunks from a chunk index: generate the covering chunks, slice the range out.
-        n_global = args.size
-        lo, hi = shard.byte_range(rank, world, n_global, bs)
-        c0 = lo >> 20
-        host = gen(max(hi - (c0 << 20), 1), seed=args.seed, chunk0=c0, nthreads=nthreads)[lo - (c0 << 20): hi - (c0 << 20)]
-        n = hi - lo
-    else:
-        # rank r owns chunks [r*chunks, (r+1)*chunks) of one global seeded stream (weak scaling: n bytes per GPU)
-        n = args.size
-        n_global = n * world
-        chunks_per_rank = (n + (1 << 20) - 1) >> 20
-        host = gen(n, seed=args.seed, chunk0=rank * chunks_per_rank, nthreads=nthreads)
-    nb = (n + bs - 1) // bs
     model, model_name = make_model(w3, args.model)
+    pipeline = args.pipeline
     ctx = w3.Context(local_rank)
     ctx.set_path(args.path)
-    ctx.set_parts(args.parts)
     ctx.set_coder(args.coder)
     ctx.set_verify(not args.no_verify)
+    ctx.set_tune(args.tune)
     if args.variant:
         ctx.set_variant(*args.variant.split(","))
 
-    d_in = torch.from_numpy(np.ascontiguousarray(host)).cuda()
-    # output buffers are double-buffered: the exchange of step k (RCCL, its own stream) overlaps the encode of step k+1
-    nbuf = 2 if exchange else 1
-    d_outs = [torch.empty(n + n // 4 + 64 * nb + 1024, dtype=torch.uint8, device="cuda") for _ in range(nbuf)]
-    d_lenss = [torch.zeros(max(nb, 1), dtype=torch.int32, device="cuda") for _ in range(nbuf)]
-    d_total = torch.zeros(1, dtype=torch.int64, device="cuda")
-    stream = torch.cuda.current_stream().cuda_stream
+    readings = ["strong", "weak"] if (args.scaling == "both" and world > 1) else ["strong" if args.scaling == "both" else args.scaling]
+    results = {}
+    rg = None
+    for rd in readings:
+        if rg is not None:
+            rg.release()
+        rg = Regime(env, rd, args.size, args.data, bs, args.seed)
+        dt, acc = rg.timed(ctx, model, args.steps, args.warmup, pipeline)
+        results[rd] = {"dt": dt, "acc": acc, "n": rg.n, "n_global": rg.n_global, "nb": rg.nb,
+                       "ratio": int(rg.d_totals[rg.last_buf].item()) / max(rg.n, 1),
+                       "exchange_totals": list(rg.gathered) if rg.gathered else None}
+    main_rd = readings[0]
+    r0 = results[main_rd]
+    if len(readings) > 1:
+        # the main line's per-kernel figures belong to the FIRST reading; the regime object left alive is the last one's: nothing
+        # below (extras run only at world == 1) needs it
+        pass
+    dt, acc, n, n_global, nb = r0["dt"], r0["acc"], r0["n"], r0["n_global"], r0["nb"]
+    path = int(acc.get("path", 0))
+    coder_name = args.coder if (args.coder != "x4" or (pipeline == 1 and "half_cu" not in args.variant)) else "x5"
 
-    gather_buf = torch.empty(int(n_global * 0.75) + 4096, dtype=torch.uint8, device="cuda") if (exchange and rank == 0) else None
-    gathered = {"pending": [], "k": 0}
+    extras = world == 1 and not exchange and rank == 0
+    ref_model = decode = None
+    kept = []   # (compressed stream, lens) of the live output buffers of the timed steps
+    if extras:
+        for k in sorted({rg.last_buf, rg.last_buf ^ 1} if (args.steps > 1) else {rg.last_buf}):
+            tot = int(rg.d_totals[k].item())
+            kept.append((rg.d_outs[k][:tot].clone(), rg.d_lenss[k][:nb].clone()))
+        if not args.no_ref_model and args.model != "order012" and args.data == "text":
+            # the largest model whose streams are entirely the reference's (no build-defined node): same input, 3 steps, outside the
+            # timed region (the main model's outputs are kept aside for the checks first)
+            m2, m2_name = make_model(w3, "order012")
+            dt2, a2 = rg.timed(ctx, m2, 3, 1, pipeline)
+            ref_model = {"model": m2_name, "value": round(n * 3 / dt2 / 2**20, 2), "unit": "MiB/s", "ms_per_step": round(dt2 / 3 * 1e3, 3), "pipeline": pipeline,
+                         "kernel_ms_per_step": {k: round(a2.get(k, 0.0) / 3, 3) for k in ("predict_ms", "apm_ms", "coder_ms", "pack_ms")},
+                         "compressed_ratio": round(int(rg.d_totals[rg.last_buf].item()) / n, 4),
+                         "note": "every node of this model is the reference's (Order0/Order1/OrderN + OpinionMixer2): its block streams are the reference's streams"}
+    # release the encoder's workspaces (two jobs' worth) before the decoder and the other configurations need the memory
+    ctx.close()
+    host = rg.host
+    d_in_keep = rg.d_in if extras else None
+    rg.d_outs = rg.d_lenss = rg.d_totals = rg.gather_buf = None
+    torch.cuda.empty_cache()
 
-    def step(mdl=None):
-        k = gathered["k"] % nbuf
-        gathered["k"] += 1
-        ctx.encode_blocks_device(mdl or model, d_in, bs, d_outs[k], d_lenss[k], d_total, stream=stream)
-        if exchange:
-            # the one exchange step: sizes all-gather + grouped send/recv of the packed streams to rank 0 (RCCL).
-            # The previous step's transfers must have landed before rank 0's gather buffer is reused.
-            shard.wait_all(gathered["pending"])
-            allb, alll, totals, reqs = shard.gather_streams(d_outs[k], int(d_total.item()), d_lenss[k][:nb], dst=0, out=gather_buf, async_op=True)
-            gathered["pending"] = reqs
-            gathered["bytes"] = sum(totals)
+    if extras and not args.no_decode:
+        # independent full check + decode rate: EVERY block of the last timed step's output through the device decoder (lane per
+        # block, k_generic_nl / k_cm_nl: no kernel in common with the predict phase), compared with the input on the device
+        dctx = w3.Context(local_rank)
+        try:
+            comp, lens = kept[-1]
+            back = torch.empty(n, dtype=torch.uint8, device="cuda")
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            dctx.decode_blocks_device(model, comp, lens, bs, n, back)
+            torch.cuda.synchronize()
+            ddt = time.perf_counter() - t0
+            decode = {"value": round(n / ddt / 2**20, 2), "unit": "MiB/s", "seconds": round(ddt, 3), "blocks": nb,
+                      "roundtrip_all_blocks": bool(torch.equal(back, d_in_keep)),
+                      "note": "w3_decode_blocks_device over the whole output of the last timed step, outside the timed region"}
+            del back
+        finally:
+            dctx.close()
+            torch.cuda.empty_cache()
 
-    def sync():
-        if exchange:
-            shard.wait_all(gathered["pending"])
-            gathered["pending"] = []
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    def timed(mdl, steps):
-        ctx.set_timing(True)
-        kern = {"predict_ms": 0.0, "achash_ms": 0.0, "slot_ms": 0.0, "apm_ms": 0.0, "coder_ms": 0.0, "pack_ms": 0.0, "generic_ms": 0.0}
-        extra = {"coder_bytes": 0, "predict_bytes": 0, "launches": 0, "parts": 1, "path": 0}
-        sync()
-        t0 = time.perf_counter()
-        for _ in range(steps):
-            step(mdl)
-            tm = ctx.timing()  # events were recorded on the launch stream; the encode call already synchronised it
-            for k in kern:
-                kern[k] += tm[k]
-            extra["coder_bytes"] += tm["coder_bytes"]
-            extra["predict_bytes"] += tm["predict_bytes"]
-            extra["launches"] += max(1, tm["n_coder_launches"])
-            extra["path"] = tm["path"]
-            extra["parts"] = max(1, tm["n_parts"])
-        sync()
-        dt = time.perf_counter() - t0
-        ctx.set_timing(False)
-        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        if world > 1:
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        return float(tt.item()), kern, extra
-
-    for _ in range(args.warmup):
-        step()
-    dt, kern_ms, ex = timed(model, args.steps)
-    coder_bytes, launches, parts, path = ex["coder_bytes"], ex["launches"], ex["parts"], ex["path"]
-    total_out = int(d_total.item())
-    last_buf = (gathered["k"] - 1) % nbuf   # buffers of the last timed step
-
-    ref_model = None
-    g_lens_keep = g_out_keep = None
-    if world == 1 and not exchange and not args.no_ref_model and args.model != "order012" and args.data == "text":
-        # the largest model whose streams are entirely the reference's (no build-defined node): same input, 3 steps, outside the
-        # timed region (the main model's output is kept aside for the bit-exactness check first)
-        if not args.no_cpu_baseline:
-            g_lens_keep = d_lenss[last_buf].clone()
-            g_out_keep = d_outs[last_buf][:total_out].clone()
-        m2, m2_name = make_model(w3, "order012")
-        step(m2)
-        dt2, k2, _ = timed(m2, 3)
-        ref_model = {"model": m2_name, "value": round(n * 3 / dt2 / 2**20, 2), "unit": "MiB/s", "ms_per_step": round(dt2 / 3 * 1e3, 3),
-                     "kernel_ms_per_step": {k: round(v / 3, 3) for k, v in k2.items()}, "compressed_ratio": round(int(d_total.item()) / n, 4),
-                     "note": "every node of this model is the reference's (Order0/Order1/OrderN + OpinionMixer2): its block streams are the reference's streams"}
-
+    res = None
     if rank == 0:
-        ratio = total_out / max(n, 1)
         ms_per_step = dt / args.steps * 1e3
         value = n_global * args.steps / dt / 2**20
-        # dominant kernel = the longest-running one of this model's two-phase kernels (or the fused lane-per-block kernel)
-        traffic = traffic_src = None
-        ncnt, nslot, napm = MODEL_SHAPE[args.model]
+        nsmall, nwide, nslot, napm = MODEL_SHAPE[args.model]
+        ncnt = nsmall + nwide
+        ratio = r0["ratio"]
         if path == 2:
-            # algorithmic HBM bytes per step: coder = streams + input + compressed bytes; k_apm0 = L streams +
-            # input + its output stream; k_slot = per leaf and input byte 2 nibbles x (96 B read + 96 B written) + input + stream
-            cands = [("k_coder_%s (mix + recurrence + output wavefronts)" % args.coder, kern_ms["coder_ms"] / launches, coder_bytes / launches)]
-            if napm == 1:
-                cands.append(("k_apm0<%d> (APM stage: wave per block, table in LDS)" % (ncnt + nslot), kern_ms["apm_ms"] / (args.steps * parts),
-                              n * (16 * (ncnt + nslot) + 1 + 16) / parts))
-            if nslot:
-                cands.append(("k_slot (slot-state leaves: lane per block, hash map in HBM; all batches of a step)",
-                              kern_ms["slot_ms"] / args.steps, nslot * n * (1 + 16 + 2 * 192)))
-            if kern_ms["achash_ms"] > 0:   # ACHistory leaves: one byte read + 8 key bytes written per input byte (+ the 8 MiB prefix table)
-                cands.append(("k_achash (ACHistory keys of every step, 16-bit prefix table)", kern_ms["achash_ms"] / (args.steps * parts),
-                              n * 9 / parts + (8 << 20)))
-            dom_name, dom_ms, dom_bytes = max(cands, key=lambda c: c[1])
-            # PMC-measured HBM bytes of this kernel for this exact config: NOT measured in this run — separate rocprofv3 --pmc passes
-            # (FETCH_SIZE doubled per the gfx950 note + WRITE_SIZE), kept under profiles/ and looked up here
-            for fn in ("r2_traffic.json", "r1_traffic.json"):
-                try:
-                    for tj in json.load(open(os.path.join(ROOT, "profiles", fn)))["entries"]:
-                        if tj["config"] == {"model": args.model, "bytes_per_gpu": n, "block_size": bs} and dom_name.startswith(tj["kernel"]) and traffic is None:
-                            traffic = int(tj["traffic_bytes_per_step"] / parts)   # per launch, like `achieved`
-                            traffic_src = "profiles/" + fn + " (rocprofv3 --pmc passes of this config; a constant looked up, not measured in this run)"
-                except (OSError, KeyError, ValueError):
-                    pass
+            rows = kernel_table(args.model, n, bs, args.steps, acc, coder_name)
         else:
-            dom_ms = kern_ms["generic_ms"] / args.steps
             # A = 1 + c (stream write) + 64 B of Counter RMW per table model and input byte
             # + 384 B per slot-state leaf (2 nibbles x 96-B cell read + write) + 48 B per APM stage (8 x (4 B read + 2 B write))
-            dom_bytes = n * (1 + ratio + 64 * ncnt + 384 * nslot + 48 * napm)
-            dom_name = "k_cm" if (nslot or napm) else "k_generic"
-        achieved = dom_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
-        coder_ms = kern_ms["coder_ms"] / args.steps
+            rows = [("k_cm" if (nslot or napm) else "k_generic", acc.get("generic_ms", 0.0) / args.steps, n * (1 + ratio + 64 * ncnt + 384 * nslot + 48 * napm))]
+        rows = rows or [("none", 1e-9, 0)]
+        table = []
+        for name, ms, nbytes in rows:
+            tr, src = lookup_traffic(args.model, n, bs, name)
+            table.append({"kernel": name, "avg_launch_ms": round(ms, 4), "algorithmic_bytes_per_launch": int(nbytes),
+                          "achieved": round(nbytes / (ms * 1e-3) / 1e9, 2), "frac": round(nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 5),
+                          "traffic": tr, "traffic_source": src})
+        dom = max(table, key=lambda r: r["avg_launch_ms"])   # the time-dominant kernel
+        coder_ms = acc.get("coder_ms", 0.0) / args.steps
         steps_per_lane = 8 * min(bs, max(n, 1))
-        workload = ("%s synthetic (tools/synth.c seed %d), %s scaling: %s, %d-byte blocks, model %s"
-                    % ("enwik9-shaped text" if args.data == "text" else "Silesia-shaped mix", args.seed, args.scaling,
-                       ("%d bytes per GPU (%d in all)" % (n, n_global)) if args.scaling == "weak" else ("ONE stream of %d bytes cut over %d GPU(s)" % (n_global, world)),
-                       bs, model_name))
-        # w3_timing.predict_bytes also carries the APM stages' bytes: take the single ORDER0 stage's out again; models with slot
-        # leaves or several stages get no predict-phase figure
+        readings_txt = {"strong": "ONE stream of %d bytes cut over %d GPU(s)" % (r0["n_global"], world),
+                        "weak": "%d bytes per GPU (%d in all)" % (n, n_global)}[main_rd]
+        workload = ("%s synthetic (tools/synth.c seed %d), %s scaling: %s, %d-byte blocks, model %s, %s"
+                    % ("enwik9-shaped text" if args.data == "text" else "Silesia-shaped mix", args.seed, main_rd, readings_txt, bs, model_name,
+                       "two encodes in flight (w3_encode_submit / w3_encode_wait)" if pipeline == 2 else "one synchronous call per step"))
+        # the predict phase is several kernels; as a whole: algorithmic bytes (per leaf input + 16-byte stream, plus 8 B written + 8 B read
+        # per record pass of a wide leaf) over the phase's time.  w3_timing.predict_bytes also carries the APM stages' bytes: take the
+        # single ORDER0 stage's out again; models with slot leaves or several stages get no predict-phase figure
         predict_phase = None
-        if path == 2 and kern_ms["predict_ms"] > 0 and nslot == 0 and napm <= 1:
-            pb = ex["predict_bytes"] / args.steps - (n * (16 * ncnt + 17) if napm == 1 else 0)
-            pms = kern_ms["predict_ms"] / args.steps
-            predict_phase = {"algorithmic_bytes_per_step": int(pb), "achieved_GBps": round(pb / pms / 1e6, 1),
+        if path == 2 and acc.get("predict_ms", 0) > 0 and nslot == 0 and napm <= 1:
+            pb = acc["predict_bytes"] / args.steps - (n * (16 * ncnt + 17) if napm == 1 else 0)
+            pms = acc["predict_ms"] / args.steps
+            predict_phase = {"algorithmic_bytes_per_step": int(pb), "ms": round(pms, 3), "achieved_GBps": round(pb / pms / 1e6, 1),
                              "frac_of_hbm_peak": round(pb / pms / 1e6 / HBM_PEAK_GBPS, 4)}
+        exch = "none (1 GPU)"
+        if exchange:
+            exch = ("all_gather sizes + grouped send/recv to rank 0 (RCCL) over %d rank(s), overlapped with the next step's encode; last step gathered %s bytes (per rank %s)"
+                    % (dist.get_world_size(), sum(r0["exchange_totals"] or [0]), r0["exchange_totals"]))
         res = {
             "metric": "encode MiB/s, %d KiB blocks, bit-exact vs CPU ref" % (bs >> 10),
             "value": round(value, 2), "unit": "MiB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
+            "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": main_rd, "vs_baseline": None,
             "dtype": "u32", "data": "synthetic",
             "config": {"workload": workload, "bytes_per_gpu": n, "bytes_total": n_global, "block_size": bs, "blocks_per_gpu": nb,
                        "context_model": model_name, "path": {1: "generic", 2: "twophase"}.get(path, str(path)), "compressed_ratio": round(ratio, 4),
-                       "ranges_per_call": parts,
-                       "exchange": "all_gather sizes + grouped send/recv to rank 0 (RCCL), overlapped with the next step's encode" if exchange else "none (1 GPU)"},
-            "roofline": {"bound": "hbm", "kernel": dom_name, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic, "traffic_source": traffic_src,
-                         "avg_launch_ms": round(dom_ms, 4), "algorithmic_bytes_per_launch": int(dom_bytes),
-                         "launches_per_step": parts if path == 2 else 1},
-            "kernel_ms_per_step": {k: round(v / args.steps, 3) for k, v in kern_ms.items()},
-            # the predict phase is several kernels on two streams (their launch durations overlap); as a whole: algorithmic bytes
-            # (per leaf input + 16-byte stream, plus 8 B written + 8 B read per record pass of a wide leaf) over the phase's time
+                       "encodes_in_flight": pipeline, "exchange": exch, "ranks_seen_by_rccl": dist.get_world_size() if exchange else 1},
+            "roofline": {"bound": "hbm", "kernel": dom["kernel"], "achieved": dom["achieved"], "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": dom["frac"], "traffic": dom["traffic"], "traffic_source": dom["traffic_source"],
+                         "avg_launch_ms": dom["avg_launch_ms"], "algorithmic_bytes_per_launch": dom["algorithmic_bytes_per_launch"], "launches_per_step": 1,
+                         "chosen_by": "longest average launch among the step's kernels (hipEvents on each kernel's launch stream)"},
+            "roofline_kernels": table,
+            "whole_step": {"algorithmic_bytes": int(sum(r["algorithmic_bytes_per_launch"] for r in table)),
+                           "achieved_GBps": round(sum(r["algorithmic_bytes_per_launch"] for r in table) / (ms_per_step * 1e-3) / 1e9, 1),
+                           "frac_of_hbm_peak": round(sum(r["algorithmic_bytes_per_launch"] for r in table) / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)},
+            "kernel_ms_per_step": {k: round(acc.get(k, 0.0) / args.steps, 3) for k in ("predict_ms", "achash_ms", "slot_ms", "apm_ms", "coder_ms", "pack_ms", "generic_ms")},
             "predict_phase": predict_phase,
             # the coder is ONE dependent chain of 8 x block_size bit-steps per lane: its time does not shrink with the block count,
             # so it is the floor of a strong-scaled run (predict / APM / pack scale with the bytes per GPU)
             "floors": {"coder_floor_ms": round(coder_ms, 3) if path == 2 else None, "bit_steps_per_lane": steps_per_lane,
                        "cycles_per_bit_step": round(coder_ms * 1e-3 * SHADER_GHZ * 1e9 / steps_per_lane, 1) if path == 2 else None,
                        "clock_ghz_assumed": SHADER_GHZ,
-                       "strong_scaling_projection_ms": ({str(g): round(coder_ms + (ms_per_step - coder_ms) / g, 2) for g in (1, 2, 4, 8)}
-                                                        if (world == 1 and path == 2) else None),
-                       "note": "projection for ONE stream of bytes_total cut over g GPUs = coder_floor + (ms_per_step - coder_floor) / g, gather overlapped; not a measurement"},
+                       "note": "the coder's launch duration; with two encodes in flight it runs beside the next step's predict kernels"},
         }
+        if "weak" in results and main_rd != "weak":
+            rw = results["weak"]
+            res["weak"] = {"value": round(rw["n_global"] * args.steps / rw["dt"] / 2**20, 2), "unit": "MiB/s", "ms_per_step": round(rw["dt"] / args.steps * 1e3, 3),
+                           "bytes_per_gpu": rw["n"], "bytes_total": rw["n_global"], "steps": args.steps, "warmup": args.warmup,
+                           "note": "weak reading: every GPU codes its own --size bytes; same K steps, same barriers"}
         if ref_model:
             res["reference_stream_model"] = ref_model
-        if world == 1 and not args.no_cpu_baseline:
+        if decode:
+            res["decode"] = decode
+
+    if extras and not args.no_other_configs and args.model == "order012apm" and args.data == "text" and args.size >= 100_000_000:
+        # BASELINE configs[2] (full CM) at the same size and configs[4]'s shape (Silesia-sized mix, 256 KiB blocks, the hash-map model)
+        d_in_keep = None
+        rg.release()
+        oc = []
+        for mname, kind, size, obs in (("fullcm", "text", args.size, bs), ("fullcm", "mixed", 211_938_580, 262144)):
+            try:
+                oc.append(short_run(w3, mname, kind, size, obs, args.seed, 3, env))
+            except Exception as e:   # an extra must not lose the main line
+                oc.append({"context_model": mname, "data": kind, "error": str(e)[:300]})
+        res["other_configs"] = oc
+
+    if rank == 0:
+        if extras and not args.no_cpu_baseline:
             cb, cout, clens, cn = cpu_baseline(args.model, host, bs)
-            # the baseline run doubles as a bit-exactness check of the timed GPU output
+            # the baseline run doubles as a bit-exactness check of the timed GPU output: every output buffer of the timed steps that is still live
             nchk = len(clens)
-            src_lens = g_lens_keep if g_lens_keep is not None else d_lenss[last_buf]
-            g_lens = src_lens[:nchk].cpu().numpy().astype(np.uint32)
-            src_out = g_out_keep if g_out_keep is not None else d_outs[last_buf]
-            g_out = src_out[: int(g_lens.sum())].cpu().numpy()
-            cb["bit_exact_vs_gpu"] = bool(np.array_equal(g_lens, clens) and np.array_equal(g_out, cout))
+            ok = True
+            for comp, lens in kept:
+                g_lens = lens[:nchk].cpu().numpy().astype(np.uint32)
+                g_out = comp[: int(g_lens.sum())].cpu().numpy()
+                ok = ok and bool(np.array_equal(g_lens, clens) and np.array_equal(g_out, cout))
+            cb["bit_exact_vs_gpu"] = ok
+            cb["buffers_checked"] = len(kept)
             res["cpu_baseline"] = cb
         print(json.dumps(res), flush=True)
     if exchange:
         dist.barrier()
         dist.destroy_process_group()
-    ctx.close()
 
 
 if __name__ == "__main__":

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define W3_ABI_VERSION 5
+#define W3_ABI_VERSION 6
 
 /* ---- error codes --------------------------------------------------------- */
 enum {
@@ -97,6 +97,9 @@ typedef struct w3_huff_table {
     uint16_t rem_code[256]; uint8_t rem_len[256];
 } w3_huff_table;
 
+/* Zero-initialise the struct before filling it (n_huff and huff are read even when no leaf uses HuffHistory:
+ * n_huff > W3_MAX_HUFF, or n_huff != 0 with huff == NULL, is W3_E_INVALID; the tables themselves are only read when a
+ * W3_HIST_HUFF leaf refers to them). */
 typedef struct w3_model_spec {
     uint32_t n_nodes;
     w3_node  nodes[W3_MAX_NODES];
@@ -121,20 +124,29 @@ int         w3_spec_validate(const w3_model_spec *spec);
 enum {
     W3_OPT_PATH   = 1,  /* W3_PATH_*: which device implementation encode uses      */
     W3_OPT_TIMING = 2,  /* 1 = record per-kernel hipEvent timings (w3_get_timing) */
-    W3_OPT_CODER  = 3,  /* two-phase coder kernel: 0 = k_coder_x4 (default), 1 = k_coder_fast, 2 = robust k_coder only, 3 = k_coder_x2, 4 = k_coder_x3 */
+    W3_OPT_CODER  = 3,  /* two-phase coder kernel: 0 = k_coder_x4 (default; w3_encode_submit and the half-CU variant run k_coder_x5 in its
+                           place), 1 = k_coder_fast, 2 = robust k_coder only, 3 = k_coder_x2, 4 = k_coder_x3, 5 = k_coder_x5 */
     W3_OPT_ACC_LIMIT = 4, /* test hook (19..46): accumulator fill at which the fast coder hands a block back */
     W3_OPT_DEBUG_STAMPS = 5, /* diagnostic: 1 = the partitioned predict kernel sums s_memtime per phase */
-    W3_OPT_PARTS = 6,   /* EXPERIMENTAL, not part of the stable surface: block ranges of one call pipelined on separate streams;
-                           0/1 = one range (default), 2..4.  Output is identical; measured no faster on MI355X */
+    /* 6 was W3_OPT_PARTS (block ranges of ONE call pipelined on streams; measured useless, ABI v5): superseded by
+       w3_encode_submit / w3_encode_wait, which pipeline successive CALLS */
     W3_OPT_VARIANT = 7, /* cross-check hook for the tests: bit mask of alternative, bit-exact implementations — 1 = Counter rounds
                            with ballots instead of returning LDS adds, 2 = 4-bit partition passes, 4 = order-2 partition from
-                           scratch, 8 = CM decoder without LDS staging, 16 = no side stream, 32 = FAULT INJECTION: one LDS-add round of
-                           every block returns two lanes each other's value (the sampled verification must catch it).  0 = defaults */
+                           scratch, 8 = CM decoder without LDS staging, 16 = no side stream, 64 = synchronous calls use the half-CU
+                           kernel shapes of the submit / wait pipeline, 128 = submitted calls use the plain shapes.  0 = defaults.
+                           32 = FAULT INJECTION (test hook of the sampled verification): one LDS-add round of every block returns two
+                           lanes each other's value; refused (W3_E_INVALID) unless W3_OPT_VERIFY is on, so it cannot corrupt output */
     W3_OPT_SLOT_BUDGET_MB = 8, /* cap (MiB) on the device memory one batch of slot-state hash maps may take; 0 = derive from free memory */
-    W3_OPT_VERIFY = 9   /* 1 (default): after every two-phase predict that used returning LDS adds — whose lane-ordered resolution is
-                           measured, not documented by the ISA — up to 64 sampled blocks are predicted again with ballot rounds and
-                           compared on the device; on a mismatch the call is re-encoded on the ballot path (w3_timing.n_lds_faults)
-                           and the context stays there.  0 = off */
+    W3_OPT_VERIFY = 9,  /* 1 (default): after every two-phase predict that used returning LDS adds — whose lane-ordered resolution is
+                           measured, not documented by the ISA — max(16, nblocks / 256) sampled full-length blocks (at most 64 MiB of
+                           input; the sample rotates from call to call) are predicted again with ballot rounds and compared on the
+                           device; on a mismatch the call is re-encoded on the ballot path (w3_timing.n_lds_faults) and the context
+                           stays there.  What it covers: a SYSTEMATIC change of the hardware's behaviour shows in any block and is
+                           caught by the first call; a sporadic mis-order in one unsampled block is caught only with probability
+                           sample / nblocks per call.  Full coverage = decode the output (w3_decode_blocks_device shares no kernel
+                           with the predict phase; bench.py does that for every block of its last step).  0 = off */
+    W3_OPT_TUNE = 11,   /* scheduling experiments of the submit / wait pipeline (bit mask; output is identical whatever is set) */
+    W3_OPT_FAULT_BLOCK = 10 /* test hook, with W3_OPT_VARIANT bit 32: the one block the injected fault hits (-1 = every block, default) */
 };
 enum { W3_PATH_AUTO = 0, W3_PATH_GENERIC = 1, W3_PATH_TWOPHASE = 2 };
 int         w3_ctx_set_option(w3_ctx *ctx, int opt, int64_t value);
@@ -174,6 +186,26 @@ int w3_encode_blocks_device(w3_ctx *ctx, const w3_model_spec *spec,
 int w3_decode_blocks_device(w3_ctx *ctx, const w3_model_spec *spec,
                             const uint8_t *d_in, size_t in_len, const uint32_t *d_block_lens, size_t nblocks,
                             size_t block_size, uint64_t orig_len, uint8_t *d_out, void *stream);
+
+/* ---- the same encode, asynchronous: up to TWO calls in flight per context -----------------------------
+ * The reference codes one bit at a time on one thread (main.rs:103-109); here a call is three phases with different
+ * bottlenecks (predict: the store path; APM: LDS round trips; coder: one latency chain per lane on 239 of 256 CUs), and a
+ * single call runs them one after the other.  w3_encode_submit only ENQUEUES: call k+1's predict phase then executes beside
+ * call k's APM and coder kernels (each job has its own workspace; kernel shapes that share a CU's LDS: DESIGN.md 2.8).
+ *   w3_encode_submit  arguments as w3_encode_blocks_device (d_total is required); *job receives a handle (0 or 1).  The
+ *                     input must stay valid and the outputs untouched until the job has been waited for.  `stream`: the
+ *                     stream d_in was produced on (the job starts after the work enqueued there so far).  W3_E_INVALID when
+ *                     two jobs are in flight already.  Specs the predict kernels do not cover, and specs with slot-state
+ *                     leaves, run synchronously inside the call (still completed by w3_encode_wait).
+ *   w3_encode_wait    blocks until the job is complete; returns what w3_encode_blocks_device would have returned
+ *                     (W3_E_NOSPACE included; d_total holds the need).  Jobs may be waited for in any order.
+ * Every other entry point returns W3_E_INVALID while a job is in flight.  Output is byte-identical to the synchronous
+ * call's.                                                                                                            */
+int w3_encode_submit(w3_ctx *ctx, const w3_model_spec *spec,
+                     const uint8_t *d_in, size_t n, size_t block_size,
+                     uint8_t *d_out, size_t out_cap,
+                     uint32_t *d_block_lens, uint64_t *d_total, void *stream, int *job);
+int w3_encode_wait(w3_ctx *ctx, int job);
 
 /* ---- sharding over several GPUs from ONE process (C, C++ or Rust hosts) ---------------------------
  * Blocks are independent (fresh model + coder each), so they shard with no data-path collective: context r codes the
@@ -274,10 +306,14 @@ typedef struct w3_timing {
     float    slot_ms;      /* slot-state leaves: table zero-fill + k_slot launches (also inside predict_ms) */
     uint32_t n_slot_launches; /* k_slot launches (block batches sized to the device memory budget) */
     float    achash_ms;    /* ACHistory key kernels (k_achash_lut + k_achash; also inside predict_ms) */
-    uint32_t n_parts;      /* block ranges the call was pipelined in (W3_OPT_PARTS); the *_ms fields above are sums over
-                              the ranges' kernels, which overlap in time: their sum can exceed total_ms */
+    uint32_t n_parts;      /* always 1 (ABI v5: block ranges of W3_OPT_PARTS) */
     uint32_t n_lds_faults; /* wavefronts of the sampled verification whose streams differed (W3_OPT_VERIFY); > 0: the call was
                               re-encoded with ballot rounds */
+    /* launch durations of the predict phase's kernels (they may overlap in time: side stream, or another job's kernels) */
+    uint32_t n_wide;       /* wide Counter leaves (H = 16 / 24) of the spec, in leaf order (at most 4 are timed) */
+    float    part_ms[4];   /* k_partition8 / k_partition pass of wide leaf w */
+    float    rank_ms[4];   /* k_rank_sorted of wide leaf w */
+    float    small_ms;     /* k_predict_small launches of the time-ordered Counter leaves (H <= 8, raw history), together */
 } w3_timing;
 int w3_get_timing(const w3_ctx *ctx, w3_timing *out);
 

@@ -20,9 +20,10 @@ def build():
 
 
 def _load():
-    if not os.path.exists(_SO):
+    so = os.environ.get("W3_ORACLE_SO") or _SO   # (bench.py points this at the native build before the first import)
+    if so == _SO and not os.path.exists(_SO):
         build()
-    lib = C.CDLL(_SO)
+    lib = C.CDLL(so)
     vp, u8p, sz = C.c_void_p, C.POINTER(C.c_uint8), C.c_size_t
     lib.w3o_order0.restype = vp
     lib.w3o_order1.restype = vp

@@ -1,5 +1,6 @@
-"""bench.py's contract on a small input: ONE JSON line with the metric, the roofline of the dominant kernel and the CPU baseline
-(the driver parses exactly this), bit-exactness of the sampled blocks against the oracle included."""
+"""bench.py's contract on a small input: ONE JSON line with the metric, the roofline of the time-dominant kernel, the CPU baseline
+(the driver parses exactly this), bit-exactness of the sampled blocks against the oracle and the full device round trip included;
+and the self-launch of the ranks for --gpus N."""
 import json
 import os
 import subprocess
@@ -8,11 +9,11 @@ import sys
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-pytestmark = pytest.mark.gpu
+sys.path.insert(0, ROOT)
 
 
-def run_bench(*extra):
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--size", "6000000", *extra],
+def run_bench(*extra, gpus=1):
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(gpus), "--steps", "3", "--warmup", "1", "--size", "6000000", *extra],
                        capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
@@ -20,28 +21,70 @@ def run_bench(*extra):
     return json.loads(lines[0])
 
 
+@pytest.mark.gpu
 def test_bench_line_contract():
     d = run_bench()
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config"):
         assert k in d, k
-    assert d["unit"] == "MiB/s" and d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1 and d["higher_is_better"] is True
-    assert d["scaling"] == "weak" and d["vs_baseline"] is None and d["data"] == "synthetic" and "workload" in d["config"] and "model" not in d["config"]
+    assert d["unit"] == "MiB/s" and d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 1 and d["higher_is_better"] is True
+    assert d["scaling"] == "strong" and d["vs_baseline"] is None and d["data"] == "synthetic" and "workload" in d["config"] and "model" not in d["config"]
+    assert d["config"]["encodes_in_flight"] == 2
     assert d["value"] > 0 and abs(d["value"] - 6000000 / (d["ms_per_step"] * 1e-3) / 2**20) / d["value"] < 0.02
     rf = d["roofline"]
     for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
         assert k in rf, k
     assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-4
+    # the named kernel is the one with the longest launch, and the predict kernels are candidates
+    table = d["roofline_kernels"]
+    assert rf["avg_launch_ms"] == max(r["avg_launch_ms"] for r in table)
+    names = " ".join(r["kernel"] for r in table)
+    for k in ("k_rank_sorted<1>", "k_rank_sorted<2>", "k_partition8<1>", "k_predict_small", "k_apm0<3>", "k_coder_x5"):
+        assert k in names, k
     cb = d["cpu_baseline"]
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in cb, k
-    assert cb["kind"] == "port" and cb["bit_exact_vs_gpu"] is True and len(cb["legs"]) == 2 and cb["legs"][0]["cores"] == 1
+    assert cb["kind"] == "port" and cb["bit_exact_vs_gpu"] is True and cb["buffers_checked"] == 2 and len(cb["legs"]) == 2 and cb["legs"][0]["cores"] == 1
+    assert d["decode"]["roundtrip_all_blocks"] is True and d["decode"]["blocks"] == 92
     assert d["floors"]["coder_floor_ms"] > 0 and d["floors"]["bit_steps_per_lane"] == 8 * 65536
     assert d["predict_phase"]["algorithmic_bytes_per_step"] == 115 * 6000000          # 3 leaves x 17 B + 2 wide leaves x 32 B of record passes
     assert d["reference_stream_model"]["value"] > 0
+    assert "other_configs" not in d   # (only at enwik8 size and above)
 
 
-def test_bench_strong_scaling_flag_and_other_models():
-    d = run_bench("--scaling", "strong", "--model", "order012", "--no-cpu-baseline")
-    assert d["scaling"] == "strong" and d.get("cpu_baseline") is None and "ONE stream" in d["config"]["workload"]
-    d = run_bench("--model", "default", "--no-cpu-baseline", "--no-ref-model")
-    assert "k_achash" in d["roofline"]["kernel"] or "k_coder" in d["roofline"]["kernel"]
+@pytest.mark.gpu
+def test_bench_readings_models_and_sync_mode():
+    d = run_bench("--scaling", "weak", "--model", "order012", "--quick")
+    assert d["scaling"] == "weak" and d.get("cpu_baseline") is None and "per GPU" in d["config"]["workload"]
+    d = run_bench("--model", "default", "--quick", "--pipeline", "1")
+    assert d["config"]["encodes_in_flight"] == 1
+    assert "k_achash" in d["roofline"]["kernel"] or "k_coder" in d["roofline"]["kernel"] or "k_predict_small" in d["roofline"]["kernel"]
+
+
+@pytest.mark.gpu
+def test_bench_self_launch_one_rank_with_exchange():
+    """--gpus N with WORLD_SIZE unset starts the ranks itself; on the 1-GPU box: through the launcher path with --force-exchange
+    under an explicit one-rank torch.distributed.run, the same command line the self-launch builds for N ranks."""
+    import bench
+    cmd = bench.launcher_command(1, ["--gpus", "1", "--steps", "2", "--warmup", "1", "--size", "6000000", "--quick", "--force-exchange"], bench.free_port())
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["config"]["ranks_seen_by_rccl"] == 1 and "over 1 rank(s)" in d["config"]["exchange"] and d["value"] > 0
+
+
+def test_launcher_command_for_n_ranks():
+    """CPU: the command bench.py runs for --gpus N when nobody launched it (the driver's own form: one process per GPU,
+    127.0.0.1 rendezvous); and the parent never reaches a GPU call before it (self_launch is the first thing main() does)."""
+    import bench
+    cmd = bench.launcher_command(2, ["--gpus", "2", "--steps", "4"], 29999)
+    assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"]
+    assert "--nnodes=1" in cmd and cmd[cmd.index("--nproc-per-node") + 1] == "2"
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[cmd.index("--master-port") + 1] == "29999"
+    assert cmd[-5] == os.path.join(ROOT, "bench.py") and cmd[-4:] == ["--gpus", "2", "--steps", "4"]
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    body = src[src.index("def main():"):]
+    assert body.index("self_launch(") < body.index("import torch")
+    a = bench.parse_args(["--gpus", "4"])
+    assert a.gpus == 4 and a.scaling == "both" and a.pipeline == 2

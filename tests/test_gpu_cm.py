@@ -189,18 +189,27 @@ def test_slot_tables_in_batches(ctx, oracle):
         ctx.set_slot_budget_mb(0)
 
 
-def test_apm_models_in_block_ranges(ctx, oracle):
-    """Range pipelining with APM chains (ORDER0 and ORDER1 stages); slot-state specs stay in one range."""
+def test_apm_models_submit_wait_pipeline(ctx, oracle):
+    """w3_encode_submit / w3_encode_wait with APM chains (ORDER0 and ORDER1 stages) and the half-CU kernel shapes: two calls in
+    flight, outputs identical to the oracle's; a spec with slot-state leaves runs synchronously inside submit."""
+    import torch
     data = markov_text(500 * 1024 + 17, seed=33)
-    ctx.set_parts(3)
-    try:
-        for name in ("o012_apm", "apm_chain4"):
-            check(ctx, oracle, name, data, 512, decode=False)
-        dev, _ = pair(oracle, "slot2")
-        ctx.encode_blocks(dev(), data[:300 * 512], 512)
-        assert ctx.timing()["n_parts"] == 1
-    finally:
-        ctx.set_parts(0)
+    host = np.frombuffer(data, dtype=np.uint8)
+    n, bs = len(host), 512
+    nb = (n + bs - 1) // bs
+    d_in = torch.from_numpy(host.copy()).cuda()
+    bufs = [(torch.empty(2 * n + 64 * nb + 64, dtype=torch.uint8, device="cuda"), torch.zeros(nb, dtype=torch.int32, device="cuda"),
+             torch.zeros(1, dtype=torch.int64, device="cuda")) for _ in range(2)]
+    torch.cuda.synchronize()
+    for name in ("o012_apm", "apm_chain4", "slot2"):
+        dev, orc = pair(oracle, name)
+        want, wlens = oracle.encode_blocks(orc(), data, bs, nthreads=8)
+        jobs = [ctx.encode_submit(dev(), d_in, bs, *bufs[k]) for k in range(2)]
+        for k in (1, 0):   # any order
+            ctx.encode_wait(jobs[k])
+            d_out, d_lens, d_total = bufs[k]
+            assert d_lens.cpu().numpy().astype(np.uint32).tolist() == wlens.tolist(), name
+            assert d_out[: int(d_total.item())].cpu().numpy().tobytes() == want.tobytes(), name
 
 
 def test_cm_unstaged_kernel_still_agrees(ctx, oracle):

@@ -140,6 +140,23 @@ def test_twophase_path_models(ctx, oracle, name):
     assert np.array_equal(p, want)
 
 
+def test_huff_keys_long_run_of_untrained_byte(ctx, oracle):
+    """A byte absent from HuffHistory's training buffer has code length 0 (legal through from_tables): it adds nothing to
+    compressed_bits, so k_huffkeys' walk-back over a long run of it never covers 32 bits.  The walk is bounded and such blocks
+    are redone with the forward recurrence (k_huffkeys_fix): a 64 KiB block that is ONE run of an untrained byte must come out
+    exact, in well under a second (the unbounded walk was ~2^31 loads for it), and so must runs that start mid-block."""
+    import time
+    data = b"x" * 65536 + markov_text(3000, seed=5) + b"\x00" * 40000 + b"e tao" * 2000 + b"x" * 30000 + markov_text(2000, seed=6)
+    t0 = time.time()
+    check_blocks(ctx, oracle, "huff_11_skew", data, 65536, "twophase")
+    check_blocks(ctx, oracle, "huff_mix_text", data, 16384, "twophase")
+    assert time.time() - t0 < 60
+    dev, orc = pair(oracle, "huff_11_skew")
+    p = ctx.predict_blocks(dev(), data[:70000], 65536)
+    want = np.concatenate([oracle.predict_all(orc(), data[o:min(o + 65536, 70000)]) for o in range(0, 70000, 65536)])
+    assert np.array_equal(p, want)
+
+
 def test_order2_partition_chained_and_from_scratch(ctx, oracle):
     """An order-2 leaf behind an Order1 leaf refines that leaf's c1-sorted records (k_partition<3>, two passes); alone,
     ahead of the Order1 leaf, or with the hook set it sorts from scratch (k_partition<2>, four passes).  Same streams."""
@@ -218,34 +235,137 @@ def test_sampled_verification_catches_misordered_lds_adds(oracle):
             out, lens = c.encode_blocks(dev(), data, 16384)                    # the context now runs ballot rounds: no fault to find
             assert c.timing()["n_lds_faults"] == 0 and out.tobytes() == want.tobytes()
             c.set_variant("inject_lds_fault")                                  # (set_variant re-arms the LDS-add path)
-            c.set_verify(False)
-            out, lens = c.encode_blocks(dev(), data, 16384)                    # verification off: the corruption goes through
-            assert out.tobytes() != want.tobytes(), name
+            p = c.predict_blocks(dev(), data[:65536], 16384)                   # Model::predict straight from the kernels (no verification
+            ref = np.concatenate([oracle.predict_all(orc(), data[o:o + 16384]) for o in range(0, 65536, 16384)])   # there): the corruption shows
+            assert not np.array_equal(p, ref), name
+            with pytest.raises(w3.W3Error):                                    # the hook cannot be used to corrupt OUTPUT: it needs the verification
+                c.set_verify(False)
         finally:
             c.close()
 
 
-@pytest.mark.parametrize("parts", [2, 3, 4])
-def test_block_ranges_pipelined_on_streams(ctx, oracle, parts):
-    """W3_OPT_PARTS: the call's blocks as 2..4 ranges on separate streams (range r's APM / coder kernels beside range
-    r+1's predict kernels), own workspace each; same streams, lengths and hand-backs as one range."""
-    data = markov_text(300 * 1024 + 333, seed=31) + bytes(40 * 1024) + lcg_text(200 * 1024, seed=6)
-    bs = 512                                                     # 1081 blocks -> ranges of >= 256 blocks
-    ctx.set_parts(parts)
+def test_sampled_verification_rotates_over_all_blocks(oracle):
+    """The sample is max(16, nblocks / 256) blocks and ROTATES from call to call: a fault confined to ONE block that the first
+    call's sample misses is met after a bounded number of calls (nblocks / sample).  Until then the corrupted stream goes out —
+    the coverage limit of a sampled check, stated in w3hip.h; the full check is a decode of the output (bench.py, test_gpu_fullsize)."""
+    bs, nb = 1024, 400
+    data = markov_text(bs * nb, seed=29)
+    c = w3.Context(0)
+    try:
+        c.set_path("twophase")
+        dev, orc = pair(oracle, "order0")
+        want, wlens = oracle.encode_blocks(orc(), data, bs, nthreads=8)
+        gap = nb // 16                      # 16 sampled blocks, 25 apart; call k samples blocks 25 s + (k mod 25)
+        victim = 25 * 3 + 7                 # first in the sample at call 7
+        c.set_variant("inject_lds_fault")
+        c.set_fault_block(victim)
+        caught_at = None
+        for call in range(gap + 1):
+            out, lens = c.encode_blocks(dev(), data, bs)
+            if c.timing()["n_lds_faults"] > 0:
+                caught_at = call
+                assert lens.tolist() == wlens.tolist() and out.tobytes() == want.tobytes()   # re-encoded on the ballot path
+                break
+            assert out.tobytes() != want.tobytes()   # not sampled yet: the one corrupted block goes out
+        assert caught_at == 7, caught_at
+        out, lens = c.encode_blocks(dev(), data, bs)   # the context stays on the ballot path
+        assert c.timing()["n_lds_faults"] == 0 and out.tobytes() == want.tobytes()
+    finally:
+        c.close()
+
+
+def _device_bufs(n, bs, count):
+    import torch
+    nb = (n + bs - 1) // bs
+    return [(torch.empty(2 * n + 64 * nb + 64, dtype=torch.uint8, device="cuda"), torch.zeros(max(nb, 1), dtype=torch.int32, device="cuda"),
+             torch.zeros(1, dtype=torch.int64, device="cuda")) for _ in range(count)]
+
+
+def test_submit_wait_pipeline(ctx, oracle):
+    """w3_encode_submit / w3_encode_wait: two calls in flight on one context (call k+1's predict phase beside call k's APM and
+    coder kernels, each job in its own workspace, half-CU kernel shapes and k_coder_x5).  Every output equals the oracle's and the
+    synchronous call's; jobs alternate over many submissions, with different inputs and specs in flight together; a third
+    submission is refused until a job has been waited for; synchronous entry points are refused while jobs are in flight;
+    specs outside the predict kernels run synchronously inside submit."""
+    import torch
+    from weath3rb0i_amd import _lib as L
+    bs = 4096
+    datas = [markov_text(300 * 1024 + 333, seed=31) + bytes(40 * 1024) + lcg_text(100 * 1024, seed=6), lcg_text(200 * 1024 + 7, seed=9) + markov_text(150 * 1024, seed=32)]
+    names = ["best012", "order0", "main_default", "ordern_12_0"]   # the last one: lane-per-block kernel, synchronous inside submit
+    d_ins = [torch.from_numpy(np.frombuffer(d, dtype=np.uint8).copy()).cuda() for d in datas]
+    bufs = _device_bufs(max(len(d) for d in datas), bs, 2)
+    torch.cuda.synchronize()
+    want = {(k, nm): oracle.encode_blocks(pair(oracle, nm)[1](), datas[k], bs, nthreads=8) for k in range(2) for nm in names}
     ctx.set_timing(True)
     try:
-        for name in ("best012", "main_default", "order0"):
-            check_blocks(ctx, oracle, name, data, bs, "twophase")
-            assert ctx.timing()["n_parts"] == parts
-        ctx.set_acc_limit(19)                                   # hand-backs in every range (robust coder per range)
-        check_blocks(ctx, oracle, "best012", data, bs, "twophase")
+        pending = []   # (job, buffer index, data index, name)
+        seq = [(i % 2, names[i % len(names)]) for i in range(10)]
+        for i, (k, nm) in enumerate(seq):
+            if len(pending) == 2:
+                job, bi, kk, nn = pending.pop(0)
+                ctx.encode_wait(job)
+                d_out, d_lens, d_total = bufs[bi]
+                w_out, w_lens = want[(kk, nn)]
+                nbk = len(w_lens)
+                assert d_lens[:nbk].cpu().numpy().astype(np.uint32).tolist() == w_lens.tolist(), (i, nn)
+                assert d_out[: int(d_total.item())].cpu().numpy().tobytes() == w_out.tobytes(), (i, nn)
+                assert ctx.timing()["total_ms"] > 0
+            bi = i % 2
+            job = ctx.encode_submit(pair(oracle, nm)[0](), d_ins[k], bs, *bufs[bi])
+            pending.append((job, bi, k, nm))
+            if len(pending) == 2 and i == 1:
+                with pytest.raises(w3.W3Error) as e:   # both jobs busy
+                    ctx.encode_submit(pair(oracle, nm)[0](), d_ins[k], bs, *bufs[bi])
+                assert e.value.code == L.W3_E_INVALID
+                with pytest.raises(w3.W3Error) as e:   # no synchronous call while jobs are in flight
+                    ctx.encode_blocks(pair(oracle, "order0")[0](), datas[0][:9000], bs)
+                assert e.value.code == L.W3_E_INVALID
+        for job, bi, kk, nn in pending:
+            ctx.encode_wait(job)
+            d_out, d_lens, d_total = bufs[bi]
+            w_out, w_lens = want[(kk, nn)]
+            assert d_out[: int(d_total.item())].cpu().numpy().tobytes() == w_out.tobytes(), nn
+        with pytest.raises(w3.W3Error):
+            ctx.encode_wait(0)   # nothing in flight
+    finally:
+        ctx.set_timing(False)
+    # the synchronous call in the pipeline's kernel shapes, and the submitted call in the plain shapes: same streams
+    for variant in ("half_cu", "full_cu"):
+        ctx.set_variant(variant)
+        try:
+            check_blocks(ctx, oracle, "best012", datas[0], bs, "twophase")
+            job = ctx.encode_submit(pair(oracle, "best012")[0](), d_ins[0], bs, *bufs[0])
+            ctx.encode_wait(job)
+            assert bufs[0][0][: int(bufs[0][2].item())].cpu().numpy().tobytes() == want[(0, "best012")][0].tobytes(), variant
+        finally:
+            ctx.set_variant()
+
+
+def test_submit_wait_redo_paths(ctx, oracle):
+    """What w3_encode_wait redoes synchronously: blocks the fast coder hands back (W3_OPT_ACC_LIMIT hook); and W3_E_NOSPACE.
+    (A stripe overflow past 2N+64 takes the same redo; no adaptive-Counter input reaches it: the estimator's regret is bounded.)"""
+    import torch
+    from weath3rb0i_amd import _lib as L
+    bs = 512
+    data = markov_text(300 * 1024 + 333, seed=31) + bytes(40 * 1024) + lcg_text(200 * 1024, seed=6)
+    d_in = torch.from_numpy(np.frombuffer(data, dtype=np.uint8).copy()).cuda()
+    bufs = _device_bufs(len(data), bs, 2)
+    w_out, w_lens = oracle.encode_blocks(pair(oracle, "best012")[1](), data, bs, nthreads=8)
+    ctx.set_acc_limit(19)   # hand-backs in many blocks
+    try:
+        jobs = [ctx.encode_submit(pair(oracle, "best012")[0](), d_in, bs, *bufs[k]) for k in range(2)]
+        for k in range(2):
+            ctx.encode_wait(jobs[k])
+            assert bufs[k][0][: int(bufs[k][2].item())].cpu().numpy().tobytes() == w_out.tobytes()
         assert ctx.timing()["n_recoded_blocks"] > 0
     finally:
         ctx.set_acc_limit(46)
-        ctx.set_parts(0)
-        ctx.set_timing(False)
-    out, lens = ctx.encode_blocks(pair(oracle, "best012")[0](), data[:100 * 512], bs)   # too few blocks: one range
-    assert ctx.timing()["n_parts"] == 1
+    # out_cap too small: W3_E_NOSPACE from the wait, the need in d_total
+    small = torch.empty(1000, dtype=torch.uint8, device="cuda")
+    job = ctx.encode_submit(pair(oracle, "best012")[0](), d_in, bs, small, bufs[0][1], bufs[0][2])
+    with pytest.raises(w3.W3Error) as e:
+        ctx.encode_wait(job)
+    assert e.value.code == L.W3_E_NOSPACE and int(bufs[0][2].item()) == len(w_out)
 
 
 @pytest.mark.parametrize("name", NOT_TWOPHASE)
@@ -281,18 +401,19 @@ def test_twophase_counter_saturation(ctx, oracle):
 
 
 def test_coder_variants_and_fallback(ctx, oracle):
-    """k_coder_fast (slot/carry accumulator) the robust k_coder, and the hand-back path."""
+    """Every coder kernel (k_coder_x4 / x5 asm pipelines, x3, x2, k_coder_fast with its slot/carry accumulator, the robust k_coder) and
+    the hand-back path; x5 also with one, three and four streams mixed on the fly and ragged / tiny blocks (its C paths)."""
     data = markov_text(60000, seed=31) + bytes(5000) + np.random.default_rng(2).integers(0, 256, 20000, dtype=np.uint8).tobytes()
     want, wlens = oracle.encode_blocks(oracle.BestOfTwoModel(oracle.Order0(), oracle.Order1()), data, 8192, nthreads=8)
     model = w3.BestOfTwoModel(w3.Order0(), w3.Order1())
     ctx.set_path("twophase")
     try:
-        for mode in ("x4", "x3", "x2", "fast", "robust"):
+        for mode in ("x4", "x5", "x3", "x2", "fast", "robust"):
             ctx.set_coder(mode)
             out, lens = ctx.encode_blocks(model, data, 8192)
             assert lens.tolist() == wlens.tolist() and out.tobytes() == want.tobytes(), mode
             assert ctx.timing()["n_recoded_blocks"] == 0
-        for mode in ("x4", "x3", "x2", "fast"):
+        for mode in ("x4", "x5", "x3", "x2", "fast"):
             ctx.set_coder(mode)
             for limit in (19, 24, 33):  # force the fast coders to give blocks back to k_coder
                 ctx.set_acc_limit(limit)
@@ -301,6 +422,11 @@ def test_coder_variants_and_fallback(ctx, oracle):
                 if limit == 19:
                     assert ctx.timing()["n_recoded_blocks"] > 0
             ctx.set_acc_limit(46)
+        ctx.set_coder("x5")
+        tail = markov_text(3 * 8192 + 5, seed=77) + b"ab"
+        for name in ("order0", "best012", "best_ac_wide"):
+            for d_, bs_ in ((data, 8192), (tail, 8192), (tail[:8195], 4099), (tail[:700], 7), (tail[:64 * 13 + 3], 13)):
+                check_blocks(ctx, oracle, name, d_, bs_, "twophase")
     finally:
         ctx.set_acc_limit(46)
         ctx.set_coder("x4")

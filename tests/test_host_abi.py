@@ -29,7 +29,7 @@ def test_exports_match_header(lib):
         assert hasattr(lib, name), "libw3hip.so does not export %s" % name
     assert declared == set(L.EXPORTS)
     m = re.search(r"#define W3_ABI_VERSION (\d+)", open(os.path.join(ROOT, "include", "w3hip.h")).read())
-    assert lib.w3_abi_version() == int(m.group(1)) == 5
+    assert lib.w3_abi_version() == int(m.group(1)) == 6
 
 
 def test_struct_layout(lib):
@@ -66,6 +66,12 @@ def test_spec_validation_errors(lib):
     assert lib.w3_spec_validate(C.byref(s)) == L.W3_E_INVALID
     s.n_nodes = 0
     assert lib.w3_spec_validate(C.byref(s)) == L.W3_E_INVALID
+    # table-set fields are checked before anything is dereferenced (a spec must be zero-initialised: w3hip.h)
+    h = w3.Order0().spec()
+    h.n_huff = 2   # huff == NULL
+    assert lib.w3_spec_validate(C.byref(h)) == L.W3_E_INVALID
+    h.n_huff = 99
+    assert lib.w3_spec_validate(C.byref(h)) == L.W3_E_INVALID
     two = L.ModelSpec()
     two.n_nodes = 2
     two.nodes[0] = w3.Order0().spec().nodes[0]

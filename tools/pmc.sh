@@ -3,7 +3,7 @@
 TAG=$1; CNT=$2; shift; shift
 OUT=$PWD/gpurun_out/pmc_$TAG
 mkdir -p "$OUT"; export TMPDIR=/tmp
-rocprofv3 --pmc $CNT --kernel-trace --output-format csv -d "$OUT/p" -o p -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-ref-model "$@" > "$OUT/bench.log" 2>&1
+rocprofv3 --pmc $CNT --kernel-trace --output-format csv -d "$OUT/p" -o p -- python3 bench.py --steps 1 --warmup 1 --quick "$@" > "$OUT/bench.log" 2>&1
 python3 - "$OUT" <<'PY'
 import csv, glob, sys, collections
 out = sys.argv[1]

@@ -8,7 +8,7 @@ TAG=$1; shift
 OUT=$PWD/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
-ARGS="--steps 2 --warmup 1 --no-cpu-baseline --no-ref-model $*"
+ARGS="--steps 2 --warmup 1 --quick $*"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kt" -o kt -- python3 bench.py $ARGS > "$OUT/bench_kt.log" 2>&1
 echo "kernel trace done"
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$OUT/fetch" -o fetch -- python3 bench.py $ARGS > "$OUT/bench_fetch.log" 2>&1

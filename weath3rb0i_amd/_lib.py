@@ -13,8 +13,9 @@ W3_MAX_APM = 4
 W3_HIST_NONE, W3_HIST_RAW, W3_HIST_AC, W3_HIST_HUFF = 0, 1, 2, 3
 W3_MAX_HUFF = 4
 W3_OK, W3_E_INVALID, W3_E_NOSPACE, W3_E_HIP, W3_E_UNSUPPORTED, W3_E_NOMEM, W3_E_FORMAT = 0, -1, -2, -3, -4, -5, -6
-W3_OPT_PATH, W3_OPT_TIMING, W3_OPT_CODER, W3_OPT_ACC_LIMIT, W3_OPT_DEBUG_STAMPS, W3_OPT_PARTS, W3_OPT_VARIANT, W3_OPT_SLOT_BUDGET_MB, W3_OPT_VERIFY = 1, 2, 3, 4, 5, 6, 7, 8, 9
+W3_OPT_PATH, W3_OPT_TIMING, W3_OPT_CODER, W3_OPT_ACC_LIMIT, W3_OPT_DEBUG_STAMPS, W3_OPT_VARIANT, W3_OPT_SLOT_BUDGET_MB, W3_OPT_VERIFY, W3_OPT_FAULT_BLOCK, W3_OPT_TUNE = 1, 2, 3, 4, 5, 7, 8, 9, 10, 11
 W3_VAR_NO_LDS_ATOMICS, W3_VAR_PARTITION4, W3_VAR_NO_CHAINED_PARTITION, W3_VAR_CM_UNSTAGED, W3_VAR_NO_SIDE_STREAM, W3_VAR_INJECT_LDS_FAULT = 1, 2, 4, 8, 16, 32
+W3_VAR_HALF_CU, W3_VAR_FULL_CU = 64, 128
 W3_PATH_AUTO, W3_PATH_GENERIC, W3_PATH_TWOPHASE = 0, 1, 2
 
 
@@ -36,13 +37,14 @@ class Timing(C.Structure):
                 ("total_ms", C.c_float), ("path", C.c_uint32), ("n_coder_launches", C.c_uint32),
                 ("coder_bytes", C.c_uint64), ("predict_bytes", C.c_uint64), ("n_recoded_blocks", C.c_uint32), ("apm_ms", C.c_float),
                 ("slot_ms", C.c_float), ("n_slot_launches", C.c_uint32), ("achash_ms", C.c_float), ("n_parts", C.c_uint32),
-                ("n_lds_faults", C.c_uint32)]
+                ("n_lds_faults", C.c_uint32), ("n_wide", C.c_uint32), ("part_ms", C.c_float * 4), ("rank_ms", C.c_float * 4),
+                ("small_ms", C.c_float)]
 
 
 EXPORTS = [
     "w3_abi_version", "w3_strerror", "w3_last_error", "w3_ctx_create", "w3_ctx_destroy", "w3_spec_validate",
     "w3_ctx_set_option", "w3_max_compressed_size", "w3_encode_blocks", "w3_decode_blocks", "w3_encode_blocks_device",
-    "w3_decode_blocks_device", "w3_compress_stream", "w3_decompress_stream", "w3_predict_blocks", "w3_stationary_table",
+    "w3_decode_blocks_device", "w3_encode_submit", "w3_encode_wait", "w3_compress_stream", "w3_decompress_stream", "w3_predict_blocks", "w3_stationary_table",
     "w3_get_timing", "w3_selftest_counter_p", "w3_debug_get_stamps", "w3_state_table", "w3_stretch_squash", "w3_huff_tables",
     "w3_shard_range", "w3_encode_blocks_sharded", "w3_encode_stats", "w3_encode_stats_device", "w3_sweep_ordern", "w3_sweep_ordern_device", "w3_export_counters",
 ]
@@ -83,6 +85,8 @@ def load():
     lib.w3_decode_blocks.argtypes = [vp, C.POINTER(ModelSpec), vp, sz, vp, sz, sz, C.c_uint64, vp]
     lib.w3_encode_blocks_device.argtypes = [vp, C.POINTER(ModelSpec), vp, sz, sz, vp, sz, vp, vp, vp]
     lib.w3_decode_blocks_device.argtypes = [vp, C.POINTER(ModelSpec), vp, sz, vp, sz, sz, C.c_uint64, vp, vp]
+    lib.w3_encode_submit.argtypes = [vp, C.POINTER(ModelSpec), vp, sz, sz, vp, sz, vp, vp, vp, C.POINTER(C.c_int)]
+    lib.w3_encode_wait.argtypes = [vp, C.c_int]
     lib.w3_compress_stream.argtypes = [vp, C.POINTER(ModelSpec), vp, sz, vp, sz, C.POINTER(sz)]
     lib.w3_decompress_stream.argtypes = [vp, C.POINTER(ModelSpec), vp, sz, vp, sz, C.POINTER(sz)]
     lib.w3_predict_blocks.argtypes = [vp, C.POINTER(ModelSpec), vp, sz, sz, vp]

@@ -44,20 +44,18 @@ class Context:
         self._chk(self.lib.w3_ctx_set_option(self.h, L.W3_OPT_PATH, {"auto": 0, "generic": 1, "twophase": 2}[path]))
 
     def set_coder(self, mode):
-        self._chk(self.lib.w3_ctx_set_option(self.h, L.W3_OPT_CODER, {"x4": 0, "fast": 1, "robust": 2, "x2": 3, "x3": 4}[mode]))
+        self._chk(self.lib.w3_ctx_set_option(self.h, L.W3_OPT_CODER, {"x4": 0, "fast": 1, "robust": 2, "x2": 3, "x3": 4, "x5": 5}[mode]))
 
     def set_acc_limit(self, bits):
         self._chk(self.lib.w3_ctx_set_option(self.h, L.W3_OPT_ACC_LIMIT, bits))
 
-    def set_parts(self, parts=0):
-        """Block ranges a two-phase encode is pipelined in on separate streams (0 = auto, 1 = one range)."""
-        self._chk(self.lib.w3_ctx_set_option(self.h, L.W3_OPT_PARTS, int(parts)))
-
     def set_variant(self, *names):
         """Cross-check hook (W3_OPT_VARIANT): alternative bit-exact implementations, by name: no_lds_atomics, partition4,
-        no_chained_partition, cm_unstaged, no_side_stream.  No names = defaults."""
+        no_chained_partition, cm_unstaged, no_side_stream, half_cu (synchronous calls in the pipeline's kernel shapes), full_cu
+        (submitted calls in the plain shapes).  No names = defaults."""
         bits = {"no_lds_atomics": L.W3_VAR_NO_LDS_ATOMICS, "partition4": L.W3_VAR_PARTITION4, "no_chained_partition": L.W3_VAR_NO_CHAINED_PARTITION,
-                "cm_unstaged": L.W3_VAR_CM_UNSTAGED, "no_side_stream": L.W3_VAR_NO_SIDE_STREAM, "inject_lds_fault": L.W3_VAR_INJECT_LDS_FAULT}
+                "cm_unstaged": L.W3_VAR_CM_UNSTAGED, "no_side_stream": L.W3_VAR_NO_SIDE_STREAM, "inject_lds_fault": L.W3_VAR_INJECT_LDS_FAULT,
+                "half_cu": L.W3_VAR_HALF_CU, "full_cu": L.W3_VAR_FULL_CU}
         v = 0
         for nm in names:
             v |= bits[nm]
@@ -66,6 +64,14 @@ class Context:
     def set_verify(self, on=True):
         """W3_OPT_VERIFY: sampled ballot-round re-prediction after every predict phase that used LDS-add rounds (default on)."""
         self._chk(self.lib.w3_ctx_set_option(self.h, L.W3_OPT_VERIFY, int(on)))
+
+    def set_tune(self, bits=0):
+        """W3_OPT_TUNE: scheduling experiments of the submit / wait pipeline (set before the first encode_submit)."""
+        self._chk(self.lib.w3_ctx_set_option(self.h, L.W3_OPT_TUNE, int(bits)))
+
+    def set_fault_block(self, block=-1):
+        """Test hook (with set_variant("inject_lds_fault")): the one block the injected fault hits; -1 = every block."""
+        self._chk(self.lib.w3_ctx_set_option(self.h, L.W3_OPT_FAULT_BLOCK, int(block)))
 
     def set_slot_budget_mb(self, mb=0):
         self._chk(self.lib.w3_ctx_set_option(self.h, L.W3_OPT_SLOT_BUDGET_MB, int(mb)))
@@ -76,7 +82,7 @@ class Context:
     def timing(self):
         t = L.Timing()
         self._chk(self.lib.w3_get_timing(self.h, C.byref(t)))
-        return {k: getattr(t, k) for k, _ in L.Timing._fields_}
+        return {k: (list(getattr(t, k)) if k in ("part_ms", "rank_ms") else getattr(t, k)) for k, _ in L.Timing._fields_}
 
     # ---- host buffers ----------------------------------------------------
     def encode_blocks(self, model, data, block_size, out_cap=None):
@@ -192,6 +198,22 @@ class Context:
                                               C.c_void_p(d_out.data_ptr()), d_out.numel(), C.c_void_p(d_lens.data_ptr()),
                                               C.c_void_p(d_total.data_ptr()), st)
         self._chk(rc)
+
+    def encode_submit(self, model, d_in, block_size, d_out, d_lens, d_total, stream=None):
+        """w3_encode_submit: enqueue the encode and return a job handle at once (at most two jobs in flight; the next call's predict
+        phase runs beside this call's APM and coder kernels).  Keep every tensor alive and untouched until encode_wait(job)."""
+        spec = model.spec() if isinstance(model, Model) else model
+        st = C.c_void_p(stream) if stream else None
+        job = C.c_int(-1)
+        rc = self.lib.w3_encode_submit(self.h, C.byref(spec), C.c_void_p(d_in.data_ptr()), d_in.numel(), block_size,
+                                       C.c_void_p(d_out.data_ptr()), d_out.numel(), C.c_void_p(d_lens.data_ptr()),
+                                       C.c_void_p(d_total.data_ptr()), st, C.byref(job))
+        self._chk(rc)
+        return job.value
+
+    def encode_wait(self, job):
+        """w3_encode_wait: block until the job's output is complete (raises what the synchronous call would have raised)."""
+        self._chk(self.lib.w3_encode_wait(self.h, int(job)))
 
     def decode_blocks_device(self, model, d_comp, d_lens, block_size, orig_len, d_out, stream=None):
         spec = model.spec() if isinstance(model, Model) else model

@@ -85,22 +85,22 @@ namespace w3 {
 // Every spin is bounded and checks the abort word, so the wave always reaches the end of the kernel.
 #define W3_X4_SPIN(LBL, OFFS, NEED, SEEN)                          \
     "s_mov_b32 s44, 0\n"                                           \
-    LBL "_loop%=:\n"                                               \
+    LBL "_loop_%=:\n"                                               \
     "ds_read_b32 v108, %[sync] offset:" W3S(OFFS) "\n"             \
     "ds_read_b32 v109, %[sync] offset:" W3S(W3_X4_SYNC_ABORT) "\n" \
     "s_waitcnt lgkmcnt(0)\n"                                       \
     "v_readfirstlane_b32 " SEEN ", v108\n"                         \
     "v_readfirstlane_b32 s45, v109\n"                              \
     "s_cmp_lg_u32 s45, 0\n"                                        \
-    "s_cbranch_scc1 Ldead%=\n"                                     \
+    "s_cbranch_scc1 Ldead_%=\n"                                     \
     "s_cmp_ge_u32 " SEEN ", " NEED "\n"                            \
-    "s_cbranch_scc1 " LBL "_done%=\n"                              \
+    "s_cbranch_scc1 " LBL "_done_%=\n"                              \
     "s_sleep 1\n"                                                  \
     "s_add_u32 s44, s44, 1\n"                                      \
     "s_cmp_lt_u32 s44, 0x1000000\n"                                \
-    "s_cbranch_scc1 " LBL "_loop%=\n"                              \
-    "s_branch Ldead%=\n"                                           \
-    LBL "_done%=:\n"
+    "s_cbranch_scc1 " LBL "_loop_%=\n"                              \
+    "s_branch Ldead_%=\n"                                           \
+    LBL "_done_%=:\n"
 // operand address of the chunk in ring slot SREG (0 .. NCH-1): v106 = ops_lane + SREG * CH * 8192
 #define W3_X4_OPADDR(SREG)                                         \
     "s_lshl_b32 s40, " SREG ", 15\n"                               \
@@ -118,16 +118,16 @@ namespace w3 {
     "v_mov_b32 v110, %[x1]\n"                                                                        \
     "s_add_u32 s41, %[i], " W3S(W3_X4_CH) "\n"                                                       \
     "s_cmp_ge_u32 %[sm], s41\n"                                                                      \
-    "s_cbranch_scc1 Lm0_done%=\n"                                                                    \
+    "s_cbranch_scc1 Lm0_done_%=\n"                                                                    \
     W3_X4_SPIN("Lm0", W3_X4_SYNC_M, "s41", "%[sm]")                                                  \
     W3_X4_OPADDR("%[slot]")                                                                          \
     W3_X4_RD(32, 0)                                                                                  \
-    "Ltop%=:\n"                                                                                      \
+    "Ltop_%=:\n"                                                                                      \
     /* the token slots of this chunk must have been consumed: o_cons + RING >= i + CH */             \
     "s_add_u32 s41, %[i], " W3S(W3_X4_CH) "\n"                                                       \
     "s_add_u32 s42, %[so], " W3S(W3_X4_RING) "\n"                                                    \
     "s_cmp_ge_u32 s42, s41\n"                                                                        \
-    "s_cbranch_scc1 Lo_done%=\n"                                                                     \
+    "s_cbranch_scc1 Lo_done_%=\n"                                                                     \
     "s_sub_u32 s43, s41, " W3S(W3_X4_RING) "\n"                                                      \
     W3_X4_SPIN("Lo", W3_X4_SYNC_O, "s43", "%[so]")                                                   \
     "s_lshl_b32 s40, %[slot], 14\n"                                                                  \
@@ -144,11 +144,11 @@ namespace w3 {
     "v_readfirstlane_b32 %[so], v109\n"                                                              \
     "s_add_u32 s46, %[i], " W3S(W3_X4_CH) "\n"                                                       \
     "s_cmp_ge_u32 s46, %[iend]\n"                                                                    \
-    "s_cbranch_scc1 Llast%=\n"                                                                       \
+    "s_cbranch_scc1 Llast_%=\n"                                                                       \
     /* another chunk follows: request its first byte's operands before this chunk's last byte is coded */ \
     "s_add_u32 s41, s46, " W3S(W3_X4_CH) "\n"                                                        \
     "s_cmp_ge_u32 %[sm], s41\n"                                                                      \
-    "s_cbranch_scc1 Lm1_done%=\n"                                                                    \
+    "s_cbranch_scc1 Lm1_done_%=\n"                                                                    \
     W3_X4_SPIN("Lm1", W3_X4_SYNC_M, "s41", "%[sm]")                                                  \
     W3_X4_OPADDR("s47")                                                                              \
     W3_X4_RD(32, 0)                                                                                  \
@@ -157,17 +157,17 @@ namespace w3 {
     "ds_write_b32 %[sync], v108 offset:" W3S(W3_X4_SYNC_X) "\n"                                      \
     "s_mov_b32 %[i], s46\n"                                                                          \
     "s_mov_b32 %[slot], s47\n"                                                                       \
-    "s_branch Ltop%=\n"                                                                              \
-    "Llast%=:\n"                                                                                     \
+    "s_branch Ltop_%=\n"                                                                              \
+    "Llast_%=:\n"                                                                                     \
     W3_X4_BYTE(64, 3)                                                                                \
     "s_mov_b32 %[i], s46\n"                                                                          \
     "s_mov_b32 %[slot], s47\n"                                                                       \
-    "s_branch Lexit%=\n"                                                                             \
-    "Ldead%=:\n"                                                                                     \
+    "s_branch Lexit_%=\n"                                                                             \
+    "Ldead_%=:\n"                                                                                     \
     "v_mov_b32 v108, 1\n"                                                                            \
     "ds_write_b32 %[sync], v108 offset:" W3S(W3_X4_SYNC_ABORT) "\n"                                  \
     "s_mov_b32 %[st], 1\n"                                                                           \
-    "Lexit%=:\n"                                                                                     \
+    "Lexit_%=:\n"                                                                                     \
     "s_waitcnt lgkmcnt(0)\n"                                                                         \
     "v_mov_b32 %[x1], v110\n"
 // ---------------------------------------------------------------------------------------------------------------------
@@ -200,7 +200,7 @@ namespace w3 {
     "v_cmp_lt_u32 vcc, 31, v79\n"                                                                            \
     "v_cmp_lt_u32 s[52:53], %[fill], v78\n"                                                                  \
     "s_or_b64 vcc, vcc, s[52:53]\n"                                                                          \
-    "s_cbranch_vccnz Lbail" W3S(K) "%=\n"                                                                    \
+    "s_cbranch_vccnz Lbail" W3S(K) "_%=\n"                                                                    \
     W3_O4_XT(T, 0, "v64") W3_O4_XT(T, 1, "v65") W3_O4_XT(T, 2, "v66") W3_O4_XT(T, 3, "v67")                  \
     W3_O4_XT(T, 4, "v68") W3_O4_XT(T, 5, "v69") W3_O4_XT(T, 6, "v70") W3_O4_XT(T, 7, "v71")                  \
     W3_O4_U(T, 0, "v64", "v72") W3_O4_U(T, 1, "v65", "v80") W3_O4_U(T, 2, "v66", "v72") W3_O4_U(T, 3, "v67", "v80") \
@@ -221,7 +221,7 @@ namespace w3 {
     "v_add_u32 v80, 33, v80\n"                                                                               \
     "v_cmp_ge_u32 vcc, v86, v80\n"                                                                           \
     "s_and_saveexec_b64 s[54:55], vcc\n"                                                                     \
-    "s_cbranch_execz Lnf" W3S(K) "%=\n"                                                                      \
+    "s_cbranch_execz Lnf" W3S(K) "_%=\n"                                                                      \
     "v_subrev_u32 v86, 32, v86\n"                                                                            \
     "v_lshrrev_b64 v[80:81], v86, v[84:85]\n"                                                                \
     "v_perm_b32 v80, 0, v80, %[bsw]\n"                                                                       \
@@ -232,16 +232,16 @@ namespace w3 {
     "global_store_dword v83, v80, %[base]\n"                                                                 \
     "s_mov_b64 exec, s[56:57]\n"                                                                             \
     "v_mov_b32 v87, v82\n"                                                                                   \
-    "Lnf" W3S(K) "%=:\n"                                                                                     \
+    "Lnf" W3S(K) "_%=:\n"                                                                                     \
     "s_or_b64 exec, exec, s[54:55]\n"
 // Absorbs the chunks [i, iend); st = 0 done, 1 = pipeline abort, 2 = byte %[k] of chunk %[i] must take the C path.
 #define W3_O4_LOOP                                                                                   \
     "v_mov_b32 v84, %[alo]\n v_mov_b32 v85, %[ahi]\n v_mov_b32 v86, %[nb]\n v_mov_b32 v87, %[pos]\n"  \
     "v_mov_b32 v88, %[xr]\n v_mov_b32 v77, 0\n"                                                      \
-    "Ltop%=:\n"                                                                                      \
+    "Ltop_%=:\n"                                                                                      \
     "s_add_u32 s41, %[i], " W3S(W3_X4_CH) "\n"                                                       \
     "s_cmp_ge_u32 %[sx], s41\n"                                                                      \
-    "s_cbranch_scc1 Lx_done%=\n"                                                                     \
+    "s_cbranch_scc1 Lx_done_%=\n"                                                                     \
     W3_X4_SPIN("Lx", W3_X4_SYNC_X, "s41", "%[sx]")                                                   \
     "s_lshl_b32 s40, %[slot], 14\n"                                                                  \
     "v_add_u32 v96, s40, %[tkl]\n"                                                                   \
@@ -255,20 +255,20 @@ namespace w3 {
     "s_mov_b32 %[i], s41\n"                                                                          \
     "s_mov_b32 %[slot], s47\n"                                                                       \
     "s_cmp_lt_u32 %[i], %[iend]\n"                                                                   \
-    "s_cbranch_scc1 Ltop%=\n"                                                                        \
-    "s_branch Lexit%=\n"                                                                             \
-    "Lbail0%=:\n s_mov_b32 %[k], 0\n s_branch Lbail%=\n"                                             \
-    "Lbail1%=:\n s_mov_b32 %[k], 1\n s_branch Lbail%=\n"                                             \
-    "Lbail2%=:\n s_mov_b32 %[k], 2\n s_branch Lbail%=\n"                                             \
-    "Lbail3%=:\n s_mov_b32 %[k], 3\n"                                                                \
-    "Lbail%=:\n"                                                                                     \
+    "s_cbranch_scc1 Ltop_%=\n"                                                                        \
+    "s_branch Lexit_%=\n"                                                                             \
+    "Lbail0_%=:\n s_mov_b32 %[k], 0\n s_branch Lbail_%=\n"                                             \
+    "Lbail1_%=:\n s_mov_b32 %[k], 1\n s_branch Lbail_%=\n"                                             \
+    "Lbail2_%=:\n s_mov_b32 %[k], 2\n s_branch Lbail_%=\n"                                             \
+    "Lbail3_%=:\n s_mov_b32 %[k], 3\n"                                                                \
+    "Lbail_%=:\n"                                                                                     \
     "s_mov_b32 %[st], 2\n"                                                                           \
-    "s_branch Lexit%=\n"                                                                             \
-    "Ldead%=:\n"                                                                                     \
+    "s_branch Lexit_%=\n"                                                                             \
+    "Ldead_%=:\n"                                                                                     \
     "v_mov_b32 v108, 1\n"                                                                            \
     "ds_write_b32 %[sync], v108 offset:" W3S(W3_X4_SYNC_ABORT) "\n"                                  \
     "s_mov_b32 %[st], 1\n"                                                                           \
-    "Lexit%=:\n"                                                                                     \
+    "Lexit_%=:\n"                                                                                     \
     "s_waitcnt lgkmcnt(0)\n"                                                                         \
     "v_mov_b32 %[alo], v84\n v_mov_b32 %[ahi], v85\n v_mov_b32 %[nb], v86\n v_mov_b32 %[pos], v87\n v_mov_b32 %[xr], v88\n"
 #define W3_O4_CLOBBERS                                                                                                     \

@@ -36,6 +36,18 @@ namespace w3 {
 
 #define W3_PF 8   // rounds whose loads are in flight together (one batch)
 
+// "Half-CU" form of the predict kernels (template parameter NW > 1): NW independent wavefronts share ONE workgroup whose
+// static LDS is padded to W3_HALF_CU_LDS = 80 KiB, half of a CU's 160 KiB: one such workgroup and ONE workgroup of the previous
+// call's APM stage (k_apm0: 79,968 B) or coder (k_coder_x5: 74,272 B) share a CU without fragmenting its LDS (DESIGN.md section
+// 2.8).  Measured (profiles/r3_pipeline/): a workgroup of MORE than 80 KiB (82,000 B was tried first) is never placed beside
+// another large one — it waits for an empty CU — so nothing here exceeds the half.  The wavefronts of a workgroup never
+// synchronise with each other (wave barriers only).  NW == 1 is the plain one-wavefront workgroup.
+#define W3_HALF_CU_LDS 81920u
+template <int NW, size_t USED> struct HalfCuPad { static constexpr size_t words = (NW > 1 && USED < W3_HALF_CU_LDS) ? (W3_HALF_CU_LDS - USED + 3u) / 4u : 1u; };
+#define W3_HALF_CU_PAD(NW, USED)                                                              \
+    __shared__ uint32_t pad_[HalfCuPad<NW, (USED)>::words];                                   \
+    if constexpr ((NW) > 1) { if (a.n == ~0ull) pad_[threadIdx.x] = 1u; }   /* never true: keeps the padding allocated */
+
 struct PredictArgs {
     const uint8_t *in;      // original bytes (device)
     uint64_t n;
@@ -54,6 +66,7 @@ struct PredictArgs {
     uint32_t dbg_flags;      // bit0 = skip the stream stores (timing experiments only); bit1 = ballot rounds only (no LDS atomics);
                              // bit3 = FAULT INJECTION for the tests of the sampled verification: one returning add of every block hands two lanes each other's value
     unsigned long long *dbg; // optional: per-phase s_memtime sums (diagnostic builds/runs only; never read by kernels)
+    uint32_t fault_block;    // dbg_flags bit3: the one block the injected fault hits, or 0xFFFFFFFF = every block
 };
 
 #define W3_STAMP(slot)                                                                         \
@@ -285,14 +298,18 @@ __device__ __forceinline__ uint32_t load_window(const uint8_t *blk, uint32_t i, 
 // ---------------------------------------------------------------------------
 // H <= 8, time order.  KEYS: key bytes come from args.keys (ACHistory leaves).
 // ---------------------------------------------------------------------------
-template <int H, bool KEYS>
-__global__ void __launch_bounds__(64) k_predict_small(PredictArgs a) {
-    __shared__ uint32_t tbl[8 * 256];
-    __shared__ uint32_t st_w[W3_PF * 64];                 // operand staging (one batch of rounds)
-    __shared__ uint2 st_k[KEYS ? W3_PF * 64 : 1];
-    const int lane = threadIdx.x;
+template <int H, bool KEYS, int NW = 1>
+__global__ void __launch_bounds__(64 * NW) k_predict_small(PredictArgs a) {
+    __shared__ uint32_t tbl_[NW][8 * 256];
+    __shared__ uint32_t st_w_[NW][W3_PF * 64];                 // operand staging (one batch of rounds)
+    __shared__ uint2 st_k_[NW][KEYS ? W3_PF * 64 : 1];
+    W3_HALF_CU_PAD(NW, sizeof(tbl_) + sizeof(st_w_) + sizeof(st_k_))
+    const int lane = threadIdx.x & 63;
+    const uint32_t wv = threadIdx.x >> 6;
+    uint32_t *tbl = tbl_[wv], *st_w = st_w_[wv];
+    uint2 *st_k = st_k_[wv];
     constexpr uint32_t KM = (1u << H) - 1u;
-    for (uint32_t b = blockIdx.x; b < a.nblocks; b += gridDim.x) {
+    for (uint32_t b = blockIdx.x * NW + wv; b < a.nblocks; b += gridDim.x * NW) {
         const uint64_t off = (uint64_t)b * a.block_size;
         const uint32_t len = (uint32_t)((a.n - off) < a.block_size ? (a.n - off) : a.block_size);
         const uint8_t *blk = a.in + off;
@@ -349,7 +366,7 @@ __global__ void __launch_bounds__(64) k_predict_small(PredictArgs a) {
                 __asm__ volatile("" ::: "memory");
                 atomic_round(tbl, c0, key, valid, v);
                 __asm__ volatile("" ::: "memory");
-                if ((a.dbg_flags & 8u) && base == 64u) v[0] = (uint32_t)__shfl_xor((int)v[0], 1, 64);   // (test hook: a mis-ordered add)
+                if ((a.dbg_flags & 8u) && base == 64u && (a.fault_block == 0xFFFFFFFFu || a.fault_block == b)) v[0] = (uint32_t)__shfl_xor((int)v[0], 1, 64);   // (test hook: a mis-ordered add)
 #pragma unroll
                 for (int j = 0; j < 8; j++) p[j] = counter_p_packed(v[j]);
                 exact = atomic_round_hot(v);
@@ -584,13 +601,17 @@ __device__ __forceinline__ void wave_excl_scan_256(uint32_t *cnt, uint32_t *excl
     if (excl2) { excl2[4 * lane] = base; excl2[4 * lane + 1] = base + c0; excl2[4 * lane + 2] = base + c0 + c1; excl2[4 * lane + 3] = base + c0 + c1 + c2; }
 }
 
-template <int MODE>
-__global__ void __launch_bounds__(64) k_partition8(PredictArgs a) {
-    __shared__ uint2 tile[W3_P8_TILE];
-    __shared__ uint32_t gcur[256], tcnt[256], tstart[256], tcur[256];
-    const int lane = threadIdx.x;
+template <int MODE, int NW = 1>
+__global__ void __launch_bounds__(64 * NW) k_partition8(PredictArgs a) {
+    __shared__ uint2 tile_[NW][W3_P8_TILE];
+    __shared__ uint32_t cnt_[NW][4][256];   // gcur, tcnt, tstart, tcur
+    W3_HALF_CU_PAD(NW, sizeof(tile_) + sizeof(cnt_))
+    const int lane = threadIdx.x & 63;
+    const uint32_t wv = threadIdx.x >> 6;
+    uint2 *tile = tile_[wv];
+    uint32_t *gcur = cnt_[wv][0], *tcnt = cnt_[wv][1], *tstart = cnt_[wv][2], *tcur = cnt_[wv][3];
     constexpr uint32_t KSH = MODE == 1 ? 8u : 16u;   // digit = window byte c1 / c2
-    for (uint32_t b = blockIdx.x; b < a.nblocks; b += gridDim.x) {
+    for (uint32_t b = blockIdx.x * NW + wv; b < a.nblocks; b += gridDim.x * NW) {
         const uint64_t off = (uint64_t)b * a.block_size;
         const uint32_t len = (uint32_t)((a.n - off) < a.block_size ? (a.n - off) : a.block_size);
         const uint8_t *blk = a.in + off;
@@ -767,11 +788,14 @@ __global__ void __launch_bounds__(64) k_partition8(PredictArgs a) {
 // P regions (1 MiB each) then stay in the 256 MiB Infinity Cache, where the eight partial 16-byte
 // writes every 128-byte line receives merge (3.2x cheaper than with 4096 blocks live; see
 // profiles/r1_ubench_partial_line_merge_vs_footprint.txt).
-template <int NBYTES>
-__global__ void __launch_bounds__(64) k_rank_sorted(PredictArgs a) {
-    __shared__ uint32_t tbl[8 * 256];
-    __shared__ uint2 st_r[W3_PF * 64];   // record staging (one batch of rounds)
-    const int lane = threadIdx.x;
+template <int NBYTES, int NW = 1>
+__global__ void __launch_bounds__(64 * NW) k_rank_sorted(PredictArgs a) {
+    __shared__ uint32_t tbl_[NW][8 * 256];
+    __shared__ uint2 st_r_[NW][W3_PF * 64];   // record staging (one batch of rounds)
+    W3_HALF_CU_PAD(NW, sizeof(tbl_) + sizeof(st_r_))
+    const int lane = threadIdx.x & 63;
+    uint32_t *tbl = tbl_[threadIdx.x >> 6];
+    uint2 *st_r = st_r_[threadIdx.x >> 6];
     const uint32_t njobs = a.nblocks * W3_SLICES;
     // jobs are handed out in block-major order from one counter: slices are very uneven (a block's biggest
     // group is one slice), and in-order hand-out keeps the set of blocks being scattered into small.
@@ -918,8 +942,29 @@ __global__ void __launch_bounds__(64) k_rank_sorted(PredictArgs a) {
 // HuffHistory keys (history/huff_history.rs:58-76): one thread per byte position computes the 8 context hashes of its
 // bit positions.  compressed_bits before byte i is the concatenation of the codes of the bytes before it (newest lowest),
 // cut to 32 bits: walk back until 32 bits are covered (a handful of bytes: codes average 4-6 bits).
+// The walk is BOUNDED (W3_HUFF_WALK bytes): a symbol absent from the training buffer has code length 0 (legal through
+// HuffHistory::from_tables / w3_huff_table) and does not advance the covered bits, so a long run of such bytes would make
+// every thread walk back to the run's start — O(block_size) per thread.  A position whose walk ends uncovered flags its
+// block, and k_huffkeys_fix recomputes that block's keys with the reference's own O(1)-per-byte recurrence
+// (compressed_bits = compressed_bits << len | code, :60-66), one lane per flagged block.
 // ---------------------------------------------------------------------------
-struct HuffKeyArgs { const uint8_t *in; uint64_t n; uint32_t block_size; uint32_t hmask; const w3_huff_table *tb; uint2 *keys; };
+#define W3_HUFF_WALK 40u   // 32 bits are covered after at most 32 bytes of non-empty codes
+struct HuffKeyArgs { const uint8_t *in; uint64_t n; uint32_t block_size; uint32_t hmask; const w3_huff_table *tb; uint2 *keys;
+                     uint32_t *redo;   /* [nblocks] zeroed before k_huffkeys: != 0 -> k_huffkeys_fix recomputes the block */
+                     uint32_t nblocks; };
+
+// the 8 keys of byte c0 at position i of its block, given compressed_bits before it
+__device__ __forceinline__ uint2 huff_keys_of(uint32_t cb, uint32_t c0, uint32_t i, uint32_t hmask, const uint16_t *rcode, const uint8_t *rlen) {
+    uint32_t out[2] = {0u, 0u};
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        if (i == 0u && j == 0) continue;                                  // ctx starts at 0 (ordern_entropy.rs:19)
+        const uint32_t rem = (1u << j) | (c0 >> (8 - j));                 // partial byte with a leading 1 (:71-73)
+        const uint32_t h = (cb << rlen[rem]) | rcode[rem];                // :74-75
+        out[j >> 2] |= (h & hmask & 0xFFu) << (8 * (j & 3));
+    }
+    return make_uint2(out[0], out[1]);
+}
 
 __global__ void __launch_bounds__(256) k_huffkeys(HuffKeyArgs a) {
     __shared__ uint16_t s_code[256], s_rcode[256];
@@ -932,37 +977,45 @@ __global__ void __launch_bounds__(256) k_huffkeys(HuffKeyArgs a) {
     const uint64_t b = g / a.block_size;
     const uint32_t i = (uint32_t)(g - b * a.block_size);
     const uint8_t *blk = a.in + b * a.block_size;
-    uint32_t cb = 0u, have = 0u;
-    for (uint32_t k = 1; k <= i && have < 32u; k++) {
+    uint32_t cb = 0u, have = 0u, k = 1;
+    for (; k <= i && have < 32u && k <= W3_HUFF_WALK; k++) {
         const uint32_t byte = blk[i - k];
         cb |= (uint32_t)s_code[byte] << have;
         have += s_len[byte];
     }
-    const uint32_t c0 = blk[i];
-    uint32_t out[2] = {0u, 0u};
-#pragma unroll
-    for (int j = 0; j < 8; j++) {
-        if (i == 0u && j == 0) continue;                                  // ctx starts at 0 (ordern_entropy.rs:19)
-        const uint32_t rem = (1u << j) | (c0 >> (8 - j));                 // partial byte with a leading 1 (:71-73)
-        const uint32_t h = (cb << s_rlen[rem]) | s_rcode[rem];            // :74-75
-        out[j >> 2] |= (h & a.hmask & 0xFFu) << (8 * (j & 3));
+    if (have < 32u && k <= i) a.redo[b] = 1u;   // uncovered with bytes left: a run of zero-length codes (benign race: every writer stores 1)
+    a.keys[g] = huff_keys_of(cb, blk[i], i, a.hmask, s_rcode, s_rlen);
+}
+
+// one lane per block; only flagged blocks do anything (65,536 serial steps of a few instructions each)
+__global__ void __launch_bounds__(64) k_huffkeys_fix(HuffKeyArgs a) {
+    const uint32_t b = blockIdx.x * 64u + threadIdx.x;
+    if (b >= a.nblocks || a.redo[b] == 0u) return;
+    const uint64_t off = (uint64_t)b * a.block_size;
+    const uint32_t len = (uint32_t)((a.n - off) < a.block_size ? (a.n - off) : a.block_size);
+    uint32_t cb = 0u;
+    for (uint32_t i = 0; i < len; i++) {
+        const uint32_t c0 = a.in[off + i];
+        a.keys[off + i] = huff_keys_of(cb, c0, i, a.hmask, a.tb->rem_code, a.tb->rem_len);
+        const uint32_t l = a.tb->len[c0];
+        cb = (l < 32u ? cb << l : 0u) | a.tb->code[c0];
     }
-    a.keys[g] = make_uint2(out[0], out[1]);
 }
 
 // ---------------------------------------------------------------------------
 // Sampled verification of the LDS-add rounds (w3_twophase.h, twophase_verify): S blocks of the input are gathered into a
 // compact buffer, predicted a second time with the ballot rounds (exact by construction), and the streams compared.
-// Sampled block s = block s * nb_full / S (full-length blocks only).
+// Sampled block s = block s * nb_full / S + rot (full-length blocks only; rot < nb_full / S rotates the sample from call to call,
+// so that after nb_full / S calls every block has been in it once).
 // ---------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_gather_blocks(const uint8_t *in, uint32_t bs, uint32_t nb_full, uint32_t S, uint8_t *out) {
+__global__ void __launch_bounds__(256) k_gather_blocks(const uint8_t *in, uint32_t bs, uint32_t nb_full, uint32_t S, uint32_t rot, uint8_t *out) {
     const uint32_t s = blockIdx.y;
-    const uint64_t src = (uint64_t)((uint64_t)s * nb_full / S) * bs;
+    const uint64_t src = (uint64_t)((uint64_t)s * nb_full / S + rot) * bs;
     for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < bs; i += gridDim.x * 256u) out[(uint64_t)s * bs + i] = in[src + i];
 }
-__global__ void __launch_bounds__(256) k_compare_blocks(const uint4 *main_p, const uint4 *ver_p, uint32_t bs, uint32_t nb_full, uint32_t S, uint32_t *mismatch) {
+__global__ void __launch_bounds__(256) k_compare_blocks(const uint4 *main_p, const uint4 *ver_p, uint32_t bs, uint32_t nb_full, uint32_t S, uint32_t rot, uint32_t *mismatch) {
     const uint32_t s = blockIdx.y;
-    const uint64_t src = (uint64_t)((uint64_t)s * nb_full / S) * bs;
+    const uint64_t src = (uint64_t)((uint64_t)s * nb_full / S + rot) * bs;
     uint32_t bad = 0;
     for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < bs; i += gridDim.x * 256u) {
         const uint4 x = main_p[src + i], y = ver_p[(uint64_t)s * bs + i];

@@ -15,6 +15,7 @@
 #include "w3_apm.h"
 #include "w3_coder.h"
 #include "w3_coder4.h"
+#include "w3_coder5.h"
 #include "w3_predict.h"
 #include "w3_slot.h"
 #include "w3_spec.h"
@@ -32,7 +33,15 @@ static inline const char *w3_tune_env(const char *name) {
 
 // W3_OPT_VARIANT bits: alternative (bit-exact) implementations that the tests cross-check against the default ones
 enum { W3_VAR_NO_LDS_ATOMICS = 1, W3_VAR_PARTITION4 = 2, W3_VAR_NO_CHAINED_PARTITION = 4, W3_VAR_CM_UNSTAGED = 8, W3_VAR_NO_SIDE_STREAM = 16,
-       W3_VAR_INJECT_LDS_FAULT = 32 /* tests: corrupt one LDS-add round per block, the sampled verification must catch it */ };
+       W3_VAR_INJECT_LDS_FAULT = 32 /* tests: corrupt one LDS-add round per block, the sampled verification must catch it */,
+       W3_VAR_HALF_CU = 64    /* synchronous calls too run the half-CU kernel shapes of the submit / wait pipeline (w3_predict.h) */,
+       W3_VAR_FULL_CU = 128   /* w3_encode_submit keeps the plain kernel shapes (experiments: what the shapes are worth) */ };
+
+// event slots (pairs: ev[2 * slot], ev[2 * slot + 1]) of one encode
+enum { W3_EV_PREDICT = 0, W3_EV_CODER = 1, W3_EV_PACK = 2, W3_EV_TOTAL = 3, W3_EV_APM = 4, W3_EV_SLOT = 5, W3_EV_ACHASH = 6,
+       W3_EV_PART0 = 7 /* .. 10: partition pass of wide leaf w */, W3_EV_RANK0 = 11 /* .. 14: rank kernel of wide leaf w */, W3_EV_SMALL = 15,
+       W3_EV_SLOTS = 16 };
+#define W3_NEV (2 * W3_EV_SLOTS)
 
 struct TwoPhaseWs {
     void *P = nullptr, *keys = nullptr, *perm = nullptr, *redo = nullptr, *streams = nullptr, *rec = nullptr, *splits = nullptr;
@@ -42,7 +51,7 @@ struct TwoPhaseWs {
     void *dbg = nullptr;       // 8 x u64 phase stamps of the last wide predict kernel (W3_OPT_DEBUG_STAMPS)
     int debug_stamps = 0;
     bool achash_timed = false; // the last predict call recorded ev[12]/ev[13]
-    hipEvent_t ev_pred_done = nullptr;   // recorded by twophase_encode when the predict phase has been enqueued (range pipelining)
+    hipEvent_t ev_pred_done = nullptr;   // two-stream form of twophase_encode: the predict phase is through (the code stream waits for it)
     int lds_order = -1;        // k_lds_order_selftest: -1 not run yet, 1 = returning LDS adds are lane-ordered (atomic rounds allowed), 0 = not
     const int16_t *stretch = nullptr;   // APM LUTs (device; owned by the ctx)
     const uint16_t *squash = nullptr;
@@ -54,11 +63,18 @@ struct TwoPhaseWs {
     size_t rec_w_cap[4] = {0, 0, 0, 0}, perm_w_cap[4] = {0, 0, 0, 0}, splits_w_cap[4] = {0, 0, 0, 0};
     int wide1_slot = -1;                // rec_w / splits_w index of an Order1-shaped leaf of the last predict (records sorted by c1)
     hipStream_t side = nullptr;
-    // range pipelining: the APM and coder kernels go to a high-priority stream, so that their workgroups are placed ahead
-    // of the next range's predict kernels (which otherwise take every slot that frees up)
-    bool use_hi = false;
-    hipStream_t hi = nullptr;
-    hipEvent_t ev_hi_start = nullptr, ev_hi_done = nullptr;
+    // what the first half of the predict phase (twophase_predict_a: keys, partition passes, time-ordered leaves) leaves for the second
+    // (twophase_predict_b: rank kernels of the wide leaves, slot-state leaves, merge)
+    struct PredictState {
+        bool forked = false, lds_atomics = false;
+        int n_def = 0, n_small_def = 0, n_live = 0;
+        struct Deferred { w3::PredictArgs pa; int cls; uint32_t grid_rank; } deferred[4];
+        uint64_t bytes = 0, slot_stride = 0;
+        w3::SlotArgs sa;
+    } pst;
+    uint32_t tune = 0;         // W3_OPT_TUNE: scheduling experiments (bit 1: k_apm0 padded to one workgroup per CU in the half-CU shapes)
+    bool half_cu = false;      // half-CU kernel shapes (w3_predict.h W3_HALF_CU_LDS, k_coder_x5): the call shares every CU with another call's stage
+    int n_wide = 0; bool small_timed = false;   // what the last predict recorded events for (W3_EV_PART0.., W3_EV_RANK0.., W3_EV_SMALL)
     hipEvent_t ev_fork = nullptr, ev_join[4] = {nullptr, nullptr, nullptr, nullptr}, ev_small = nullptr;
     void *achash_lut = nullptr;         // k_achash_lut: [65536][8] coder states (8 MiB)
     size_t achash_lut_cap = 0;
@@ -66,10 +82,14 @@ struct TwoPhaseWs {
     size_t dummy_cap = 0;
     void *slot_tables = nullptr;        // per-lane HashMaps of the slot-state leaves
     size_t slot_tables_cap = 0;
-    int coder_mode = 0;        // 0 = k_coder_x4 (mix + asm recurrence + output waves), 1 = k_coder_fast, 2 = k_coder only, 3 = k_coder_x2, 4 = k_coder_x3
+    void *huff_redo = nullptr;          // k_huffkeys: per-block "recompute serially" flags
+    size_t huff_redo_cap = 0;
+    int coder_mode = 0;        // 0 = k_coder_x4 (mix + asm recurrence + output waves), 1 = k_coder_fast, 2 = k_coder only, 3 = k_coder_x2, 4 = k_coder_x3, 5 = k_coder_x5 (x4 with 72 KiB rings)
     uint32_t acc_limit = 46;   // test hook: lower values force the fast coder's fallback
     uint32_t variant = 0;      // W3_VAR_* (W3_OPT_VARIANT)
     uint32_t slot_budget_mb = 0;   // W3_OPT_SLOT_BUDGET_MB: cap on the slot leaves' hash-map batch (0 = from the free device memory)
+    uint32_t verify_calls = 0; // rotates the verification's sample
+    uint32_t fault_block = 0xFFFFFFFFu;   // W3_OPT_FAULT_BLOCK (with W3_VAR_INJECT_LDS_FAULT)
     int verify = 1;            // W3_OPT_VERIFY: sampled re-prediction with ballot rounds after every predict phase that used LDS-add rounds
     TwoPhaseWs *vws = nullptr; // workspace of that re-prediction (owned)
     void *vin = nullptr; size_t vin_cap = 0;   // the sampled blocks, gathered
@@ -99,16 +119,16 @@ struct TwoPhaseWs {
         if (ev_small) (void)hipEventDestroy(ev_small);
         ev_small = nullptr;
         side = nullptr; ev_fork = nullptr;
-        if (hi) (void)hipStreamDestroy(hi);
-        if (ev_hi_start) (void)hipEventDestroy(ev_hi_start);
-        if (ev_hi_done) (void)hipEventDestroy(ev_hi_done);
-        hi = nullptr; ev_hi_start = ev_hi_done = nullptr;
+        if (ev_pred_done) (void)hipEventDestroy(ev_pred_done);
+        ev_pred_done = nullptr;
         if (achash_lut) (void)hipFree(achash_lut);
         achash_lut = nullptr; achash_lut_cap = 0;
         if (dummy) (void)hipFree(dummy);
         dummy = nullptr; dummy_cap = 0;
         if (slot_tables) (void)hipFree(slot_tables);
         slot_tables = nullptr; slot_tables_cap = 0;
+        if (huff_redo) (void)hipFree(huff_redo);
+        huff_redo = nullptr; huff_redo_cap = 0;
         if (streams) (void)hipFree(streams);
         if (rec) (void)hipFree(rec);
         if (splits) (void)hipFree(splits);
@@ -154,19 +174,31 @@ static inline bool twophase_supported(const ParsedSpec &ps, size_t block_size, s
     return true;
 }
 
-template <bool KEYS>
+// waves per half-CU workgroup (NW * per-wave LDS <= W3_HALF_CU_LDS): k_predict_small 10,240 B, k_partition8 20,480 B, k_rank_sorted 12,288 B
+#define W3_NW_SMALL 8
+#define W3_NW_PART 4
+#define W3_NW_RANK 6
+#define W3_HALF_CU_GRID 256u   // one workgroup per CU
+
+template <bool KEYS, int NW = 1>
 static inline void launch_small(int H, dim3 grid, hipStream_t s, const w3::PredictArgs &pa) {
+    const dim3 blk(64 * NW);
     switch (H) {
-    case 0: hipLaunchKernelGGL((w3::k_predict_small<0, KEYS>), grid, dim3(64), 0, s, pa); break;
-    case 1: hipLaunchKernelGGL((w3::k_predict_small<1, KEYS>), grid, dim3(64), 0, s, pa); break;
-    case 2: hipLaunchKernelGGL((w3::k_predict_small<2, KEYS>), grid, dim3(64), 0, s, pa); break;
-    case 3: hipLaunchKernelGGL((w3::k_predict_small<3, KEYS>), grid, dim3(64), 0, s, pa); break;
-    case 4: hipLaunchKernelGGL((w3::k_predict_small<4, KEYS>), grid, dim3(64), 0, s, pa); break;
-    case 5: hipLaunchKernelGGL((w3::k_predict_small<5, KEYS>), grid, dim3(64), 0, s, pa); break;
-    case 6: hipLaunchKernelGGL((w3::k_predict_small<6, KEYS>), grid, dim3(64), 0, s, pa); break;
-    case 7: hipLaunchKernelGGL((w3::k_predict_small<7, KEYS>), grid, dim3(64), 0, s, pa); break;
-    default: hipLaunchKernelGGL((w3::k_predict_small<8, KEYS>), grid, dim3(64), 0, s, pa); break;
+    case 0: hipLaunchKernelGGL((w3::k_predict_small<0, KEYS, NW>), grid, blk, 0, s, pa); break;
+    case 1: hipLaunchKernelGGL((w3::k_predict_small<1, KEYS, NW>), grid, blk, 0, s, pa); break;
+    case 2: hipLaunchKernelGGL((w3::k_predict_small<2, KEYS, NW>), grid, blk, 0, s, pa); break;
+    case 3: hipLaunchKernelGGL((w3::k_predict_small<3, KEYS, NW>), grid, blk, 0, s, pa); break;
+    case 4: hipLaunchKernelGGL((w3::k_predict_small<4, KEYS, NW>), grid, blk, 0, s, pa); break;
+    case 5: hipLaunchKernelGGL((w3::k_predict_small<5, KEYS, NW>), grid, blk, 0, s, pa); break;
+    case 6: hipLaunchKernelGGL((w3::k_predict_small<6, KEYS, NW>), grid, blk, 0, s, pa); break;
+    case 7: hipLaunchKernelGGL((w3::k_predict_small<7, KEYS, NW>), grid, blk, 0, s, pa); break;
+    default: hipLaunchKernelGGL((w3::k_predict_small<8, KEYS, NW>), grid, blk, 0, s, pa); break;
     }
+}
+// time-ordered Counter leaf in the shape the workspace asks for
+static inline void launch_small_shaped(const TwoPhaseWs &ws, int H, uint32_t nb, hipStream_t s, const w3::PredictArgs &pa) {
+    if (ws.half_cu && (ws.tune & 32u)) launch_small<false, W3_NW_SMALL>(H, dim3(std::min<uint32_t>((nb + W3_NW_SMALL - 1) / W3_NW_SMALL, 2 * W3_HALF_CU_GRID)), s, pa);
+    else launch_small<false>(H, dim3(std::min<uint32_t>(nb, 256 * 20)), s, pa);
 }
 
 // Runs the predict kernels of every leaf; *d_P receives the merged stream.
@@ -211,15 +243,21 @@ static inline bool twophase_lds_order_ok(TwoPhaseWs &ws, hipStream_t s) {
 
 // need_P: also merge the leaves' streams into ws.P (k_mix).  The default coder (k_coder_x3) mixes on the fly
 // and needs no P for up to 4 live leaves.
-static inline int twophase_predict(TwoPhaseWs &ws, hipStream_t s, const ParsedSpec &ps, const uint8_t *d_in, size_t n, size_t block_size,
-                                   uint32_t nb, bool need_P, const uint16_t **d_P, hipEvent_t *ev, w3_timing *tm, std::string &err) {
+// The predict phase in two halves (the submit / wait pipeline puts the previous call's APM stage between them):
+//   a: context keys, partition passes of the wide leaves, time-ordered leaves — kernels that fill every CU's LDS
+//   b: rank kernels of the wide leaves (bound by their scattered stores: the coder of the previous call runs beside them),
+//      slot-state leaves, merge
+// join_all: s also waits for the side stream's kernels (the caller wants the whole first half behind one event)
+static inline int twophase_predict_a(TwoPhaseWs &ws, hipStream_t s, const ParsedSpec &ps, const uint8_t *d_in, size_t n, size_t block_size,
+                                     uint32_t nb, hipEvent_t *ev, std::string &err, bool join_all = false) {
     int rc = W3_OK;
     ws.P_valid = false;
     ws.achash_timed = false;
     const bool lds_atomics = twophase_lds_order_ok(ws, s);
     ws.used_lds_atomics = false;
-    const uint32_t grid_small = std::min<uint32_t>(nb, 256 * 20);
+    const uint32_t grid_small = std::min<uint32_t>(nb, 256 * 20);   // (KEYS leaves; the plain ones: launch_small_shaped)
     const uint32_t grid_wide = std::min<uint32_t>(nb, 256 * 16);
+    ws.n_wide = 0; ws.small_timed = false;
     bool need_keys = false, need_perm = false;
     for (int l = 0; l < ps.n_leaves; l++) {
         int c = leaf_class(ps.leaf[l]);
@@ -253,21 +291,22 @@ static inline int twophase_predict(TwoPhaseWs &ws, hipStream_t s, const ParsedSp
     if (n_live <= 1 && (rc = tp_ensure(ws.P, ws.P_cap, n * 16, err))) return rc;
 
     if ((rc = tp_ensure(ws.dummy, ws.dummy_cap, 2048, err))) return rc;
-    if (ev) (void)hipEventRecord(ev[0], s);
+    if (ev) (void)hipEventRecord(ev[2 * W3_EV_PREDICT], s);
     // fork: the partition passes of the wide leaves go to the side stream (they are bound by scattered line requests, the
     // time-ordered kernels by VALU issue); the rank kernels follow on the main stream after the join
-    const bool forked = need_perm && !(ws.variant & W3_VAR_NO_SIDE_STREAM);
+    const bool forked = need_perm && !(ws.variant & W3_VAR_NO_SIDE_STREAM) && !(ws.half_cu && (ws.tune & 32u));
     hipStream_t sp = forked ? ws.side : s;
     if (forked) { (void)hipEventRecord(ws.ev_fork, s); (void)hipStreamWaitEvent(ws.side, ws.ev_fork, 0); }
     ws.wide1_slot = -1;
-    struct Deferred { w3::PredictArgs pa; int cls; uint32_t grid_rank; } deferred[4];
+    TwoPhaseWs::PredictState &st = ws.pst;
+    auto &deferred = st.deferred;
     int n_def = 0;
     w3::PredictArgs small_def[8];   // time-ordered table leaves held back until the partition passes are queued
     int n_small_def = 0;
     uint64_t bytes = 0;
     w3::MixArgs &ma = ws.mix;
     memset(&ma, 0, sizeof ma);
-    w3::SlotArgs sa;
+    w3::SlotArgs &sa = st.sa;
     memset(&sa, 0, sizeof sa);
     uint64_t slot_stride = 0;
     bool achash_timed = false;
@@ -298,6 +337,7 @@ static inline int twophase_predict(TwoPhaseWs &ws, hipStream_t s, const ParsedSp
         if (const char *ev_ = w3_tune_env("W3_ATOMIC_MAXSEG")) pa.maxseg = (uint32_t)std::max(0, atoi(ev_));   // tuning hook
         if (!lds_atomics) pa.dbg_flags |= 2u;
         if (ws.variant & W3_VAR_INJECT_LDS_FAULT) pa.dbg_flags |= 8u;
+        pa.fault_block = ws.fault_block;
         bytes += n * 17;
         if (c == LEAF_SMALL_AC) {
             w3::HashArgs ha;
@@ -308,10 +348,10 @@ static inline int twophase_predict(TwoPhaseWs &ws, hipStream_t s, const ParsedSp
             if ((rc = tp_ensure(ws.achash_lut, ws.achash_lut_cap, (size_t)(8u << W3_ACHASH_LUT_BITS) * 18, err))) return rc;
             ha.lut = (uint4 *)ws.achash_lut;
             ha.lut_key = (uint16_t *)((uint8_t *)ws.achash_lut + (size_t)(8u << W3_ACHASH_LUT_BITS) * 16);
-            if (ev && !achash_timed) (void)hipEventRecord(ev[12], s);   // (timed for the first ACHistory leaf)
+            if (ev && !achash_timed) (void)hipEventRecord(ev[2 * W3_EV_ACHASH], s);   // (timed for the first ACHistory leaf)
             hipLaunchKernelGGL(w3::k_achash_lut, dim3((8u << W3_ACHASH_LUT_BITS) / 256), dim3(256), 0, s, ha);
             hipLaunchKernelGGL(w3::k_achash, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, ha);
-            if (ev && !achash_timed) { (void)hipEventRecord(ev[13], s); achash_timed = true; ws.achash_timed = true; }
+            if (ev && !achash_timed) { (void)hipEventRecord(ev[2 * W3_EV_ACHASH + 1], s); achash_timed = true; ws.achash_timed = true; }
             pa.keys = (const uint2 *)ws.keys;
             launch_small<true>(nd.bits - 3, dim3(grid_small), s, pa);
             bytes += n * 17;
@@ -320,14 +360,19 @@ static inline int twophase_predict(TwoPhaseWs &ws, hipStream_t s, const ParsedSp
             w3::HuffKeyArgs hk;
             hk.in = d_in; hk.n = n; hk.block_size = (uint32_t)block_size; hk.hmask = (1u << (nd.bits - 3)) - 1u;
             hk.tb = ws.huff + nd.reserved; hk.keys = (uint2 *)ws.keys;
+            // blocks whose bounded walk-back met a run of zero-length codes are redone serially (k_huffkeys_fix)
+            if ((rc = tp_ensure(ws.huff_redo, ws.huff_redo_cap, (size_t)nb * 4, err))) return rc;
+            hk.redo = (uint32_t *)ws.huff_redo; hk.nblocks = nb;
+            (void)hipMemsetAsync(ws.huff_redo, 0, (size_t)nb * 4, s);
             hipLaunchKernelGGL(w3::k_huffkeys, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, hk);
+            hipLaunchKernelGGL(w3::k_huffkeys_fix, dim3((nb + 63u) / 64u), dim3(64), 0, s, hk);
             pa.keys = (const uint2 *)ws.keys;
             launch_small<true>(nd.bits - 3, dim3(grid_small), s, pa);
             bytes += n * 17;
         } else if (c == LEAF_SMALL) {
             // beside a wide leaf's rank kernel (bound by its scattered stores) instead of beside the partition passes: see below
-            if (forked && n_small_def < 8) small_def[n_small_def++] = pa;
-            else launch_small<false>(nd.bits - 3, dim3(grid_small), s, pa);
+            if (n_small_def < 8) small_def[n_small_def++] = pa;
+            else launch_small_shaped(ws, nd.bits - 3, nb, s, pa);
         } else {
             const int w = n_def;
             pa.perm = (uint32_t *)ws.perm_w[w];
@@ -346,17 +391,26 @@ static inline int twophase_predict(TwoPhaseWs &ws, hipStream_t s, const ParsedSp
             // 4096): 64.0 / 59.1 / 54.6 / 55.1 / 58.7 / 58.7 ms.
             uint32_t rank_waves = 2048u;
             if (const char *ev_ = w3_tune_env("W3_RANK_GRID")) rank_waves = (uint32_t)std::max(64, atoi(ev_));   // tuning hook
-            const uint32_t grid_rank = std::min<uint32_t>(nb * W3_SLICES, rank_waves);
+            // half-CU shapes: the FIRST rank kernel starts beside the previous call's coder and must leave it its half of every CU's
+            // LDS whichever of the two is dispatched first; the later ones are single wavefronts again (they fill what is free)
+            const uint32_t grid_rank = (ws.half_cu && (w == 0 || (ws.tune & 32u)) && !(ws.tune & 8u)) ? std::min<uint32_t>((nb * W3_SLICES + W3_NW_RANK - 1) / W3_NW_RANK, W3_HALF_CU_GRID)
+                                                              : std::min<uint32_t>(nb * W3_SLICES, rank_waves);
             // an order-2 leaf behind an Order1 leaf starts from that leaf's records (sorted by c1; same stream, so they are ready)
             const bool chained = c == LEAF_WIDE2 && ws.wide1_slot >= 0 && !(ws.variant & W3_VAR_NO_CHAINED_PARTITION);
             if (chained) pa.rec_src = (const uint2 *)ws.rec_w[ws.wide1_slot];
             // one 8-bit pass through LDS tiles (k_partition8) needs the lane-ordered LDS adds; otherwise 4-bit passes
             const bool p8 = lds_atomics && !(ws.variant & W3_VAR_PARTITION4);
-            if (c == LEAF_WIDE1 && p8) hipLaunchKernelGGL(w3::k_partition8<1>, dim3(grid_wide), dim3(64), 0, sp, pa);
+            const uint32_t grid_p8h = std::min<uint32_t>((nb + W3_NW_PART - 1) / W3_NW_PART, 2 * W3_HALF_CU_GRID);
+            const bool p8h = p8 && ws.half_cu && (ws.tune & 32u);   // W3_OPT_TUNE bit 5: the first predict half in half-CU shapes too
+            if (ev && w < 4) (void)hipEventRecord(ev[2 * (W3_EV_PART0 + w)], sp);
+            if (c == LEAF_WIDE1 && p8h) hipLaunchKernelGGL((w3::k_partition8<1, W3_NW_PART>), dim3(grid_p8h), dim3(64 * W3_NW_PART), 0, sp, pa);
+            else if (chained && p8h) hipLaunchKernelGGL((w3::k_partition8<3, W3_NW_PART>), dim3(grid_p8h), dim3(64 * W3_NW_PART), 0, sp, pa);
+            else if (c == LEAF_WIDE1 && p8) hipLaunchKernelGGL(w3::k_partition8<1>, dim3(grid_wide), dim3(64), 0, sp, pa);
             else if (chained && p8) hipLaunchKernelGGL(w3::k_partition8<3>, dim3(grid_wide), dim3(64), 0, sp, pa);
             else if (c == LEAF_WIDE1) hipLaunchKernelGGL(w3::k_partition<1>, dim3(grid_wide), dim3(64), 0, sp, pa);
             else if (chained) hipLaunchKernelGGL(w3::k_partition<3>, dim3(grid_wide), dim3(64), 0, sp, pa);
             else hipLaunchKernelGGL(w3::k_partition<2>, dim3(grid_wide), dim3(64), 0, sp, pa);
+            if (ev && w < 4) (void)hipEventRecord(ev[2 * (W3_EV_PART0 + w) + 1], sp);
             if (forked) (void)hipEventRecord(ws.ev_join[n_def], ws.side);
             if (c == LEAF_WIDE1) ws.wide1_slot = n_def;
             deferred[n_def].pa = pa; deferred[n_def].cls = c; deferred[n_def].grid_rank = grid_rank; n_def++;
@@ -372,11 +426,34 @@ static inline int twophase_predict(TwoPhaseWs &ws, hipStream_t s, const ParsedSp
     if (n_small_def) {
         // (Measured: with 3 .. 8 instead of 20 waves per CU, so that it fits beside the rank kernel's 8 from the start, the phase
         // takes the same 43-44 ms — the two kernels' times add up either way.)
-        for (int k = 0; k < n_small_def; k++) launch_small<false>(small_def[k].hbits, dim3(grid_small), sp, small_def[k]);
+        if (ev) { (void)hipEventRecord(ev[2 * W3_EV_SMALL], sp); ws.small_timed = true; }
+        for (int k = 0; k < n_small_def; k++) launch_small_shaped(ws, (int)small_def[k].hbits, nb, sp, small_def[k]);
+        if (ev) (void)hipEventRecord(ev[2 * W3_EV_SMALL + 1], sp);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) { err = std::string("predict launch: ") + hipGetErrorString(e); return W3_E_HIP; }
-        (void)hipEventRecord(ws.ev_small, ws.side);
+        if (forked) (void)hipEventRecord(ws.ev_small, ws.side);
     }
+    if (join_all && forked) {
+        if (n_def) (void)hipStreamWaitEvent(s, ws.ev_join[n_def - 1], 0);
+        if (n_small_def) (void)hipStreamWaitEvent(s, ws.ev_small, 0);
+    }
+    st.forked = forked; st.lds_atomics = lds_atomics; st.n_def = n_def; st.n_small_def = n_small_def; st.n_live = n_live;
+    st.bytes = bytes; st.slot_stride = slot_stride;
+    return W3_OK;
+}
+
+// need_P: also merge the leaves' streams into ws.P (k_mix).  The default coder mixes on the fly and needs no P for up to 4 live leaves.
+static inline int twophase_predict_b(TwoPhaseWs &ws, hipStream_t s, const ParsedSpec &ps, const uint8_t *d_in, size_t n, size_t block_size,
+                                     uint32_t nb, bool need_P, const uint16_t **d_P, hipEvent_t *ev, w3_timing *tm, std::string &err) {
+    int rc = W3_OK;
+    TwoPhaseWs::PredictState &st = ws.pst;
+    auto &deferred = st.deferred;
+    const bool forked = st.forked;
+    const int n_def = st.n_def, n_small_def = st.n_small_def, n_live = st.n_live;
+    uint64_t bytes = st.bytes;
+    const uint64_t slot_stride = st.slot_stride;
+    w3::SlotArgs &sa = st.sa;
+    w3::MixArgs &ma = ws.mix;
     // join, then rank inside the sorted groups (main stream: these kernels want the Infinity Cache to themselves)
     // (measured, no gain: the later leaves' rank kernels on the side stream beside the first one — 35 + 28 ms together against
     // 17.7 + 15.8 ms one after the other: they saturate the same scattered-store path — and the time-ordered leaves last)
@@ -384,12 +461,18 @@ static inline int twophase_predict(TwoPhaseWs &ws, hipStream_t s, const ParsedSp
     // bound by the same non-coalesced store path — together 21.5 ms, one after the other 3.5 + 14: timeline_after_reorder.txt.)
     for (int w = 0; w < n_def; w++) {
         if (forked) (void)hipStreamWaitEvent(s, ws.ev_join[n_def - 1], 0);   // every leaf's records are sorted
-        if (deferred[w].cls == LEAF_WIDE1) hipLaunchKernelGGL(w3::k_rank_sorted<1>, dim3(deferred[w].grid_rank), dim3(64), 0, s, deferred[w].pa);
+        if (ev) (void)hipEventRecord(ev[2 * (W3_EV_RANK0 + w)], s);
+        if (ws.half_cu && (w == 0 || (ws.tune & 32u)) && !(ws.tune & 8u)) {
+            if (deferred[w].cls == LEAF_WIDE1) hipLaunchKernelGGL((w3::k_rank_sorted<1, W3_NW_RANK>), dim3(deferred[w].grid_rank), dim3(64 * W3_NW_RANK), 0, s, deferred[w].pa);
+            else hipLaunchKernelGGL((w3::k_rank_sorted<2, W3_NW_RANK>), dim3(deferred[w].grid_rank), dim3(64 * W3_NW_RANK), 0, s, deferred[w].pa);
+        } else if (deferred[w].cls == LEAF_WIDE1) hipLaunchKernelGGL(w3::k_rank_sorted<1>, dim3(deferred[w].grid_rank), dim3(64), 0, s, deferred[w].pa);
         else hipLaunchKernelGGL(w3::k_rank_sorted<2>, dim3(deferred[w].grid_rank), dim3(64), 0, s, deferred[w].pa);
+        if (ev) (void)hipEventRecord(ev[2 * (W3_EV_RANK0 + w) + 1], s);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) { err = std::string("rank launch: ") + hipGetErrorString(e); return W3_E_HIP; }
     }
-    if (n_small_def) (void)hipStreamWaitEvent(s, ws.ev_small, 0);
+    ws.n_wide = n_def;
+    if (n_small_def && forked) (void)hipStreamWaitEvent(s, ws.ev_small, 0);
     if (sa.n_leaves) {
         // HashMaps in HBM, one per (block, leaf), zeroed per batch of blocks; as many blocks at once as the budget allows
         if (!ws.st) { err = "state table not staged"; return W3_E_HIP; }
@@ -422,7 +505,7 @@ static inline int twophase_predict(TwoPhaseWs &ws, hipStream_t s, const ParsedSp
         if ((rc = tp_ensure(ws.dummy, ws.dummy_cap, 2048, err))) return rc;
         sa.dummy = (uint8_t *)ws.dummy;
         if (const char *ev_ = w3_tune_env("W3_SLOT_DEBUG")) sa.dbg_flags = (uint32_t)atoi(ev_);   // -DW3_TUNING timing experiments only: results are wrong
-        if (ev) (void)hipEventRecord(ev[10], s);
+        if (ev) (void)hipEventRecord(ev[2 * W3_EV_SLOT], s);
         for (uint32_t first = 0; first < nb; first += (uint32_t)lanes) {
             const uint32_t cnt = std::min<uint32_t>((uint32_t)lanes, nb - first);
             sa.first_block = first; sa.n_lanes = cnt;
@@ -430,7 +513,7 @@ static inline int twophase_predict(TwoPhaseWs &ws, hipStream_t s, const ParsedSp
             hipLaunchKernelGGL(w3::k_slot, dim3((cnt + 63) / 64, sa.n_leaves), dim3(64), 0, s, sa);
             if (tm) tm->n_slot_launches++;
         }
-        if (ev) (void)hipEventRecord(ev[11], s);
+        if (ev) (void)hipEventRecord(ev[2 * W3_EV_SLOT + 1], s);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) { err = std::string("slot predict launch: ") + hipGetErrorString(e); return W3_E_HIP; }
         bytes += (uint64_t)sa.n_leaves * n * (1 + 16 + 2 * 192);   // 2 nibbles x (96 B read + 96 B written) per input byte
@@ -441,14 +524,22 @@ static inline int twophase_predict(TwoPhaseWs &ws, hipStream_t s, const ParsedSp
         if ((rc = twophase_mix(ws, s, n, err))) return rc;
         bytes += n * 16 * (n_live + 1);
     }
-    if (ev) (void)hipEventRecord(ev[1], s);
+    if (ev) (void)hipEventRecord(ev[2 * W3_EV_PREDICT + 1], s);
     if (tm) tm->predict_bytes = bytes;
     if (d_P) *d_P = (const uint16_t *)ws.P;
     return W3_OK;
 }
 
-#define W3_VERIFY_BLOCKS 16u   // sampled blocks per call (64: +2.0 ms per step beside k_apm0 at 1e9 B, measured; the check looks for a systematic
-                               // change of hardware behaviour, which shows in any block)
+static inline int twophase_predict(TwoPhaseWs &ws, hipStream_t s, const ParsedSpec &ps, const uint8_t *d_in, size_t n, size_t block_size,
+                                   uint32_t nb, bool need_P, const uint16_t **d_P, hipEvent_t *ev, w3_timing *tm, std::string &err) {
+    int rc = twophase_predict_a(ws, s, ps, d_in, n, block_size, nb, ev, err, false);
+    if (rc) return rc;
+    return twophase_predict_b(ws, s, ps, d_in, n, block_size, nb, need_P, d_P, ev, tm, err);
+}
+
+#define W3_VERIFY_BLOCKS 16u   // sampled blocks per call, at least; max(this, nblocks / 256) are taken, and the sample ROTATES from call to call
+                               // (a systematic change of hardware behaviour shows in any block; a fault confined to one block is
+                               // met after at most nblocks / sample calls)
 
 // Always-on insurance for the one undocumented hardware property the default predict kernels rely on (returning LDS adds of
 // one wavefront resolve in ascending lane order: atomic_round, k_partition8).  After a predict phase that used it, up to W3_VERIFY_BLOCKS
@@ -461,15 +552,16 @@ static inline int twophase_verify(TwoPhaseWs &ws, hipStream_t s, const ParsedSpe
                                   uint32_t nb, uint32_t *d_mismatch, std::string &err) {
     if (!ws.verify || !ws.used_lds_atomics) return W3_OK;
     const uint32_t nb_full = (uint32_t)(n / block_size);
-    uint32_t S = (uint32_t)std::min<uint64_t>(std::min<uint32_t>(nb_full, W3_VERIFY_BLOCKS), std::max<uint64_t>(1, (64ull << 20) / block_size));
+    uint32_t S = (uint32_t)std::min<uint64_t>(std::min<uint32_t>(nb_full, std::max<uint32_t>(W3_VERIFY_BLOCKS, nb_full / 256u)), std::max<uint64_t>(1, (64ull << 20) / block_size));
     size_t vn = (size_t)S * block_size;
+    const uint32_t gap = S ? nb_full / S : 0u, rot = gap ? ws.verify_calls++ % gap : 0u;
     const uint8_t *vsrc = nullptr;
     int rc;
     if (nb_full == 0) { S = 1; vn = n; vsrc = d_in; (void)nb; }   // a single short block: verify it whole, in place
     else {
         if ((rc = tp_ensure(ws.vin, ws.vin_cap, vn, err))) return rc;
         hipLaunchKernelGGL(w3::k_gather_blocks, dim3(std::min<uint32_t>((uint32_t)((block_size + 255) / 256), 64u), S), dim3(256), 0, s,
-                           d_in, (uint32_t)block_size, nb_full, S, (uint8_t *)ws.vin);
+                           d_in, (uint32_t)block_size, nb_full, S, rot, (uint8_t *)ws.vin);
         vsrc = (const uint8_t *)ws.vin;
     }
     if (!ws.vws) ws.vws = new TwoPhaseWs();
@@ -493,7 +585,7 @@ static inline int twophase_verify(TwoPhaseWs &ws, hipStream_t s, const ParsedSpe
     const uint32_t cmp_bs = nb_full ? (uint32_t)block_size : (uint32_t)n;
     for (int k = 0; k < nmap; k++)
         hipLaunchKernelGGL(w3::k_compare_blocks, dim3(std::min<uint32_t>((cmp_bs + 255u) / 256u, 64u), S), dim3(256), 0, s,
-                           ws.mix.src[map[k]], v.mix.src[k], cmp_bs, nb_full ? nb_full : 1u, S, d_mismatch);
+                           ws.mix.src[map[k]], v.mix.src[k], cmp_bs, nb_full ? nb_full : 1u, S, rot, d_mismatch);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { err = std::string("verify launch: ") + hipGetErrorString(e); return W3_E_HIP; }
     return W3_OK;
@@ -507,7 +599,7 @@ static inline int twophase_apm(TwoPhaseWs &ws, hipStream_t s, const ParsedSpec &
     int rc = tp_ensure(ws.P, ws.P_cap, n * 16, err);
     if (rc) return rc;
     if ((rc = tp_ensure(ws.dummy, ws.dummy_cap, 2048, err))) return rc;
-    if (ev) (void)hipEventRecord(ev[8], s);
+    if (ev) (void)hipEventRecord(ev[2 * W3_EV_APM], s);
     uint64_t bytes = 0;
     bool partitioned = false;
     for (int k = 0; k < ps.n_apm; k++) {
@@ -522,16 +614,24 @@ static inline int twophase_apm(TwoPhaseWs &ws, hipStream_t s, const ParsedSpec &
             else if (ws.mix.n_src <= 8) { L = ws.mix.n_src; for (int l = 0; l < L; l++) aa.src[l] = (const uint16_t *)ws.mix.src[l]; }
             else { if ((rc = twophase_mix(ws, s, n, err))) return rc; aa.src[0] = (const uint16_t *)ws.P; bytes += n * 16 * (ws.mix.n_src + 1); }
             const dim3 grid((nb + W3_APM_WAVES - 1) / W3_APM_WAVES), blk(128 * W3_APM_WAVES);   // two wavefronts per block
+            // W3_OPT_TUNE bit 1: dynamic LDS on top of the kernel's 79,968 B, so that two of its workgroups do not fit a CU
+            const uint32_t dyn = (ws.half_cu && (ws.tune & 2u)) ? 2048u : 0u;
+#define W3_LAUNCH_APM0(LL)                                                                                                   \
+            do {                                                                                                             \
+                if (dyn) (void)hipFuncSetAttribute((const void *)w3::k_apm0<LL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn); \
+                hipLaunchKernelGGL(w3::k_apm0<LL>, grid, blk, dyn, s, aa);                                                   \
+            } while (0)
             switch (L) {
-            case 1: hipLaunchKernelGGL(w3::k_apm0<1>, grid, blk, 0, s, aa); break;
-            case 2: hipLaunchKernelGGL(w3::k_apm0<2>, grid, blk, 0, s, aa); break;
-            case 3: hipLaunchKernelGGL(w3::k_apm0<3>, grid, blk, 0, s, aa); break;
-            case 4: hipLaunchKernelGGL(w3::k_apm0<4>, grid, blk, 0, s, aa); break;
-            case 5: hipLaunchKernelGGL(w3::k_apm0<5>, grid, blk, 0, s, aa); break;
-            case 6: hipLaunchKernelGGL(w3::k_apm0<6>, grid, blk, 0, s, aa); break;
-            case 7: hipLaunchKernelGGL(w3::k_apm0<7>, grid, blk, 0, s, aa); break;
-            default: hipLaunchKernelGGL(w3::k_apm0<8>, grid, blk, 0, s, aa); break;
+            case 1: W3_LAUNCH_APM0(1); break;
+            case 2: W3_LAUNCH_APM0(2); break;
+            case 3: W3_LAUNCH_APM0(3); break;
+            case 4: W3_LAUNCH_APM0(4); break;
+            case 5: W3_LAUNCH_APM0(5); break;
+            case 6: W3_LAUNCH_APM0(6); break;
+            case 7: W3_LAUNCH_APM0(7); break;
+            default: W3_LAUNCH_APM0(8); break;
             }
+#undef W3_LAUNCH_APM0
             bytes += n * (16 * (uint64_t)L + 1 + 16);
         } else {
             if (!ws.P_valid) { if ((rc = twophase_mix(ws, s, n, err))) return rc; bytes += n * 16 * (ws.mix.n_src + 1); }
@@ -564,32 +664,65 @@ static inline int twophase_apm(TwoPhaseWs &ws, hipStream_t s, const ParsedSpec &
     }
     memset(&ws.mix, 0, sizeof ws.mix);
     ws.mix.src[0] = (const uint4 *)ws.P; ws.mix.n_src = 1; ws.mix.P = (uint4 *)ws.P; ws.mix.n = n;
-    if (ev) (void)hipEventRecord(ev[9], s);
+    if (ev) (void)hipEventRecord(ev[2 * W3_EV_APM + 1], s);
     if (tm) tm->predict_bytes += bytes;
     return W3_OK;
 }
 
-static inline int twophase_encode(TwoPhaseWs &ws, hipStream_t s, const ParsedSpec &ps, const uint8_t *d_in, size_t n, size_t block_size,
-                                  uint32_t nb, uint8_t *stripes, uint32_t stripe_cap, uint32_t *d_lens, uint32_t *d_flag, hipEvent_t *ev,
-                                  w3_timing *tm, std::string &err) {
-    int n_live = 0;
-    for (int l = 0; l < ps.n_leaves; l++) n_live += leaf_class(ps.leaf[l]) != LEAF_FROZEN;
-    const bool x3 = (ws.coder_mode == 0 || ws.coder_mode == 4) && (n_live <= 4 || ps.n_apm > 0);   // more leaves: merge with k_mix first, then k_coder_x2
-    int rc = twophase_predict(ws, s, ps, d_in, n, block_size, nb, !x3 && ps.n_apm == 0, nullptr, ev, tm, err);
-    if (rc) return rc;
+// The encode in three pieces, so that w3_encode_submit can interleave two calls:
+//   twophase_predict (a + b)   on the predict stream
+//   tp_after_predict           verification of a single-leaf APM spec in place; records "predict phase through"
+//   tp_code_stage              APM stages, sampled verification (forked), coder — on the code stream
+// twophase_encode below is the three in sequence (one stream for both = one call at a time, phases strictly in order).
+struct TpPlan { int n_live, coder; bool x3, need_P, verify_on, verify_in_place; };
+static inline TpPlan tp_plan(const TwoPhaseWs &ws, const ParsedSpec &ps) {
+    TpPlan p;
+    p.n_live = 0;
+    for (int l = 0; l < ps.n_leaves; l++) p.n_live += leaf_class(ps.leaf[l]) != LEAF_FROZEN;
+    p.coder = ws.half_cu && ws.coder_mode == 0 ? 5 : ws.coder_mode;   // half-CU shapes: k_coder_x5 in k_coder_x4's place
+    p.x3 = (p.coder == 0 || p.coder == 4 || p.coder == 5) && (p.n_live <= 4 || ps.n_apm > 0);   // more leaves: merge with k_mix first, then k_coder_x2
+    p.need_P = !p.x3 && ps.n_apm == 0;
+    p.verify_on = false; p.verify_in_place = false;
+    return p;
+}
+
+static inline int tp_after_predict(TwoPhaseWs &ws, hipStream_t s_pred, const ParsedSpec &ps, const uint8_t *d_in, size_t n, size_t block_size, uint32_t nb,
+                                   uint32_t *d_flag, std::string &err) {
+    const TpPlan pl = tp_plan(ws, ps);
     // flag word 2: mismatching waves.  The re-prediction only reads the leaves' streams, so it runs on its own stream (2.8 ms of
     // small launches otherwise) beside the CODER kernel, which leaves the chip's memory system and most of its issue slots
     // idle (beside k_apm0 its workgroups displaced some of that kernel's for ~1.4 ms per step, measured) — unless an APM stage
-    // is about to rewrite the single leaf's stream in place: then it runs first, on the main stream.
+    // is about to rewrite the single leaf's stream in place: then it runs first, on the predict stream.
+    const bool verify_on = ws.verify && ws.used_lds_atomics;
+    const bool verify_in_place = verify_on && pl.n_live == 1 && ps.n_apm > 0;
+    int rc;
+    if (verify_in_place && (rc = twophase_verify(ws, s_pred, ps, d_in, n, block_size, nb, d_flag + 2, err))) return rc;
+    if (!ws.ev_pred_done && hipEventCreateWithFlags(&ws.ev_pred_done, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); err = "event creation failed"; return W3_E_HIP; }
+    (void)hipEventRecord(ws.ev_pred_done, s_pred);
+    return W3_OK;
+}
+
+// wait_ev: one more event the stage waits for (the NEXT call's first predict half); rec_after_apm: recorded when the APM stages are
+// through (the next call's rank kernels wait for it).  Either may be null.
+static inline int tp_code_stage(TwoPhaseWs &ws, hipStream_t s_pred, hipStream_t s, const ParsedSpec &ps, const uint8_t *d_in, size_t n, size_t block_size,
+                                uint32_t nb, uint8_t *stripes, uint32_t stripe_cap, uint32_t *d_lens, uint32_t *d_flag, hipEvent_t wait_ev, hipEvent_t rec_after_apm,
+                                hipEvent_t *ev, w3_timing *tm, std::string &err) {
+    const TpPlan pl = tp_plan(ws, ps);
+    const int n_live = pl.n_live, coder = pl.coder;
+    const bool x3 = pl.x3;
+    int rc;
     bool verify_forked = false;
     const bool verify_on = ws.verify && ws.used_lds_atomics;
     const bool verify_in_place = verify_on && n_live == 1 && ps.n_apm > 0;
-    if (verify_in_place && (rc = twophase_verify(ws, s, ps, d_in, n, block_size, nb, d_flag + 2, err))) return rc;
     if (verify_on && !verify_in_place && !ws.vstream) {
-        bool ok = hipStreamCreateWithFlags(&ws.vstream, hipStreamNonBlocking) == hipSuccess && hipEventCreateWithFlags(&ws.ev_v0, hipEventDisableTiming) == hipSuccess &&
-                  hipEventCreateWithFlags(&ws.ev_v1, hipEventDisableTiming) == hipSuccess;
+        // (lowest priority level: its own hardware queues, apart from the launch streams'; and the re-prediction is in nobody's way)
+        int lo_p = 0, hi_p = 0;
+        bool ok = hipDeviceGetStreamPriorityRange(&lo_p, &hi_p) == hipSuccess && hipStreamCreateWithPriority(&ws.vstream, hipStreamNonBlocking, lo_p) == hipSuccess &&
+                  hipEventCreateWithFlags(&ws.ev_v0, hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&ws.ev_v1, hipEventDisableTiming) == hipSuccess;
         if (!ok) { (void)hipGetLastError(); err = "verification stream creation failed"; return W3_E_HIP; }
     }
+    if (s != s_pred) (void)hipStreamWaitEvent(s, ws.ev_pred_done, 0);
+    if (wait_ev) (void)hipStreamWaitEvent(s, wait_ev, 0);
     // join on every way out of this function: the caller reads the mismatch word (and may free buffers) next
     struct Join { hipStream_t st; hipEvent_t ev; const bool &on; ~Join() { if (on) (void)hipStreamWaitEvent(st, ev, 0); } } join{s, ws.ev_v1, verify_forked};
     const auto leaf_streams = ws.mix;   // (the APM stages below replace ws.mix by their one output stream)
@@ -603,25 +736,13 @@ static inline int twophase_encode(TwoPhaseWs &ws, hipStream_t s, const ParsedSpe
         verify_forked = true;
         return vr;
     };
-    if (ws.ev_pred_done) (void)hipEventRecord(ws.ev_pred_done, s);   // the next block range may start its predict kernels
-    hipStream_t s_lo = s;
-    if (ws.use_hi) {
-        if (!ws.hi) {
-            int lo_p = 0, hi_p = 0;
-            bool ok = hipDeviceGetStreamPriorityRange(&lo_p, &hi_p) == hipSuccess && hipStreamCreateWithPriority(&ws.hi, hipStreamNonBlocking, hi_p) == hipSuccess &&
-                      hipEventCreateWithFlags(&ws.ev_hi_start, hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&ws.ev_hi_done, hipEventDisableTiming) == hipSuccess;
-            if (!ok) { (void)hipGetLastError(); err = "high-priority stream creation failed"; return W3_E_HIP; }
-        }
-        (void)hipEventRecord(ws.ev_hi_start, s);
-        (void)hipStreamWaitEvent(ws.hi, ws.ev_hi_start, 0);
-        s = ws.hi;
-    }
     if ((rc = twophase_apm(ws, s, ps, d_in, n, block_size, nb, ev, tm, err))) return rc;   // leaves ws.P as the one source stream
+    if (rec_after_apm) (void)hipEventRecord(rec_after_apm, s);
     if (verify_on && !verify_in_place && (rc = fork_verify(s))) return rc;
     if (w3_tune_env("W3_DEBUG_NOSTORE")) { err = "W3_DEBUG_NOSTORE: predict-only timing experiment"; return W3_E_UNSUPPORTED; }
     if ((rc = tp_ensure(ws.redo, ws.redo_cap, (size_t)nb * 4, err))) return rc;
     const uint32_t limit = std::min<uint32_t>(ws.acc_limit, 46u);
-    if (ev) (void)hipEventRecord(ev[2], s);
+    if (ev) (void)hipEventRecord(ev[2 * W3_EV_CODER], s);
     if (x3) {
         w3::Coder3Args c3;
         memset(&c3, 0, sizeof c3);
@@ -631,12 +752,20 @@ static inline int twophase_encode(TwoPhaseWs &ws, hipStream_t s, const ParsedSpe
         c3.acc_limit = limit;
         c3.out_bits = ws.out_bits;
         const dim3 grid((nb + 63) / 64), blk(192);
-        if (ws.coder_mode == 4) {
+        if (coder == 4) {
             switch (ws.mix.n_src) {
             case 1: hipLaunchKernelGGL(w3::k_coder_x3<1>, grid, blk, 0, s, c3); break;
             case 2: hipLaunchKernelGGL(w3::k_coder_x3<2>, grid, blk, 0, s, c3); break;
             case 3: hipLaunchKernelGGL(w3::k_coder_x3<3>, grid, blk, 0, s, c3); break;
             default: hipLaunchKernelGGL(w3::k_coder_x3<4>, grid, blk, 0, s, c3); break;
+            }
+        } else if (coder == 5) {   // half the LDS: leaves room beside it for the next call's predict workgroups
+            const dim3 blk2(256);
+            switch (ws.mix.n_src) {
+            case 1: hipLaunchKernelGGL(w3::k_coder_x5<1>, grid, blk, 0, s, c3); break;
+            case 2: hipLaunchKernelGGL(w3::k_coder_x5<2>, grid, blk2, 0, s, c3); break;
+            case 3: hipLaunchKernelGGL(w3::k_coder_x5<3>, grid, blk2, 0, s, c3); break;
+            default: hipLaunchKernelGGL(w3::k_coder_x5<4>, grid, blk2, 0, s, c3); break;
             }
         } else {
             const dim3 blk2(256);   // two M-waves when the leaves are mixed on the fly
@@ -655,22 +784,32 @@ static inline int twophase_encode(TwoPhaseWs &ws, hipStream_t s, const ParsedSpe
         ca.stripes = stripes; ca.stripe_cap = stripe_cap; ca.out_len = d_lens; ca.flags = d_flag;
         ca.acc_limit = limit;
         ca.out_bits = ws.out_bits;
-        if (ws.coder_mode == 2) {
+        if (coder == 2) {
             ca.redo = nullptr;
             hipLaunchKernelGGL(w3::k_coder, dim3((nb + 63) / 64), dim3(64), 0, s, ca);
         } else {
             ca.redo = (uint32_t *)ws.redo;
-            if (ws.coder_mode == 1) hipLaunchKernelGGL(w3::k_coder_fast, dim3((nb + 63) / 64), dim3(64), 0, s, ca);
+            if (coder == 1) hipLaunchKernelGGL(w3::k_coder_fast, dim3((nb + 63) / 64), dim3(64), 0, s, ca);
             else hipLaunchKernelGGL(w3::k_coder_x2, dim3((nb + 63) / 64), dim3(128), 0, s, ca);
         }
         if (tm) tm->coder_bytes = (uint64_t)n * 17;
     }
-    if (ev) (void)hipEventRecord(ev[3], s);
+    if (ev) (void)hipEventRecord(ev[2 * W3_EV_CODER + 1], s);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { err = std::string("coder launch: ") + hipGetErrorString(e); return W3_E_HIP; }
     if (tm) tm->n_coder_launches = 1;
-    if (s != s_lo) { (void)hipEventRecord(ws.ev_hi_done, s); (void)hipStreamWaitEvent(s_lo, ws.ev_hi_done, 0); }
     return W3_OK;
+}
+
+// s_pred: the predict phase's launch stream; s: the stream of the APM stages, the coder and whatever the caller enqueues next
+// (pack, status read-back).  One stream for both = one call at a time, phases strictly in sequence.
+static inline int twophase_encode(TwoPhaseWs &ws, hipStream_t s_pred, hipStream_t s, const ParsedSpec &ps, const uint8_t *d_in, size_t n, size_t block_size,
+                                  uint32_t nb, uint8_t *stripes, uint32_t stripe_cap, uint32_t *d_lens, uint32_t *d_flag, hipEvent_t *ev,
+                                  w3_timing *tm, std::string &err) {
+    int rc = twophase_predict(ws, s_pred, ps, d_in, n, block_size, nb, tp_plan(ws, ps).need_P, nullptr, ev, tm, err);
+    if (rc) return rc;
+    if ((rc = tp_after_predict(ws, s_pred, ps, d_in, n, block_size, nb, d_flag, err))) return rc;
+    return tp_code_stage(ws, s_pred, s, ps, d_in, n, block_size, nb, stripes, stripe_cap, d_lens, d_flag, nullptr, nullptr, ev, tm, err);
 }
 
 // Blocks the fast coder gave up on (pending run longer than its accumulator): re-code with k_coder.

@@ -33,7 +33,23 @@ struct DevBuf {
     size_t cap = 0;
 };
 
-#define W3_MAX_PARTS 4
+// One encode in flight: its own workspace, so that call k+1's predict phase can run beside call k's APM and coder kernels
+// (w3_encode_submit / w3_encode_wait).  Job 0's members live in w3_ctx itself (every synchronous call uses them).
+struct JobState {
+    int state = 0;                 // 0 idle, 1 enqueued (w3_encode_wait completes it), 2 ran synchronously inside w3_encode_submit
+    hipEvent_t ev_done = nullptr, ev_in = nullptr;
+    hipEvent_t ev_a = nullptr, ev_apm = nullptr;   // first predict half through / APM stages through (what the other job's kernels wait for)
+    bool code_pending = false;     // the APM + coder + pack stage is not enqueued yet (it goes behind the NEXT job's first predict half)
+    ParsedSpec ps; uint32_t nb = 0, cap = 0;
+    uint32_t *h_status = nullptr;  // pinned: [0..3] the coder's flag words, [4..5] total compressed bytes
+    // the submitted call, kept for the rare synchronous redo in w3_encode_wait (stripe overflow, fast-coder hand-back, LDS-order fault)
+    w3_model_spec spec{};
+    w3_huff_table huff_copy[W3_MAX_HUFF];
+    const uint8_t *d_in = nullptr; size_t n = 0, block_size = 0; uint8_t *d_out = nullptr; size_t out_cap = 0;
+    uint32_t *d_block_lens = nullptr; uint64_t *d_total = nullptr;
+    w3_timing tm{};
+    bool has_apm = false, has_slot = false, timed = false;
+};
 
 struct w3_ctx {
     int device = 0;
@@ -42,16 +58,25 @@ struct w3_ctx {
     int opt_path = W3_PATH_AUTO;
     int opt_timing = 0;
     w3_timing timing{};
-    hipEvent_t ev[14]{};
+    hipEvent_t ev[W3_NEV]{};
     // workspace
     DevBuf tables, stripes, lens, offs, total, flag, io_in, io_out, coffs, misc, cm_luts, achash_luts, huff, bits, sweep;
     TwoPhaseWs tp;
-    // block ranges 1..3 of a pipelined two-phase encode (range 0 uses tp, ev and the caller's stream)
-    struct Range { TwoPhaseWs ws; hipStream_t stream = nullptr; hipEvent_t ev[14]{}; hipEvent_t ev_done = nullptr; };
-    Range ranges[W3_MAX_PARTS - 1];
-    hipEvent_t ev_fork = nullptr, ev_pred[W3_MAX_PARTS]{};
-    int opt_parts = 0;   // 0 = auto
+    // the second job of the submit / wait pipeline
+    struct Job1 { TwoPhaseWs tp; DevBuf stripes, flag, bits, offs, huff; hipEvent_t ev[W3_NEV]{}; } j1;
+    JobState js[2];
+    hipStream_t s_pred = nullptr, s_code = nullptr;   // created by the first w3_encode_submit
+    int next_job = 0;
 };
+
+// the members of job j under one name
+struct JobRef {
+    TwoPhaseWs &tp; DevBuf &stripes, &flag, &bits, &offs, &huff; hipEvent_t *ev; JobState &st;
+};
+static JobRef jobref(w3_ctx *c, int j) {
+    if (j == 0) return JobRef{c->tp, c->stripes, c->flag, c->bits, c->offs, c->huff, c->ev, c->js[0]};
+    return JobRef{c->j1.tp, c->j1.stripes, c->j1.flag, c->j1.bits, c->j1.offs, c->j1.huff, c->j1.ev, c->js[1]};
+}
 
 #define HIPCHK(ctx, expr)                                                                       \
     do {                                                                                        \
@@ -122,14 +147,20 @@ extern "C" void w3_ctx_destroy(w3_ctx *ctx) {
     for (DevBuf *b : bufs)
         if (b->p) (void)hipFree(b->p);
     ctx->tp.release();
-    for (auto &r : ctx->ranges) {
-        r.ws.release();
-        for (auto &e : r.ev) if (e) (void)hipEventDestroy(e);
-        if (r.ev_done) (void)hipEventDestroy(r.ev_done);
-        if (r.stream) (void)hipStreamDestroy(r.stream);
+    ctx->j1.tp.release();
+    DevBuf *bufs1[] = {&ctx->j1.stripes, &ctx->j1.flag, &ctx->j1.bits, &ctx->j1.offs, &ctx->j1.huff};
+    for (DevBuf *b : bufs1)
+        if (b->p) (void)hipFree(b->p);
+    for (auto &e : ctx->j1.ev) if (e) (void)hipEventDestroy(e);
+    for (auto &st : ctx->js) {
+        if (st.ev_done) (void)hipEventDestroy(st.ev_done);
+        if (st.ev_in) (void)hipEventDestroy(st.ev_in);
+        if (st.ev_a) (void)hipEventDestroy(st.ev_a);
+        if (st.ev_apm) (void)hipEventDestroy(st.ev_apm);
+        if (st.h_status) (void)hipHostFree(st.h_status);
     }
-    if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
-    for (auto &e : ctx->ev_pred) if (e) (void)hipEventDestroy(e);
+    if (ctx->s_pred) (void)hipStreamDestroy(ctx->s_pred);
+    if (ctx->s_code) (void)hipStreamDestroy(ctx->s_code);
     for (auto &e : ctx->ev)
         if (e) (void)hipEventDestroy(e);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -145,29 +176,36 @@ extern "C" int w3_ctx_set_option(w3_ctx *ctx, int opt, int64_t value) {
         return W3_OK;
     case W3_OPT_TIMING: ctx->opt_timing = value ? 1 : 0; return W3_OK;
     case W3_OPT_CODER:
-        if (value < 0 || value > 4) return W3_E_INVALID;
+        if (value < 0 || value > 5) return W3_E_INVALID;
         ctx->tp.coder_mode = (int)value;
         return W3_OK;
     case W3_OPT_DEBUG_STAMPS: ctx->tp.debug_stamps = value ? 1 : 0; return W3_OK;
-    case W3_OPT_PARTS:
-        if (value < 0 || value > W3_MAX_PARTS) return W3_E_INVALID;
-        ctx->opt_parts = (int)value;
-        return W3_OK;
     case W3_OPT_ACC_LIMIT:
         if (value < 19 || value > 46) return W3_E_INVALID;
         ctx->tp.acc_limit = (uint32_t)value;
         return W3_OK;
     case W3_OPT_VARIANT:
-        if (value < 0 || value > 63) return W3_E_INVALID;
+        if (value < 0 || value > 255) return W3_E_INVALID;
+        // the fault-injection hook exists for the test of the sampled verification: without the verification it would only corrupt output
+        if ((value & W3_VAR_INJECT_LDS_FAULT) && !ctx->tp.verify) { ctx->err = "W3_OPT_VARIANT bit 32 (fault injection) needs W3_OPT_VERIFY on"; return W3_E_INVALID; }
         ctx->tp.variant = (uint32_t)value;
         ctx->tp.lds_order = -1;   // re-run the lane-order self-test under the new setting
         return W3_OK;
     case W3_OPT_VERIFY:
+        if (!value && (ctx->tp.variant & W3_VAR_INJECT_LDS_FAULT)) { ctx->err = "W3_OPT_VERIFY cannot be switched off while the fault-injection variant is set"; return W3_E_INVALID; }
         ctx->tp.verify = value ? 1 : 0;
         return W3_OK;
     case W3_OPT_SLOT_BUDGET_MB:
         if (value < 0 || value > (1 << 20)) return W3_E_INVALID;
         ctx->tp.slot_budget_mb = (uint32_t)value;
+        return W3_OK;
+    case W3_OPT_TUNE:
+        if (value < 0 || value > 0xFFFF) return W3_E_INVALID;
+        ctx->tp.tune = (uint32_t)value;
+        return W3_OK;
+    case W3_OPT_FAULT_BLOCK:
+        if (value < -1 || value > 0x7FFFFFFF) return W3_E_INVALID;
+        ctx->tp.fault_block = value < 0 ? 0xFFFFFFFFu : (uint32_t)value;
         return W3_OK;
     default: return W3_E_INVALID;
     }
@@ -193,7 +231,9 @@ extern "C" size_t w3_max_compressed_size(size_t n, size_t block_size) {
 // ---------------------------------------------------------------------------
 static int parse_spec(const w3_model_spec *spec, ParsedSpec &ps) {
     if (!spec || spec->n_nodes == 0 || spec->n_nodes > W3_MAX_NODES) return W3_E_INVALID;
+    if (spec->n_huff > W3_MAX_HUFF || (spec->n_huff && !spec->huff)) return W3_E_INVALID;   // (the spec must be zero-initialised: w3hip.h)
     int depth = 0;
+    uint32_t huff_used = 0;   // table sets some W3_HIST_HUFF leaf refers to: only those are read
     ps = ParsedSpec();
     for (uint32_t i = 0; i < spec->n_nodes; i++) {
         const w3_node &nd = spec->nodes[i];
@@ -212,7 +252,10 @@ static int parse_spec(const w3_model_spec *spec, ParsedSpec &ps) {
             if ((int)nd.bits - (int)nd.align > 31) return W3_E_INVALID;
             if (nd.history > W3_HIST_HUFF) return W3_E_INVALID;
             if (nd.history == W3_HIST_AC && nd.max_bits > 32) return W3_E_INVALID;
-            if (nd.history == W3_HIST_HUFF && (spec->n_huff > W3_MAX_HUFF || nd.reserved >= spec->n_huff || !spec->huff)) return W3_E_INVALID;
+            if (nd.history == W3_HIST_HUFF) {
+                if (nd.reserved >= spec->n_huff) return W3_E_INVALID;
+                huff_used |= 1u << nd.reserved;
+            }
             if (ps.n_leaves == W3_MAX_LEAVES) return W3_E_UNSUPPORTED;
             ps.leaf[ps.n_leaves++] = nd;
             depth++;
@@ -229,26 +272,20 @@ static int parse_spec(const w3_model_spec *spec, ParsedSpec &ps) {
             return W3_E_INVALID;
         }
     }
-    ps.n_huff = spec->n_huff <= W3_MAX_HUFF ? spec->n_huff : 0;
+    // the table sets travel to the device only when a leaf uses one (a spec without HuffHistory leaves never has its huff
+    // pointer dereferenced); code lengths index shifts of u32 values
+    ps.n_huff = huff_used ? spec->n_huff : 0;
     ps.huff = ps.n_huff ? spec->huff : nullptr;
-    if (ps.n_huff) {   // code lengths index shifts of u32 values
-        for (uint32_t k = 0; k < ps.n_huff; k++)
-            for (int v = 0; v < 256; v++)
-                if (ps.huff[k].len[v] > 16 || ps.huff[k].rem_len[v] > 16) return W3_E_INVALID;
+    for (uint32_t k = 0; k < ps.n_huff; k++) {
+        if (!((huff_used >> k) & 1u)) continue;
+        for (int v = 0; v < 256; v++)
+            if (ps.huff[k].len[v] > 16 || ps.huff[k].rem_len[v] > 16) return W3_E_INVALID;
     }
     return depth == 1 ? W3_OK : W3_E_INVALID;
 }
 
-// HuffHistory table sets of the spec -> device (per call: the tables are the caller's memory)
-static int stage_huff(w3_ctx *ctx, hipStream_t s, const ParsedSpec &ps) {
-    ctx->tp.huff = nullptr;
-    if (!ps.n_huff) return W3_OK;
-    ENSURE(ctx, ctx->huff, sizeof(w3_huff_table) * W3_MAX_HUFF);
-    HIPCHK(ctx, hipMemcpyAsync(ctx->huff.p, ps.huff, sizeof(w3_huff_table) * ps.n_huff, hipMemcpyHostToDevice, s));
-    HIPCHK(ctx, hipStreamSynchronize(s));   // (pageable source: the caller may free it after the call)
-    ctx->tp.huff = (const w3_huff_table *)ctx->huff.p;
-    return W3_OK;
-}
+// HuffHistory table sets of the spec -> device (per call: the tables are the caller's memory); job 0's copy
+static int stage_huff(w3_ctx *ctx, hipStream_t s, const ParsedSpec &ps);
 
 extern "C" int w3_spec_validate(const w3_model_spec *spec) {
     ParsedSpec ps;
@@ -295,28 +332,14 @@ static uint64_t layout_generic(const ParsedSpec &ps, size_t block_size, GenericA
 static int prepare_achash_luts(w3_ctx *ctx, hipStream_t s, GenericArgs &ga);
 
 // ---------------------------------------------------------------------------
-// timing helpers
-// ---------------------------------------------------------------------------
-struct Timer {
-    w3_ctx *c; hipStream_t s; int i;
-    void start(int slot) { i = slot; if (c->opt_timing) (void)hipEventRecord(c->ev[2 * slot], s); }
-    void stop() { if (c->opt_timing) (void)hipEventRecord(c->ev[2 * i + 1], s); }
-};
-static float elapsed(w3_ctx *c, int slot) {
-    float ms = 0.f;
-    if (hipEventElapsedTime(&ms, c->ev[2 * slot], c->ev[2 * slot + 1]) != hipSuccess) { (void)hipGetLastError(); return 0.f; }
-    return ms;
-}
-
-// ---------------------------------------------------------------------------
 // pack: scan block lengths, compact stripes into d_out
 // ---------------------------------------------------------------------------
-static int run_pack(w3_ctx *ctx, hipStream_t s, const uint8_t *stripes, uint64_t stride, const uint32_t *d_lens, uint32_t nb,
+static int run_pack(w3_ctx *ctx, JobRef &J, hipStream_t s, const uint8_t *stripes, uint64_t stride, const uint32_t *d_lens, uint32_t nb,
                     uint8_t *d_out, size_t out_cap, uint64_t *d_total) {
-    ENSURE(ctx, ctx->offs, (size_t)nb * 8);
-    hipLaunchKernelGGL(k_scan_lens, dim3(1), dim3(1024), 0, s, d_lens, (uint64_t *)ctx->offs.p, d_total, nb);
+    ENSURE(ctx, J.offs, (size_t)nb * 8);
+    hipLaunchKernelGGL(k_scan_lens, dim3(1), dim3(1024), 0, s, d_lens, (uint64_t *)J.offs.p, d_total, nb);
     uint32_t grid = std::min<uint32_t>(nb, 256 * 8);
-    hipLaunchKernelGGL(k_pack, dim3(grid), dim3(256), 0, s, stripes, stride, d_lens, (const uint64_t *)ctx->offs.p, d_out,
+    hipLaunchKernelGGL(k_pack, dim3(grid), dim3(256), 0, s, stripes, stride, d_lens, (const uint64_t *)J.offs.p, d_out,
                        (uint64_t)out_cap, nb);
     HIPCHK(ctx, hipGetLastError());
     return W3_OK;
@@ -561,44 +584,48 @@ static float elapsed_ev(hipEvent_t *ev, int slot) {
     return ms;
 }
 
-// How many block ranges a two-phase encode is pipelined in (W3_OPT_PARTS; default ONE).  The idea: the coder (lane per
-// block: fewer wavefronts than SIMDs) and the APM kernels (two wavefronts per SIMD, LDS-bound) leave most issue slots idle,
-// so range r's APM and coder kernels could execute beside range r+1's predict kernels.  Measured on MI355X (1e9 B,
-// order012apm): 2 ranges 115 -> 115 ms, 4 ranges 185 ms.  The APM workgroups (77 KB of LDS) are starved while predict
-// kernels are resident: 8 KB workgroups refill every hole that opens, the LDS never has a contiguous free region, and a
-// high-priority stream (tried: use_hi) does not reserve one.  Kept as a tested option; not the default.
-// Slot-state leaves size their hash-map batches from the free device memory, so specs with them stay in one range.
-static int choose_parts(const w3_ctx *ctx, const ParsedSpec &ps, uint32_t nb) {
-    if (ps.has_slot) return 1;
-    int k = ctx->opt_parts;
-    if (const char *e = w3_tune_env("W3_PARTS")) k = atoi(e);   // -DW3_TUNING builds only
-    if (k <= 0) k = 1;
-    k = std::min(k, W3_MAX_PARTS);
-    while (k > 1 && nb / (uint32_t)k < 256u) k--;
-    return k;
+// per-kernel launch times of one two-phase encode from its events (W3_OPT_TIMING)
+static void collect_timing(hipEvent_t *ev, const TwoPhaseWs &ws, bool has_apm, bool has_slot, bool packed, w3_timing &t) {
+    t.predict_ms = elapsed_ev(ev, W3_EV_PREDICT); t.coder_ms = elapsed_ev(ev, W3_EV_CODER);
+    if (has_apm) t.apm_ms = elapsed_ev(ev, W3_EV_APM);
+    if (has_slot) t.slot_ms = elapsed_ev(ev, W3_EV_SLOT);
+    if (ws.achash_timed) t.achash_ms = elapsed_ev(ev, W3_EV_ACHASH);
+    t.n_wide = (uint32_t)std::min(ws.n_wide, 4);
+    for (int w = 0; w < ws.n_wide && w < 4; w++) { t.part_ms[w] = elapsed_ev(ev, W3_EV_PART0 + w); t.rank_ms[w] = elapsed_ev(ev, W3_EV_RANK0 + w); }
+    if (ws.small_timed) t.small_ms = elapsed_ev(ev, W3_EV_SMALL);
+    t.pack_ms = packed ? elapsed_ev(ev, W3_EV_PACK) : 0.f;
+    t.total_ms = elapsed_ev(ev, W3_EV_TOTAL);
 }
 
-static int ensure_ranges(w3_ctx *ctx, int parts, bool timing) {
-    if (!ctx->ev_fork) HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
-    for (int p = 0; p < parts; p++)
-        if (!ctx->ev_pred[p]) HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_pred[p], hipEventDisableTiming));
-    for (int p = 1; p < parts; p++) {
-        w3_ctx::Range &r = ctx->ranges[p - 1];
-        if (!r.stream) HIPCHK(ctx, hipStreamCreateWithFlags(&r.stream, hipStreamNonBlocking));
-        if (!r.ev_done) HIPCHK(ctx, hipEventCreateWithFlags(&r.ev_done, hipEventDisableTiming));
-        if (timing)
-            for (auto &e : r.ev)
-                if (!e) HIPCHK(ctx, hipEventCreate(&e));
-        r.ws.coder_mode = ctx->tp.coder_mode; r.ws.acc_limit = ctx->tp.acc_limit; r.ws.debug_stamps = 0;
-        r.ws.variant = ctx->tp.variant; r.ws.slot_budget_mb = ctx->tp.slot_budget_mb; r.ws.verify = ctx->tp.verify;
-        r.ws.stretch = ctx->tp.stretch; r.ws.squash = ctx->tp.squash; r.ws.st = ctx->tp.st; r.ws.huff = ctx->tp.huff;
-    }
+static int stage_huff_job(w3_ctx *ctx, JobRef &J, hipStream_t s, const ParsedSpec &ps) {
+    J.tp.huff = nullptr;
+    if (!ps.n_huff) return W3_OK;
+    ENSURE(ctx, J.huff, sizeof(w3_huff_table) * W3_MAX_HUFF);
+    HIPCHK(ctx, hipMemcpyAsync(J.huff.p, ps.huff, sizeof(w3_huff_table) * ps.n_huff, hipMemcpyHostToDevice, s));
+    HIPCHK(ctx, hipStreamSynchronize(s));   // (pageable source: the caller may free it after the call)
+    J.tp.huff = (const w3_huff_table *)J.huff.p;
     return W3_OK;
 }
 
+static int stage_huff(w3_ctx *ctx, hipStream_t s, const ParsedSpec &ps) {
+    JobRef J = jobref(ctx, 0);
+    return stage_huff_job(ctx, J, s, ps);
+}
+
+// options live in job 0's workspace (w3_ctx_set_option); job 1 follows it
+static void sync_job_options(w3_ctx *ctx, JobRef &J) {
+    if (&J.tp == &ctx->tp) return;
+    J.tp.coder_mode = ctx->tp.coder_mode; J.tp.acc_limit = ctx->tp.acc_limit; J.tp.debug_stamps = 0;
+    J.tp.variant = ctx->tp.variant; J.tp.slot_budget_mb = ctx->tp.slot_budget_mb; J.tp.verify = ctx->tp.verify;
+    J.tp.stretch = ctx->tp.stretch; J.tp.squash = ctx->tp.squash; J.tp.st = ctx->tp.st; J.tp.fault_block = ctx->tp.fault_block; J.tp.tune = ctx->tp.tune;
+    if (ctx->tp.lds_order >= 0) J.tp.lds_order = ctx->tp.lds_order;   // (job 0 has run the self-test)
+}
+
 // d_out == nullptr: counting-sink mode (ACStats, helpers.rs:60-90) — the streams are coded into the stripes as usual, the
-// pack is skipped and only ctx->bits (per-block bit counts) is of interest; d_block_lens may then be a scratch buffer.
-static int encode_core(w3_ctx *ctx, const w3_model_spec *spec, const uint8_t *d_in, size_t n, size_t block_size,
+// pack is skipped and only J.bits (per-block bit counts) is of interest; d_block_lens may then be a scratch buffer.
+// Synchronous: returns when the output is complete.  J = the job whose workspace is used (job 0 for every synchronous entry point;
+// w3_encode_wait redoes a job of its own here).
+static int encode_core(w3_ctx *ctx, JobRef J, const w3_model_spec *spec, const uint8_t *d_in, size_t n, size_t block_size,
                        uint8_t *d_out, size_t out_cap, uint32_t *d_block_lens, uint64_t *d_total, void *stream) {
     int rc = check_args(ctx, n, block_size);
     if (rc) return rc;
@@ -616,9 +643,9 @@ static int encode_core(w3_ctx *ctx, const w3_model_spec *spec, const uint8_t *d_
         return W3_OK;
     }
     if (!d_in || !d_block_lens) return W3_E_INVALID;
-    ENSURE(ctx, ctx->flag, 16);
-    ENSURE(ctx, ctx->bits, (size_t)nb * 4);
-    if ((rc = stage_huff(ctx, s, ps))) return rc;
+    ENSURE(ctx, J.flag, 16);
+    ENSURE(ctx, J.bits, (size_t)nb * 4);
+    if ((rc = stage_huff_job(ctx, J, s, ps))) return rc;
 
     bool two = twophase_supported(ps, block_size, n);   // Counter and slot-state leaves + APM chain (decode: k_generic / k_cm)
     if (ctx->opt_path == W3_PATH_GENERIC) two = false;
@@ -628,142 +655,277 @@ static int encode_core(w3_ctx *ctx, const w3_model_spec *spec, const uint8_t *d_
         ctx->tp.stretch = lut.stretch; ctx->tp.squash = lut.squash; ctx->tp.st = lut.st;
     }
     if (ctx->opt_path == W3_PATH_TWOPHASE && !two) { ctx->err = "spec/block size not covered by the two-phase path"; return W3_E_UNSUPPORTED; }
+    if (!two && &J.tp != &ctx->tp) { ctx->err = "internal: the lane-per-block path runs on job 0"; return W3_E_INVALID; }
+    sync_job_options(ctx, J);
+    J.tp.half_cu = (ctx->tp.variant & W3_VAR_HALF_CU) != 0;
 
-    Timer tm{ctx, s, 0};
+    hipEvent_t *evp = ctx->opt_timing ? J.ev : nullptr;
     uint32_t cap = default_stripe_cap(block_size);
-    const int parts = two ? choose_parts(ctx, ps, nb) : 1;
-    uint32_t pb[W3_MAX_PARTS + 1];   // range p = blocks [pb[p], pb[p+1]); boundaries on multiples of 64 blocks
-    for (int p = 0; p <= parts; p++) pb[p] = p == parts ? nb : (uint32_t)((uint64_t)nb * p / parts) / 64u * 64u;
-    w3_timing ptm[W3_MAX_PARTS];
-    memset(ptm, 0, sizeof ptm);
-    if (parts > 1 && (rc = ensure_ranges(ctx, parts, ctx->opt_timing != 0))) return rc;
-    ENSURE(ctx, ctx->flag, 16 * W3_MAX_PARTS);
+    w3_timing ptm;
+    memset(&ptm, 0, sizeof ptm);
     bool cap_raised = false, fault_seen = false;
     uint32_t lds_faults = 0;
     for (int attempt = 0; attempt < 4; attempt++) {
-        ENSURE(ctx, ctx->stripes, (size_t)nb * cap);
-        HIPCHK(ctx, hipMemsetAsync(ctx->flag.p, 0, 16 * W3_MAX_PARTS, s));
-        tm.start(3);
-        uint32_t fl[4 * W3_MAX_PARTS];
-        memset(fl, 0, sizeof fl);
+        ENSURE(ctx, J.stripes, (size_t)nb * cap);
+        HIPCHK(ctx, hipMemsetAsync(J.flag.p, 0, 16, s));
+        if (evp) HIPCHK(ctx, hipEventRecord(evp[2 * W3_EV_TOTAL], s));
+        uint32_t fl[4] = {0, 0, 0, 0};
         if (two) {
-            if (parts > 1) HIPCHK(ctx, hipEventRecord(ctx->ev_fork, s));
-            for (int p = 0; p < parts && !rc; p++) {
-                TwoPhaseWs &ws = p ? ctx->ranges[p - 1].ws : ctx->tp;
-                hipStream_t sp = p ? ctx->ranges[p - 1].stream : s;
-                hipEvent_t *evp = !ctx->opt_timing ? nullptr : p ? ctx->ranges[p - 1].ev : ctx->ev;
-                const size_t o = (size_t)pb[p] * block_size, np = std::min<size_t>(n, (size_t)pb[p + 1] * block_size) - o;
-                if (p) {   // after the call's earlier work on s, and once the previous range's predict kernels are through
-                    HIPCHK(ctx, hipStreamWaitEvent(sp, ctx->ev_fork, 0));
-                    HIPCHK(ctx, hipStreamWaitEvent(sp, ctx->ev_pred[p - 1], 0));
-                }
-                ws.use_hi = parts > 1 && !w3_tune_env("W3_NO_HI_STREAM");
-                ws.ev_pred_done = parts > 1 ? ctx->ev_pred[p] : nullptr;
-                ws.out_bits = (uint32_t *)ctx->bits.p + pb[p];
-                if (p && ctx->tp.lds_order >= 0) ws.lds_order = ctx->tp.lds_order;   // (range 0 has run the self-test)
-                rc = twophase_encode(ws, sp, ps, d_in + o, np, block_size, pb[p + 1] - pb[p], (uint8_t *)ctx->stripes.p + (size_t)pb[p] * cap, cap,
-                                     d_block_lens + pb[p], (uint32_t *)ctx->flag.p + 4 * p, evp, &ptm[p], ctx->err);
-                ws.ev_pred_done = nullptr;
-                if (p && !rc) { HIPCHK(ctx, hipEventRecord(ctx->ranges[p - 1].ev_done, sp)); HIPCHK(ctx, hipStreamWaitEvent(s, ctx->ranges[p - 1].ev_done, 0)); }
-            }
-            if (rc) {   // leave no range running behind an error return
-                if (parts > 1) (void)hipDeviceSynchronize();
-                return rc;
-            }
+            J.tp.out_bits = (uint32_t *)J.bits.p;
+            memset(&ptm, 0, sizeof ptm);
+            rc = twophase_encode(J.tp, s, s, ps, d_in, n, block_size, nb, (uint8_t *)J.stripes.p, cap, d_block_lens, (uint32_t *)J.flag.p, evp, &ptm, ctx->err);
+            if (rc) return rc;
             ctx->timing.path = W3_PATH_TWOPHASE;
         } else {
-            tm.start(0);
+            if (evp) HIPCHK(ctx, hipEventRecord(evp[2 * W3_EV_PREDICT], s));
             rc = ps.is_cm() ? cm_encode(ctx, s, ps, d_in, n, block_size, nb, cap, d_block_lens)
                             : generic_encode(ctx, s, ps, d_in, n, block_size, nb, cap, d_block_lens);
-            tm.stop();
+            if (evp) HIPCHK(ctx, hipEventRecord(evp[2 * W3_EV_PREDICT + 1], s));
             ctx->timing.path = W3_PATH_GENERIC;
             if (rc) return rc;
         }
-        HIPCHK(ctx, hipMemcpyAsync(fl, ctx->flag.p, sizeof fl, hipMemcpyDeviceToHost, s));
+        HIPCHK(ctx, hipMemcpyAsync(fl, J.flag.p, sizeof fl, hipMemcpyDeviceToHost, s));
         HIPCHK(ctx, hipStreamSynchronize(s));
-        {   // sampled verification of the LDS-add rounds (twophase_verify): a mismatch means the hardware did not resolve returning LDS
+        if (two && fl[2]) {
+            // sampled verification of the LDS-add rounds (twophase_verify): a mismatch means the hardware did not resolve returning LDS
             // adds in lane order under this load.  The streams just coded cannot be trusted: code the call again with the ballot
             // rounds, and keep this context on them.
-            uint32_t mism = 0;
-            for (int p = 0; p < parts && two; p++) mism += fl[4 * p + 2];
-            if (mism) {
-                if (fault_seen) { ctx->err = "predict streams differ from their ballot-round re-prediction even without LDS-add rounds (internal error)"; return W3_E_HIP; }
-                fault_seen = true;
-                lds_faults += mism;
-                ctx->tp.variant |= W3_VAR_NO_LDS_ATOMICS; ctx->tp.lds_order = 0;
-                for (auto &r : ctx->ranges) { r.ws.variant |= W3_VAR_NO_LDS_ATOMICS; r.ws.lds_order = 0; }
-                ctx->timing.n_recoded_blocks = 0;
-                continue;
-            }
+            if (fault_seen) { ctx->err = "predict streams differ from their ballot-round re-prediction even without LDS-add rounds (internal error)"; return W3_E_HIP; }
+            fault_seen = true;
+            lds_faults += fl[2];
+            ctx->tp.variant |= W3_VAR_NO_LDS_ATOMICS; ctx->tp.lds_order = 0;
+            ctx->j1.tp.variant |= W3_VAR_NO_LDS_ATOMICS; ctx->j1.tp.lds_order = 0;
+            ctx->timing.n_recoded_blocks = 0;
+            continue;
         }
-        bool recoded = false;
-        for (int p = 0; p < parts && two; p++) {
-            if (!fl[4 * p + 1]) continue;   // blocks the fast coder handed back (pending-bit run longer than its accumulator)
-            TwoPhaseWs &ws = p ? ctx->ranges[p - 1].ws : ctx->tp;
-            const size_t o = (size_t)pb[p] * block_size, np = std::min<size_t>(n, (size_t)pb[p + 1] * block_size) - o;
-            ctx->timing.n_recoded_blocks += fl[4 * p + 1];
-            rc = twophase_recode(ws, s, d_in + o, np, block_size, pb[p + 1] - pb[p], (uint8_t *)ctx->stripes.p + (size_t)pb[p] * cap, cap,
-                                 d_block_lens + pb[p], (uint32_t *)ctx->flag.p + 4 * p, fl[4 * p + 1], ctx->err);
+        if (two && fl[1]) {   // blocks the fast coder handed back (pending-bit run longer than its accumulator)
+            ctx->timing.n_recoded_blocks += fl[1];
+            rc = twophase_recode(J.tp, s, d_in, n, block_size, nb, (uint8_t *)J.stripes.p, cap, d_block_lens, (uint32_t *)J.flag.p, fl[1], ctx->err);
             if (rc) return rc;
-            recoded = true;
-        }
-        if (recoded) {
-            HIPCHK(ctx, hipMemcpyAsync(fl, ctx->flag.p, sizeof fl, hipMemcpyDeviceToHost, s));
+            HIPCHK(ctx, hipMemcpyAsync(fl, J.flag.p, sizeof fl, hipMemcpyDeviceToHost, s));
             HIPCHK(ctx, hipStreamSynchronize(s));
         }
-        uint32_t f0 = 0;
-        for (int p = 0; p < parts; p++) f0 |= fl[4 * p];
-        if (f0 & 2u) { ctx->err = "coder pipeline timeout (internal error)"; return W3_E_HIP; }
-        const uint32_t ovf = f0 & 1u;
-        if (!ovf) break;
+        if (fl[0] & 2u) { ctx->err = "coder pipeline timeout (internal error)"; return W3_E_HIP; }
+        if (!(fl[0] & 1u)) break;
         if (cap_raised) { ctx->err = "stripe overflow at the worst-case bound (internal error)"; return W3_E_HIP; }
         cap = worst_stripe_cap(block_size);  // rare: a block expanded past 2N+64
         cap_raised = true;
         ctx->timing.n_recoded_blocks = 0;
     }
     ctx->timing.n_lds_faults = lds_faults;
-    Timer tp{ctx, s, 0};
     uint64_t total = 0;
     if (d_out) {
-        tp.start(2);
-        rc = run_pack(ctx, s, (const uint8_t *)ctx->stripes.p, cap, d_block_lens, nb, d_out, out_cap, total_p);
-        tp.stop();
-        tm.i = 3; tm.stop();
+        if (evp) HIPCHK(ctx, hipEventRecord(evp[2 * W3_EV_PACK], s));
+        rc = run_pack(ctx, J, s, (const uint8_t *)J.stripes.p, cap, d_block_lens, nb, d_out, out_cap, total_p);
+        if (evp) { HIPCHK(ctx, hipEventRecord(evp[2 * W3_EV_PACK + 1], s)); HIPCHK(ctx, hipEventRecord(evp[2 * W3_EV_TOTAL + 1], s)); }
         if (rc) return rc;
         HIPCHK(ctx, hipMemcpyAsync(&total, total_p, 8, hipMemcpyDeviceToHost, s));
         HIPCHK(ctx, hipStreamSynchronize(s));
-    } else { tm.i = 3; tm.stop(); HIPCHK(ctx, hipStreamSynchronize(s)); }
+    } else {
+        if (evp) HIPCHK(ctx, hipEventRecord(evp[2 * W3_EV_TOTAL + 1], s));
+        HIPCHK(ctx, hipStreamSynchronize(s));
+    }
     if (two) {
-        for (int p = 0; p < parts; p++) {
-            ctx->timing.coder_bytes += ptm[p].coder_bytes; ctx->timing.predict_bytes += ptm[p].predict_bytes;
-            ctx->timing.n_coder_launches += ptm[p].n_coder_launches; ctx->timing.n_slot_launches += ptm[p].n_slot_launches;
-        }
-        ctx->timing.coder_bytes += total;
+        ctx->timing.coder_bytes = ptm.coder_bytes + total; ctx->timing.predict_bytes = ptm.predict_bytes;
+        ctx->timing.n_coder_launches = ptm.n_coder_launches; ctx->timing.n_slot_launches = ptm.n_slot_launches;
     }
-    if (ctx->opt_timing) {
-        if (!two) ctx->timing.generic_ms = elapsed(ctx, 0);
-        else {
-            for (int p = 0; p < parts; p++) {   // sums over the ranges (their kernels overlap in time)
-                hipEvent_t *evp = p ? ctx->ranges[p - 1].ev : ctx->ev;
-                const TwoPhaseWs &ws = p ? ctx->ranges[p - 1].ws : ctx->tp;
-                ctx->timing.predict_ms += elapsed_ev(evp, 0); ctx->timing.coder_ms += elapsed_ev(evp, 1);
-                if (ps.n_apm) ctx->timing.apm_ms += elapsed_ev(evp, 4);
-                if (ps.has_slot) ctx->timing.slot_ms += elapsed_ev(evp, 5);
-                if (ws.achash_timed) ctx->timing.achash_ms += elapsed_ev(evp, 6);
-            }
-        }
-        ctx->timing.pack_ms = d_out ? elapsed(ctx, 2) : 0.f;
-        ctx->timing.total_ms = elapsed(ctx, 3);
+    if (evp) {
+        if (!two) { ctx->timing.generic_ms = elapsed_ev(evp, W3_EV_PREDICT); ctx->timing.pack_ms = d_out ? elapsed_ev(evp, W3_EV_PACK) : 0.f; ctx->timing.total_ms = elapsed_ev(evp, W3_EV_TOTAL); }
+        else collect_timing(evp, J.tp, ps.n_apm > 0, ps.has_slot, d_out != nullptr, ctx->timing);
     }
-    ctx->timing.n_parts = (uint32_t)parts;
+    ctx->timing.n_parts = 1;
     if (d_out && total > out_cap) { ctx->err = "out_cap too small"; return W3_E_NOSPACE; }
+    return W3_OK;
+}
+
+static int jobs_idle(w3_ctx *ctx) {
+    if (ctx->js[0].state == 1 || ctx->js[1].state == 1) { ctx->err = "asynchronous jobs are in flight on this context: w3_encode_wait them first"; return W3_E_INVALID; }
     return W3_OK;
 }
 
 extern "C" int w3_encode_blocks_device(w3_ctx *ctx, const w3_model_spec *spec, const uint8_t *d_in, size_t n, size_t block_size,
                                        uint8_t *d_out, size_t out_cap, uint32_t *d_block_lens, uint64_t *d_total, void *stream) {
+    if (!ctx) return W3_E_INVALID;
     if (n && !d_out) return W3_E_INVALID;
-    return encode_core(ctx, spec, d_in, n, block_size, d_out, out_cap, d_block_lens, d_total, stream);
+    int rc = jobs_idle(ctx);
+    if (rc) return rc;
+    return encode_core(ctx, jobref(ctx, 0), spec, d_in, n, block_size, d_out, out_cap, d_block_lens, d_total, stream);
+}
+
+// ---------------------------------------------------------------------------
+// submit / wait: up to two encodes in flight on one context (main.rs:103-109 run for call k+1's predict phase while call k is
+// still being coded).  Each job has its own workspace; the predict phases follow each other on one stream, the APM + coder +
+// pack stages on another, so in steady state the chip always holds one call's predict kernels and the previous call's APM
+// or coder kernel — in the half-CU shapes (w3_predict.h, w3_coder5.h) that let the two share every CU.
+// ---------------------------------------------------------------------------
+static int ensure_pipeline(w3_ctx *ctx) {
+    // The two stages must not share a hardware queue (HIP maps streams onto GPU_MAX_HW_QUEUES = 4 queues per priority level by
+    // default, round-robin: two streams of one level can land on the same queue and then run one after the other).  Streams of
+    // different PRIORITY levels use different queues: the code stage — it carries the latency chain — gets the high level.
+    if (!ctx->s_pred || !ctx->s_code) {
+        int lo_p = 0, hi_p = 0;
+        HIPCHK(ctx, hipDeviceGetStreamPriorityRange(&lo_p, &hi_p));
+        const bool pred_high = (ctx->tp.tune & 1u) != 0;   // W3_OPT_TUNE bit 0
+        if (!ctx->s_pred) HIPCHK(ctx, hipStreamCreateWithPriority(&ctx->s_pred, hipStreamNonBlocking, pred_high ? hi_p : 0));
+        if (!ctx->s_code) HIPCHK(ctx, hipStreamCreateWithPriority(&ctx->s_code, hipStreamNonBlocking, (pred_high || (ctx->tp.tune & 16u)) ? 0 : hi_p));
+    }
+    for (int j = 0; j < 2; j++) {
+        JobState &st = ctx->js[j];
+        if (!st.ev_done) HIPCHK(ctx, hipEventCreateWithFlags(&st.ev_done, hipEventDisableTiming));
+        if (!st.ev_in) HIPCHK(ctx, hipEventCreateWithFlags(&st.ev_in, hipEventDisableTiming));
+        if (!st.ev_a) HIPCHK(ctx, hipEventCreateWithFlags(&st.ev_a, hipEventDisableTiming));
+        if (!st.ev_apm) HIPCHK(ctx, hipEventCreateWithFlags(&st.ev_apm, hipEventDisableTiming));
+        if (!st.h_status) HIPCHK(ctx, hipHostMalloc((void **)&st.h_status, 32, hipHostMallocDefault));
+        for (auto &e : ctx->j1.ev)
+            if (!e) HIPCHK(ctx, hipEventCreate(&e));
+    }
+    return W3_OK;
+}
+
+// APM stages + coder + pack + status read-back of an enqueued job, on the code stream
+static int enqueue_code(w3_ctx *ctx, JobRef &J, hipEvent_t wait_ev, hipEvent_t rec_after_apm) {
+    JobState &st = J.st;
+    hipStream_t sp = ctx->s_pred, sc = ctx->s_code;
+    hipEvent_t *evp = st.timed ? J.ev : nullptr;
+    int rc = tp_code_stage(J.tp, sp, sc, st.ps, st.d_in, st.n, st.block_size, st.nb, (uint8_t *)J.stripes.p, st.cap, st.d_block_lens, (uint32_t *)J.flag.p,
+                           wait_ev, rec_after_apm, evp, &st.tm, ctx->err);
+    if (rc) return rc;
+    if (evp) HIPCHK(ctx, hipEventRecord(evp[2 * W3_EV_PACK], sc));
+    rc = run_pack(ctx, J, sc, (const uint8_t *)J.stripes.p, st.cap, st.d_block_lens, st.nb, st.d_out, st.out_cap, st.d_total);
+    if (evp) { HIPCHK(ctx, hipEventRecord(evp[2 * W3_EV_PACK + 1], sc)); HIPCHK(ctx, hipEventRecord(evp[2 * W3_EV_TOTAL + 1], sc)); }
+    if (rc) return rc;
+    HIPCHK(ctx, hipMemcpyAsync(st.h_status, J.flag.p, 16, hipMemcpyDeviceToHost, sc));
+    HIPCHK(ctx, hipMemcpyAsync(st.h_status + 4, st.d_total, 8, hipMemcpyDeviceToHost, sc));
+    HIPCHK(ctx, hipEventRecord(st.ev_done, sc));
+    st.code_pending = false;
+    return W3_OK;
+}
+
+extern "C" int w3_encode_submit(w3_ctx *ctx, const w3_model_spec *spec, const uint8_t *d_in, size_t n, size_t block_size,
+                                uint8_t *d_out, size_t out_cap, uint32_t *d_block_lens, uint64_t *d_total, void *stream, int *job) {
+    if (!ctx || !job) return W3_E_INVALID;
+    *job = -1;
+    int rc = check_args(ctx, n, block_size);
+    if (rc) return rc;
+    if (n && (!d_out || !d_in || !d_block_lens)) return W3_E_INVALID;
+    if (!d_total) { ctx->err = "w3_encode_submit needs d_total"; return W3_E_INVALID; }
+    ParsedSpec ps;
+    if ((rc = parse_spec(spec, ps))) { ctx->err = "malformed model spec"; return rc; }
+    const int j = ctx->next_job;
+    if (ctx->js[j].state != 0) { ctx->err = "two jobs are in flight already: w3_encode_wait the older one first"; return W3_E_INVALID; }
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const uint32_t nb = (uint32_t)((n + block_size - 1) / block_size);
+    const bool two = nb > 0 && twophase_supported(ps, block_size, n) && ctx->opt_path != W3_PATH_GENERIC;
+    if (!two || ps.has_slot) {
+        // Not pipelined: the lane-per-block kernels (any spec the predict kernels do not cover) and specs with slot-state leaves
+        // (their hash maps are sized from the memory that is free at the time) run to completion here, on job 0's workspace.
+        if (ctx->js[0].state == 1 || ctx->js[1].state == 1) {   // let the other job's kernels finish first; its status is in pinned memory already
+            const JobState &o = ctx->js[ctx->js[0].state == 1 ? 0 : 1];
+            HIPCHK(ctx, hipEventSynchronize(o.ev_done));
+        }
+        rc = encode_core(ctx, jobref(ctx, 0), spec, d_in, n, block_size, d_out, out_cap, d_block_lens, d_total, stream);
+        if (rc) return rc;
+        ctx->js[j].state = 2; ctx->js[j].tm = ctx->timing;
+        *job = j; ctx->next_job = j ^ 1;
+        return W3_OK;
+    }
+    if ((rc = ensure_pipeline(ctx))) return rc;
+    JobRef J = jobref(ctx, j);
+    JobState &st = J.st;
+    // keep the call (the spec and its HuffHistory tables are the caller's memory)
+    st.spec = *spec;
+    if (ps.n_huff) { memcpy(st.huff_copy, ps.huff, sizeof(w3_huff_table) * ps.n_huff); st.spec.huff = st.huff_copy; ps.huff = st.huff_copy; }
+    st.ps = ps;
+    st.d_in = d_in; st.n = n; st.block_size = block_size; st.d_out = d_out; st.out_cap = out_cap; st.d_block_lens = d_block_lens; st.d_total = d_total;
+    st.has_apm = ps.n_apm > 0; st.has_slot = false; st.timed = ctx->opt_timing != 0;
+    st.nb = nb;
+    memset(&st.tm, 0, sizeof st.tm);
+    hipStream_t sp = ctx->s_pred;
+    // after whatever produced d_in on the caller's stream
+    hipStream_t s_in = stream ? (hipStream_t)stream : ctx->stream;
+    HIPCHK(ctx, hipEventRecord(st.ev_in, s_in));
+    HIPCHK(ctx, hipStreamWaitEvent(sp, st.ev_in, 0));
+    ENSURE(ctx, J.flag, 16);
+    ENSURE(ctx, J.bits, (size_t)nb * 4);
+    if ((rc = stage_huff_job(ctx, J, sp, ps))) return rc;
+    if (ps.is_cm()) {
+        CmArgs lut;
+        if ((rc = cm_luts(ctx, sp, lut))) return rc;
+        ctx->tp.stretch = lut.stretch; ctx->tp.squash = lut.squash; ctx->tp.st = lut.st;
+    }
+    sync_job_options(ctx, J);
+    J.tp.half_cu = !(ctx->tp.variant & W3_VAR_FULL_CU);
+    st.cap = default_stripe_cap(block_size);
+    ENSURE(ctx, J.stripes, (size_t)nb * st.cap);
+    hipEvent_t *evp = st.timed ? J.ev : nullptr;
+    HIPCHK(ctx, hipMemsetAsync(J.flag.p, 0, 16, sp));
+    if (evp) HIPCHK(ctx, hipEventRecord(evp[2 * W3_EV_TOTAL], sp));
+    J.tp.out_bits = (uint32_t *)J.bits.p;
+    // The order in which the two jobs' kernels reach the chip (measured, profiles/r3_pipeline/: kernels that fill the LDS — the
+    // partition passes, the time-ordered leaves, k_apm0 — only slow each other down when they share CUs; the rank kernels, bound
+    // by their scattered stores, and the coder, one latency chain per lane, run well side by side):
+    //     first predict half of THIS job  ->  APM stages of the OTHER job  ->  coder of the other job  BESIDE  rank kernels of this job
+    // So the other job's code stage is enqueued here, between this job's two predict halves (W3_OPT_TUNE bit 2: no such order).
+    const bool ordered = !(ctx->tp.tune & 4u);
+    JobRef O = jobref(ctx, j ^ 1);
+    rc = twophase_predict_a(J.tp, sp, ps, d_in, n, block_size, nb, evp, ctx->err, ordered);
+    if (!rc && ordered) {
+        HIPCHK(ctx, hipEventRecord(st.ev_a, sp));
+        if (O.st.state == 1 && O.st.code_pending) {
+            rc = enqueue_code(ctx, O, st.ev_a, O.st.ev_apm);
+            if (!rc) HIPCHK(ctx, hipStreamWaitEvent(sp, O.st.ev_apm, 0));
+        }
+    }
+    if (!rc) rc = twophase_predict_b(J.tp, sp, ps, d_in, n, block_size, nb, tp_plan(J.tp, ps).need_P, nullptr, evp, &st.tm, ctx->err);
+    if (!rc) rc = tp_after_predict(J.tp, sp, ps, d_in, n, block_size, nb, (uint32_t *)J.flag.p, ctx->err);
+    if (!rc) {
+        st.state = 1; st.code_pending = true;
+        if (!ordered) rc = enqueue_code(ctx, J, nullptr, nullptr);
+    }
+    if (rc) {   // leave nothing of either job running behind an error return
+        (void)hipDeviceSynchronize();
+        st.state = 0; st.code_pending = false;
+        return rc;
+    }
+    *job = j; ctx->next_job = j ^ 1;
+    return W3_OK;
+}
+
+extern "C" int w3_encode_wait(w3_ctx *ctx, int job) {
+    if (!ctx || job < 0 || job > 1) return W3_E_INVALID;
+    JobRef J = jobref(ctx, job);
+    JobState &st = J.st;
+    if (st.state == 0) { ctx->err = "no such job in flight"; return W3_E_INVALID; }
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    if (st.state == 2) { st.state = 0; ctx->timing = st.tm; return W3_OK; }
+    if (st.code_pending) {   // no later submit has placed this job's code stage: it goes out now
+        const int rc = enqueue_code(ctx, J, nullptr, nullptr);
+        if (rc) { (void)hipDeviceSynchronize(); st.state = 0; st.code_pending = false; return rc; }
+    }
+    HIPCHK(ctx, hipEventSynchronize(st.ev_done));
+    st.state = 0;
+    const uint32_t f0 = st.h_status[0], redo = st.h_status[1], mism = st.h_status[2];
+    uint64_t total;
+    memcpy(&total, st.h_status + 4, 8);
+    if ((f0 & 2u) && !mism) { ctx->err = "coder pipeline timeout (internal error)"; return W3_E_HIP; }
+    if (f0 || redo || mism) {
+        // Rare: a stripe overflowed the 2N+64 bound, the fast coder handed blocks back, or the sampled verification saw the LDS-add
+        // rounds misbehave.  Let the other job's kernels finish (its output is complete then, its status in pinned memory) and
+        // run this call again synchronously on this job's workspace: encode_core's own retry loop deals with each case.
+        HIPCHK(ctx, hipDeviceSynchronize());
+        if (mism) { ctx->tp.variant |= W3_VAR_NO_LDS_ATOMICS; ctx->tp.lds_order = 0; ctx->j1.tp.variant |= W3_VAR_NO_LDS_ATOMICS; ctx->j1.tp.lds_order = 0; }
+        const int rc = encode_core(ctx, J, &st.spec, st.d_in, st.n, st.block_size, st.d_out, st.out_cap, st.d_block_lens, st.d_total, ctx->stream);
+        ctx->timing.n_lds_faults += mism;
+        return rc;
+    }
+    memset(&ctx->timing, 0, sizeof ctx->timing);
+    ctx->timing.path = W3_PATH_TWOPHASE;
+    ctx->timing.coder_bytes = st.tm.coder_bytes + total; ctx->timing.predict_bytes = st.tm.predict_bytes;
+    ctx->timing.n_coder_launches = st.tm.n_coder_launches; ctx->timing.n_slot_launches = st.tm.n_slot_launches;
+    ctx->timing.n_parts = 1;
+    if (st.timed) collect_timing(J.ev, J.tp, st.has_apm, st.has_slot, true, ctx->timing);
+    if (total > st.out_cap) { ctx->err = "out_cap too small"; return W3_E_NOSPACE; }
+    return W3_OK;
 }
 
 // ---------------------------------------------------------------------------
@@ -778,7 +940,8 @@ extern "C" int w3_encode_stats_device(w3_ctx *ctx, const w3_model_spec *spec, co
     if (!d_in || !d_block_bits) return W3_E_INVALID;
     HIPCHK(ctx, hipSetDevice(ctx->device));
     ENSURE(ctx, ctx->lens, nb * 4);
-    rc = encode_core(ctx, spec, d_in, n, block_size, nullptr, 0, (uint32_t *)ctx->lens.p, nullptr, stream);
+    if ((rc = jobs_idle(ctx))) return rc;
+    rc = encode_core(ctx, jobref(ctx, 0), spec, d_in, n, block_size, nullptr, 0, (uint32_t *)ctx->lens.p, nullptr, stream);
     if (rc) return rc;
     hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
     HIPCHK(ctx, hipMemcpyAsync(d_block_bits, ctx->bits.p, nb * 4, hipMemcpyDeviceToDevice, s));
@@ -796,7 +959,8 @@ extern "C" int w3_encode_stats(w3_ctx *ctx, const w3_model_spec *spec, const uin
     ENSURE(ctx, ctx->io_in, n);
     ENSURE(ctx, ctx->lens, nb * 4);
     HIPCHK(ctx, hipMemcpyAsync(ctx->io_in.p, in, n, hipMemcpyHostToDevice, ctx->stream));
-    rc = encode_core(ctx, spec, (const uint8_t *)ctx->io_in.p, n, block_size, nullptr, 0, (uint32_t *)ctx->lens.p, nullptr, ctx->stream);
+    if ((rc = jobs_idle(ctx))) return rc;
+    rc = encode_core(ctx, jobref(ctx, 0), spec, (const uint8_t *)ctx->io_in.p, n, block_size, nullptr, 0, (uint32_t *)ctx->lens.p, nullptr, ctx->stream);
     if (rc) return rc;
     HIPCHK(ctx, hipMemcpy(block_bits, ctx->bits.p, nb * 4, hipMemcpyDeviceToHost));
     return W3_OK;
@@ -898,7 +1062,11 @@ extern "C" int w3_shard_range(size_t nblocks, int world, int rank, size_t *first
 extern "C" int w3_encode_blocks_sharded(w3_ctx *const *ctxs, int n_ctx, const w3_model_spec *spec, const uint8_t *in, size_t n, size_t block_size,
                                         uint8_t *out, size_t out_cap, size_t *out_len, uint32_t *block_lens) {
     if (!ctxs || n_ctx <= 0 || !out_len) return W3_E_INVALID;
-    for (int r = 0; r < n_ctx; r++) if (!ctxs[r]) return W3_E_INVALID;
+    for (int r = 0; r < n_ctx; r++) {
+        if (!ctxs[r]) return W3_E_INVALID;
+        for (int q = 0; q < r; q++)
+            if (ctxs[q] == ctxs[r]) { ctxs[0]->err = "the same context appears twice in ctxs[] (a context is not thread-safe)"; return W3_E_INVALID; }
+    }
     *out_len = 0;
     int rc = check_args(ctxs[0], n, block_size);
     if (rc) return rc;
@@ -1107,7 +1275,7 @@ extern "C" int w3_export_counters(w3_ctx *ctx, const w3_model_spec *spec, const 
     ENSURE(ctx, ctx->io_in, n);
     ENSURE(ctx, ctx->stripes, cap);
     ENSURE(ctx, ctx->lens, 4);
-    ENSURE(ctx, ctx->flag, 16 * W3_MAX_PARTS);
+    ENSURE(ctx, ctx->flag, 16);
     HIPCHK(ctx, hipMemcpyAsync(ctx->io_in.p, in, n, hipMemcpyHostToDevice, s));
     HIPCHK(ctx, hipMemsetAsync(ctx->tables.p, 0, entries * 4, s));
     ga.n = n; ga.block_size = (uint32_t)n; ga.first_block = 0; ga.n_lanes = 1;

@@ -3,6 +3,7 @@ src/mixers): same names and argument meaning, but each object only DESCRIBES a
 model — it builds the w3_model_spec the HIP kernels execute.  There is no
 per-bit Python arithmetic here; predict/update happen on the GPU."""
 import ctypes as C
+import threading
 
 import numpy as np
 
@@ -118,7 +119,8 @@ class HuffHistory:
 
 class Model:
     """trait Model (models/mod.rs:12-15), as a spec tree."""
-    _cur_huff_index = {}
+    _tls = threading.local()   # .huff_index: HuffHistory object -> slot in w3_model_spec::huff while spec() walks the tree (per thread:
+                               # several contexts may build specs from several host threads at once)
 
     def _nodes(self):
         raise NotImplementedError
@@ -134,11 +136,11 @@ class Model:
                 huffs.append(h)
         if len(huffs) > L.W3_MAX_HUFF:
             raise W3Error(L.W3_E_UNSUPPORTED, "more than %d HuffHistory table sets" % L.W3_MAX_HUFF)
-        Model._cur_huff_index = {id(h): i for i, h in enumerate(huffs)}   # read by AdaptiveModel._leaf while the tree is walked
+        Model._tls.huff_index = {id(h): i for i, h in enumerate(huffs)}   # read by AdaptiveModel._leaf while the tree is walked
         try:
             nodes = self._nodes()
         finally:
-            Model._cur_huff_index = {}
+            Model._tls.huff_index = {}
         if len(nodes) > L.W3_MAX_NODES:
             raise W3Error(L.W3_E_UNSUPPORTED, "model tree too large")
         s = L.ModelSpec()
@@ -179,7 +181,7 @@ class AdaptiveModel(Model):
             return _leaf(self.bits, self.align, frozen=frozen)
         nd = _leaf(self.bits, self.align, h.kind, h.max_bits, h.table, frozen=frozen)
         if h.kind == L.W3_HIST_HUFF:
-            nd.reserved = Model._cur_huff_index.get(id(h), 0)
+            nd.reserved = getattr(Model._tls, "huff_index", {}).get(id(h), 0)
         return nd
 
     def _huff_sets(self):
