@@ -219,6 +219,25 @@ int w3_encode_blocks_sharded(w3_ctx *const *ctxs, int n_ctx, const w3_model_spec
                              const uint8_t *in, size_t n, size_t block_size,
                              uint8_t *out, size_t out_cap, size_t *out_len, uint32_t *block_lens);
 
+/* The same with the data RESIDENT ON THE DEVICES and the gather over xGMI — BASELINE.json's "RCCL gather over xGMI to concatenate
+ * per-GPU compressed streams" for a host that is not a torch.distributed program (the reference has no counterpart: it is one
+ * thread, Cargo.toml:14-15).  d_in[r] (on ctxs[r]'s device) holds shard r: the bytes of the block range w3_shard_range(nblocks,
+ * n_ctx, r) of one stream, n[r] of them (a whole number of blocks for every shard but the last).  The shards are encoded
+ * concurrently (one host thread per context); then ONE exchange step: an all-gather of the ranks' totals and, at the offsets of
+ * their exclusive scan, grouped ncclSend / ncclRecv of the packed streams and length tables straight to the root's d_out /
+ * d_block_lens (device pointers on ctxs[root]'s GPU; every peer has its own xGMI link to the root, so the transfers overlap).
+ * totals[r] (host) = compressed bytes of shard r; W3_E_NOSPACE when their sum exceeds out_cap.
+ * transport: W3_GATHER_AUTO = RCCL when every context has its own device, device copies otherwise; W3_GATHER_RCCL forces the
+ * communicator path (one rank is allowed: that is how a 1-GPU box rehearses the RCCL calls); W3_GATHER_PEER_COPY =
+ * hipMemcpyPeerAsync from the root's stream.  RCCL is resolved at the first use (dlopen "librccl.so.1"): libw3hip.so itself
+ * does not link it, and W3_E_HIP with w3_last_error(ctxs[0]) = "RCCL not available ..." is returned when it is missing.
+ * Output identical to w3_encode_blocks_device on one context over the concatenated shards.                               */
+enum { W3_GATHER_AUTO = 0, W3_GATHER_RCCL = 1, W3_GATHER_PEER_COPY = 2 };
+int w3_encode_blocks_sharded_device(w3_ctx *const *ctxs, int n_ctx, const w3_model_spec *spec,
+                                    const uint8_t *const *d_in, const size_t *n, size_t block_size, int root,
+                                    uint8_t *d_out, size_t out_cap, uint32_t *d_block_lens,
+                                    uint64_t *totals, int transport);
+
 /* ---- ACStats, the counting sink (helpers.rs:60-90) -------------------------------
  * Every figure the reference publishes is `csize = bits / 8` from this sink (bin/ordern/main.rs:66-80): write_bit counts
  * 1 + the pending parity bits it resolves, flush adds nothing (:87-89).  block_bits[b] = that count for block b coded

@@ -214,6 +214,52 @@ def test_sharded_encode_from_one_process(oracle):
             c.close()
 
 
+def test_sharded_encode_device_resident_gather(oracle):
+    """w3_encode_blocks_sharded_device: shards resident on the devices, streams and length table gathered on the root's device.
+    On the 1-GPU box: three contexts on the one device (device-copy transport; ranges may be empty), and ONE context through the
+    RCCL transport (ncclCommInitAll with one rank + the sizes all-gather: the lazily resolved librccl really loads and runs).
+    Output identical to the single-context call over the concatenated shards."""
+    import ctypes as C
+    import torch
+    from weath3rb0i_amd import _lib as L
+    cs = [w3.Context(0) for _ in range(3)]
+    try:
+        bs = 4096
+        model = w3.BestOfTwoModel(w3.Order0(), w3.Order1())
+        for n in (150000, 4096 * 2 + 5, 100):
+            data = np.frombuffer(markov_text(n, seed=28), dtype=np.uint8).copy()
+            nb = (n + bs - 1) // bs
+            want, wlens = cs[0].encode_blocks(model, data, bs)
+            d_out = torch.empty(2 * n + 64 * nb + 64, dtype=torch.uint8, device="cuda")
+            d_lens = torch.zeros(nb, dtype=torch.int32, device="cuda")
+            for k, transport, root in ((3, "auto", 0), (3, "peer_copy", 2), (1, "rccl", 0)):
+                d_out.zero_(); d_lens.zero_()
+                shards = []
+                for r in range(k):
+                    b0, b1 = C.c_size_t(), C.c_size_t()
+                    assert cs[0].lib.w3_shard_range(nb, k, r, C.byref(b0), C.byref(b1)) == 0
+                    shards.append(torch.from_numpy(data[min(b0.value * bs, n):min(b1.value * bs, n)].copy()).cuda())
+                torch.cuda.synchronize()
+                totals = w3.encode_blocks_sharded_device(cs[:k], model, shards, bs, d_out, d_lens, root=root, transport=transport)
+                assert sum(totals) == len(want), (n, k, transport)
+                assert d_lens.cpu().numpy().astype(np.uint32).tolist() == wlens.tolist(), (n, k, transport)
+                assert d_out[: len(want)].cpu().numpy().tobytes() == want.tobytes(), (n, k, transport)
+        # errors: RCCL transport with contexts that share a device; a middle shard that is not a whole number of blocks; out_cap
+        shards = [torch.zeros(4096, dtype=torch.uint8, device="cuda"), torch.zeros(100, dtype=torch.uint8, device="cuda")]
+        with pytest.raises(w3.W3Error) as e:
+            w3.encode_blocks_sharded_device(cs[:2], model, shards, bs, d_out, d_lens, transport="rccl")
+        assert e.value.code == L.W3_E_INVALID
+        with pytest.raises(w3.W3Error) as e:
+            w3.encode_blocks_sharded_device(cs[:2], model, shards[::-1], bs, d_out, d_lens)
+        assert e.value.code == L.W3_E_INVALID
+        with pytest.raises(w3.W3Error) as e:
+            w3.encode_blocks_sharded_device(cs[:2], model, shards, bs, d_out[:3], d_lens)
+        assert e.value.code == L.W3_E_NOSPACE
+    finally:
+        for c in cs:
+            c.close()
+
+
 def test_sampled_verification_catches_misordered_lds_adds(oracle):
     """VERDICT r1 #5 / ADVICE: the default predict kernels rely on returning LDS adds resolving in lane order (measured, not in
     the ISA manual).  Every call re-predicts sampled blocks with ballot rounds and compares (W3_OPT_VERIFY).  With the fault

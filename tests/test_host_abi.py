@@ -32,6 +32,23 @@ def test_exports_match_header(lib):
     assert lib.w3_abi_version() == int(m.group(1)) == 6
 
 
+def test_integration_doc_binds_every_export():
+    """INTEGRATION.md's `extern "C"` block (the binding a maintainer of the reference crate would add) names every entry point the
+    header declares, and its #[repr(C)] twin of w3_timing has the header's fields in order."""
+    hdr = open(os.path.join(ROOT, "include", "w3hip.h")).read()
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    block = doc[doc.index('extern "C" {'):doc.index("/// The crate's model types describe themselves")]
+    declared = set(re.findall(r"\b(w3_[a-z0-9_]+)\s*\(", re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)))
+    bound = set(re.findall(r"pub fn (w3_[a-z0-9_]+)\(", block))
+    assert declared == bound, (sorted(declared - bound), sorted(bound - declared))
+    tm = hdr[hdr.index("typedef struct w3_timing {"):hdr.index("} w3_timing;")]
+    tm = re.sub(r"/\*.*?\*/", "", tm, flags=re.S)
+    fields = re.findall(r"\b(?:float|uint32_t|uint64_t)\s+([a-z_0-9]+)(?:\[\d+\])?;", tm)
+    rust = doc[doc.index("pub struct W3Timing {"):doc.index("// w3_ctx_set_option: option ids")]
+    assert re.findall(r"pub ([a-z_0-9]+):", rust) == fields
+    assert fields == [f for f, _ in L.Timing._fields_]
+
+
 def test_struct_layout(lib):
     assert C.sizeof(L.Node) == 24
     assert C.sizeof(L.HuffTable) == 1536

@@ -16,6 +16,7 @@ W3_OK, W3_E_INVALID, W3_E_NOSPACE, W3_E_HIP, W3_E_UNSUPPORTED, W3_E_NOMEM, W3_E_
 W3_OPT_PATH, W3_OPT_TIMING, W3_OPT_CODER, W3_OPT_ACC_LIMIT, W3_OPT_DEBUG_STAMPS, W3_OPT_VARIANT, W3_OPT_SLOT_BUDGET_MB, W3_OPT_VERIFY, W3_OPT_FAULT_BLOCK, W3_OPT_TUNE = 1, 2, 3, 4, 5, 7, 8, 9, 10, 11
 W3_VAR_NO_LDS_ATOMICS, W3_VAR_PARTITION4, W3_VAR_NO_CHAINED_PARTITION, W3_VAR_CM_UNSTAGED, W3_VAR_NO_SIDE_STREAM, W3_VAR_INJECT_LDS_FAULT = 1, 2, 4, 8, 16, 32
 W3_VAR_HALF_CU, W3_VAR_FULL_CU = 64, 128
+W3_GATHER_AUTO, W3_GATHER_RCCL, W3_GATHER_PEER_COPY = 0, 1, 2
 W3_PATH_AUTO, W3_PATH_GENERIC, W3_PATH_TWOPHASE = 0, 1, 2
 
 
@@ -46,7 +47,7 @@ EXPORTS = [
     "w3_ctx_set_option", "w3_max_compressed_size", "w3_encode_blocks", "w3_decode_blocks", "w3_encode_blocks_device",
     "w3_decode_blocks_device", "w3_encode_submit", "w3_encode_wait", "w3_compress_stream", "w3_decompress_stream", "w3_predict_blocks", "w3_stationary_table",
     "w3_get_timing", "w3_selftest_counter_p", "w3_debug_get_stamps", "w3_state_table", "w3_stretch_squash", "w3_huff_tables",
-    "w3_shard_range", "w3_encode_blocks_sharded", "w3_encode_stats", "w3_encode_stats_device", "w3_sweep_ordern", "w3_sweep_ordern_device", "w3_export_counters",
+    "w3_shard_range", "w3_encode_blocks_sharded", "w3_encode_blocks_sharded_device", "w3_encode_stats", "w3_encode_stats_device", "w3_sweep_ordern", "w3_sweep_ordern_device", "w3_export_counters",
 ]
 
 _lib = None
@@ -99,6 +100,8 @@ def load():
     lib.w3_huff_tables.argtypes = [vp, sz, C.c_uint8, C.c_uint8, C.POINTER(HuffTable)]
     lib.w3_shard_range.argtypes = [sz, C.c_int, C.c_int, C.POINTER(sz), C.POINTER(sz)]
     lib.w3_encode_blocks_sharded.argtypes = [C.POINTER(vp), C.c_int, C.POINTER(ModelSpec), vp, sz, sz, vp, sz, C.POINTER(sz), vp]
+    lib.w3_encode_blocks_sharded_device.argtypes = [C.POINTER(vp), C.c_int, C.POINTER(ModelSpec), C.POINTER(vp), C.POINTER(sz), sz, C.c_int, vp, sz, vp,
+                                                    C.POINTER(C.c_uint64), C.c_int]
     lib.w3_encode_stats.argtypes = [vp, C.POINTER(ModelSpec), vp, sz, sz, vp]
     lib.w3_encode_stats_device.argtypes = [vp, C.POINTER(ModelSpec), vp, sz, sz, vp, vp]
     lib.w3_sweep_ordern.argtypes = [vp, vp, sz, sz, vp, vp, sz, vp]

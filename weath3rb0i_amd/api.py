@@ -221,3 +221,21 @@ class Context:
         rc = self.lib.w3_decode_blocks_device(self.h, C.byref(spec), C.c_void_p(d_comp.data_ptr()), d_comp.numel(), C.c_void_p(d_lens.data_ptr()),
                                               d_lens.numel(), block_size, orig_len, C.c_void_p(d_out.data_ptr()), st)
         self._chk(rc)
+
+
+def encode_blocks_sharded_device(ctxs, model, d_ins, block_size, d_out, d_lens, root=0, transport="auto"):
+    """w3_encode_blocks_sharded_device: ONE process, one Context per device; d_ins[r] (torch.uint8 CUDA tensor on ctxs[r]'s device) is
+    shard r of one stream (w3_shard_range); the packed streams and the length table are gathered on ctxs[root]'s device (d_out,
+    d_lens) with RCCL (grouped send/recv over xGMI) or device copies.  -> per-shard compressed byte counts."""
+    spec = model.spec() if isinstance(model, Model) else model
+    k = len(ctxs)
+    hs = (C.c_void_p * k)(*[c.h for c in ctxs])
+    ins = (C.c_void_p * k)(*[C.c_void_p(t.data_ptr() if t.numel() else 0) for t in d_ins])
+    ns = (C.c_size_t * k)(*[t.numel() for t in d_ins])
+    totals = (C.c_uint64 * k)()
+    tr = {"auto": L.W3_GATHER_AUTO, "rccl": L.W3_GATHER_RCCL, "peer_copy": L.W3_GATHER_PEER_COPY}[transport]
+    rc = ctxs[0].lib.w3_encode_blocks_sharded_device(hs, k, C.byref(spec), ins, ns, block_size, root, C.c_void_p(d_out.data_ptr()), d_out.numel(),
+                                                     C.c_void_p(d_lens.data_ptr()), totals, tr)
+    if rc:
+        raise W3Error(rc, ctxs[0].lib.w3_last_error(ctxs[0].h).decode())
+    return [int(t) for t in totals]

@@ -27,6 +27,7 @@ def build(force=False, verbose=False):
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall",
            "-Wno-unused-function", "-o", SO, SRC]
+    cmd += os.environ.get("W3_EXTRA_FLAGS", "").split()   # e.g. -DW3_TUNING: tuning hooks + the APM kernels' store guard (debug builds)
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

@@ -44,8 +44,26 @@ struct ApmArgs {
     const uint2 *rec;          // k_apm1: records sorted by c1 (k_partition<1>)
     const uint32_t *splits;    // k_apm1: [nblocks][W3_SLICES + 1]
     uint32_t *job_counter;     // k_apm1
-    uint16_t *dummy;           // [64] sink for the stores of lanes past the block end (keeps every store unconditional)
+    uint16_t *dummy;           // 2 KiB sink for the stores of lanes past the block end (keeps every store unconditional)
+    uint32_t *oob;             // -DW3_TUNING builds: counts stores whose address lies neither in [P, P + 16 n) nor in the sink (else null)
 };
+
+// Debug-build guard of every global store of the APM kernels ("the round-2 faults"): the address must lie
+// inside the stage's output stream or inside the sink.  A store that does not is counted and redirected to the sink, and the
+// host turns the count into W3_E_HIP — instead of a memory access fault that may take the GPU down.
+#ifdef W3_TUNING
+#define W3_APM_CHECK_STORE(a, ptr, bytes)                                                                     \
+    do {                                                                                                      \
+        const uintptr_t p_ = (uintptr_t)(ptr), lo_ = (uintptr_t)(a).P, hi_ = lo_ + (uintptr_t)(a).n * 16u;    \
+        const uintptr_t s_ = (uintptr_t)(a).dummy;                                                            \
+        if (!((p_ >= lo_ && p_ + (bytes) <= hi_) || (p_ >= s_ && p_ + (bytes) <= s_ + 2048u))) {              \
+            if ((a).oob) atomicAdd((a).oob, 1u);                                                              \
+            ptr = reinterpret_cast<decltype(ptr)>((a).dummy);                                                 \
+        }                                                                                                     \
+    } while (0)
+#else
+#define W3_APM_CHECK_STORE(a, ptr, bytes) do { } while (0)
+#endif
 
 // LDS pointers keep their address space (a generic pointer turns every access into a flat_* instruction).
 // Lanes of one wave communicate through the table: ordering comes from the hardware (LDS executes one wave's
@@ -281,6 +299,7 @@ __device__ __forceinline__ void apm0_block(const ApmArgs &a, const Apm0Ctx &c) {
         // unconditional store (a branch around it makes hipcc wait vmcnt(0) — store latency included — before it touches the
         // prefetched operands of the next batch); lanes past the block end write to the sink
         if constexpr (!FAST) dst = ip < c.len ? dst : reinterpret_cast<uint2 *>(a.dummy) + lane;
+        W3_APM_CHECK_STORE(a, dst, 8u);
         *dst = make_uint2((uint32_t)ov, (uint32_t)(ov >> 32));
     };
     load(pA, yA, sA, c.role * BATCH);
@@ -432,6 +451,7 @@ __global__ void __launch_bounds__(64 * W3_APM_WAVES) k_apm1(ApmArgs a) {
                     o = o < 1u ? 1u : o;
                 }
                 uint16_t *dst = valid ? P + ((uint64_t)rc[r].x * 8u + (uint32_t)j) : a.dummy + lane;
+                W3_APM_CHECK_STORE(a, dst, 2u);
                 *dst = (uint16_t)o;
             }
         }

@@ -72,6 +72,7 @@ struct TwoPhaseWs {
         uint64_t bytes = 0, slot_stride = 0;
         w3::SlotArgs sa;
     } pst;
+    uint32_t *apm_oob = nullptr;   // -DW3_TUNING builds: the call's flag word 3 (W3_APM_CHECK_STORE), else null
     uint32_t tune = 0;         // W3_OPT_TUNE: scheduling experiments (bit 1: k_apm0 padded to one workgroup per CU in the half-CU shapes)
     bool half_cu = false;      // half-CU kernel shapes (w3_predict.h W3_HALF_CU_LDS, k_coder_x5): the call shares every CU with another call's stage
     int n_wide = 0; bool small_timed = false;   // what the last predict recorded events for (W3_EV_PART0.., W3_EV_RANK0.., W3_EV_SMALL)
@@ -608,6 +609,7 @@ static inline int twophase_apm(TwoPhaseWs &ws, hipStream_t s, const ParsedSpec &
         aa.in = d_in; aa.n = n; aa.block_size = (uint32_t)block_size; aa.nblocks = nb;
         aa.P = (uint16_t *)ws.P; aa.stretch = ws.stretch; aa.squash = ws.squash; aa.rate = ps.apm[k].max_bits;
         aa.dummy = (uint16_t *)ws.dummy;
+        aa.oob = ws.apm_oob;
         if (ps.apm[k].align == W3_APM_ORDER0) {
             int L = 1;
             if (ws.P_valid) aa.src[0] = (const uint16_t *)ws.P;

@@ -8,6 +8,7 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -20,6 +21,7 @@
 #include "w3_twophase.h"
 #include "w3_selftest.h"
 #include "w3_sweep.h"
+#include "w3_rccl.h"
 
 using namespace w3;
 
@@ -672,6 +674,9 @@ static int encode_core(w3_ctx *ctx, JobRef J, const w3_model_spec *spec, const u
         uint32_t fl[4] = {0, 0, 0, 0};
         if (two) {
             J.tp.out_bits = (uint32_t *)J.bits.p;
+#ifdef W3_TUNING
+            J.tp.apm_oob = (uint32_t *)J.flag.p + 3;
+#endif
             memset(&ptm, 0, sizeof ptm);
             rc = twophase_encode(J.tp, s, s, ps, d_in, n, block_size, nb, (uint8_t *)J.stripes.p, cap, d_block_lens, (uint32_t *)J.flag.p, evp, &ptm, ctx->err);
             if (rc) return rc;
@@ -706,6 +711,7 @@ static int encode_core(w3_ctx *ctx, JobRef J, const w3_model_spec *spec, const u
             HIPCHK(ctx, hipStreamSynchronize(s));
         }
         if (fl[0] & 2u) { ctx->err = "coder pipeline timeout (internal error)"; return W3_E_HIP; }
+        if (fl[3]) { ctx->err = "APM kernel: " + std::to_string(fl[3]) + " stores outside the stage's stream and the sink (W3_TUNING store guard)"; return W3_E_HIP; }
         if (!(fl[0] & 1u)) break;
         if (cap_raised) { ctx->err = "stripe overflow at the worst-case bound (internal error)"; return W3_E_HIP; }
         cap = worst_stripe_cap(block_size);  // rare: a block expanded past 2N+64
@@ -861,6 +867,9 @@ extern "C" int w3_encode_submit(w3_ctx *ctx, const w3_model_spec *spec, const ui
     HIPCHK(ctx, hipMemsetAsync(J.flag.p, 0, 16, sp));
     if (evp) HIPCHK(ctx, hipEventRecord(evp[2 * W3_EV_TOTAL], sp));
     J.tp.out_bits = (uint32_t *)J.bits.p;
+#ifdef W3_TUNING
+    J.tp.apm_oob = (uint32_t *)J.flag.p + 3;
+#endif
     // The order in which the two jobs' kernels reach the chip (measured, profiles/r3_pipeline/: kernels that fill the LDS — the
     // partition passes, the time-ordered leaves, k_apm0 — only slow each other down when they share CUs; the rank kernels, bound
     // by their scattered stores, and the coder, one latency chain per lane, run well side by side):
@@ -908,6 +917,7 @@ extern "C" int w3_encode_wait(w3_ctx *ctx, int job) {
     uint64_t total;
     memcpy(&total, st.h_status + 4, 8);
     if ((f0 & 2u) && !mism) { ctx->err = "coder pipeline timeout (internal error)"; return W3_E_HIP; }
+    if (st.h_status[3]) { ctx->err = "APM kernel: stores outside the stage's stream and the sink (W3_TUNING store guard)"; return W3_E_HIP; }
     if (f0 || redo || mism) {
         // Rare: a stripe overflowed the 2N+64 bound, the fast coder handed blocks back, or the sampled verification saw the LDS-add
         // rounds misbehave.  Let the other job's kernels finish (its output is complete then, its status in pinned memory) and
@@ -1103,6 +1113,173 @@ extern "C" int w3_encode_blocks_sharded(w3_ctx *const *ctxs, int n_ctx, const w3
     if (total > out_cap || !out) return W3_E_NOSPACE;
     size_t o = 0;
     for (int r = 0; r < n_ctx; r++) { if (sh[r].len) memcpy(out + o, sh[r].buf.data(), sh[r].len); o += sh[r].len; }
+    return W3_OK;
+}
+
+// ---------------------------------------------------------------------------
+// The same sharding with the data resident on the devices and the gather over xGMI (north star: "RCCL gather over xGMI to
+// concatenate per-GPU compressed streams"; SURVEY section 8(e): ncclCommInitAll, sizes all-gather, grouped ncclSend / ncclRecv at
+// the offsets of the exclusive scan — RCCL has no gatherv).  One process, one context and one host thread per device.
+// ---------------------------------------------------------------------------
+struct ShardComms {          // one communicator set per device list, created on first use and kept (ncclCommInitAll is slow)
+    std::vector<int> devs;
+    std::vector<w3rccl::comm_t> comms;
+};
+static std::mutex g_comm_mu;
+static std::vector<ShardComms *> g_comms;
+
+static ShardComms *shard_comms(const std::vector<int> &devs, std::string &err) {
+    std::lock_guard<std::mutex> lk(g_comm_mu);
+    for (ShardComms *c : g_comms)
+        if (c->devs == devs) return c;
+    w3rccl::Api *r = w3rccl::api();
+    if (!r->error.empty()) { err = r->error; return nullptr; }
+    ShardComms *c = new ShardComms();
+    c->devs = devs; c->comms.assign(devs.size(), nullptr);
+    const int rc = r->CommInitAll(c->comms.data(), (int)devs.size(), devs.data());
+    if (rc != w3rccl::kSuccess) { err = std::string("ncclCommInitAll: ") + r->GetErrorString(rc); delete c; return nullptr; }
+    g_comms.push_back(c);
+    return c;
+}
+
+extern "C" int w3_encode_blocks_sharded_device(w3_ctx *const *ctxs, int n_ctx, const w3_model_spec *spec, const uint8_t *const *d_in, const size_t *n,
+                                               size_t block_size, int root, uint8_t *d_out, size_t out_cap, uint32_t *d_block_lens,
+                                               uint64_t *totals, int transport) {
+    if (!ctxs || n_ctx <= 0 || n_ctx > 64 || !d_in || !n || !totals || root < 0 || root >= n_ctx) return W3_E_INVALID;
+    if (transport < W3_GATHER_AUTO || transport > W3_GATHER_PEER_COPY) return W3_E_INVALID;
+    std::vector<int> devs(n_ctx);
+    bool distinct = true;
+    size_t nb_total = 0;
+    for (int r = 0; r < n_ctx; r++) {
+        if (!ctxs[r]) return W3_E_INVALID;
+        for (int q = 0; q < r; q++) {
+            if (ctxs[q] == ctxs[r]) { ctxs[0]->err = "the same context appears twice in ctxs[] (a context is not thread-safe)"; return W3_E_INVALID; }
+            distinct &= ctxs[q]->device != ctxs[r]->device;
+        }
+        devs[r] = ctxs[r]->device;
+        totals[r] = 0;
+        int rc = check_args(ctxs[r], n[r], block_size);
+        if (rc) return rc;
+        if (n[r] && !d_in[r]) return W3_E_INVALID;
+        if (r + 1 < n_ctx && n[r] % block_size) { ctxs[0]->err = "every shard but the last must be a whole number of blocks (w3_shard_range)"; return W3_E_INVALID; }
+        if ((rc = jobs_idle(ctxs[r]))) return rc;
+        nb_total += (n[r] + block_size - 1) / block_size;
+    }
+    if (nb_total == 0) return w3_spec_validate(spec);
+    if (!d_out || !d_block_lens) return W3_E_INVALID;
+    // RCCL needs one device per rank (ncclCommInitAll refuses a device twice): contexts that share a device — how the path is
+    // rehearsed on a 1-GPU box — gather with device copies instead
+    const bool use_rccl = transport == W3_GATHER_RCCL || (transport == W3_GATHER_AUTO && distinct && n_ctx > 1);
+    if (use_rccl && !distinct) { ctxs[0]->err = "W3_GATHER_RCCL needs one device per context"; return W3_E_INVALID; }
+    ShardComms *cm = nullptr;
+    if (use_rccl && !(cm = shard_comms(devs, ctxs[0]->err))) return W3_E_HIP;
+
+    // 1. every shard on its own device and host thread, into its context's staging buffers (io_out, lens, total)
+    std::vector<int> rcs(n_ctx, W3_OK);
+    std::vector<size_t> nbs(n_ctx, 0);
+    {
+        std::vector<std::thread> th;
+        for (int r = 0; r < n_ctx; r++) {
+            nbs[r] = (n[r] + block_size - 1) / block_size;
+            if (!nbs[r]) continue;
+            th.emplace_back([&, r]() {
+                w3_ctx *c = ctxs[r];
+                auto body = [&]() -> int {
+                    HIPCHK(c, hipSetDevice(c->device));
+                    size_t cap = n[r] + n[r] / 4 + 64 * nbs[r] + 1024;   // realistic bound; grown to the reported need on W3_E_NOSPACE
+                    for (int attempt = 0; attempt < 2; attempt++) {
+                        ENSURE(c, c->io_out, cap);
+                        ENSURE(c, c->lens, nbs[r] * 4);
+                        ENSURE(c, c->total, 8);
+                        int rc = encode_core(c, jobref(c, 0), spec, d_in[r], n[r], block_size, (uint8_t *)c->io_out.p, cap, (uint32_t *)c->lens.p, (uint64_t *)c->total.p, nullptr);
+                        uint64_t t = 0;
+                        if (rc == W3_OK || rc == W3_E_NOSPACE) HIPCHK(c, hipMemcpy(&t, c->total.p, 8, hipMemcpyDeviceToHost));
+                        totals[r] = t;
+                        if (rc != W3_E_NOSPACE || t <= cap) return rc;
+                        cap = (size_t)t;
+                    }
+                    return W3_E_NOSPACE;
+                };
+                rcs[r] = body();
+            });
+        }
+        for (auto &t : th) t.join();
+    }
+    for (int r = 0; r < n_ctx; r++)
+        if (rcs[r]) { if (r) ctxs[0]->err = "shard " + std::to_string(r) + ": " + (ctxs[r]->err.empty() ? w3_strerror(rcs[r]) : ctxs[r]->err); return rcs[r]; }
+
+    w3_ctx *rt = ctxs[root];
+    HIPCHK(rt, hipSetDevice(rt->device));
+    // 2. the sizes: with RCCL an all-gather of every rank's total (the exchange step's first half, exercised even with one rank)
+    if (use_rccl) {
+        w3rccl::Api *rc_api = w3rccl::api();
+        std::vector<DevBuf *> gathered(n_ctx);
+        int gs = rc_api->GroupStart();
+        for (int r = 0; r < n_ctx && gs == w3rccl::kSuccess; r++) {
+            w3_ctx *c = ctxs[r];
+            HIPCHK(c, hipSetDevice(c->device));
+            ENSURE(c, c->total, 8);                          // (holds this rank's total already when the shard was not empty)
+            if (!nbs[r]) HIPCHK(c, hipMemsetAsync(c->total.p, 0, 8, c->stream));
+            ENSURE(c, c->misc, 8 * (size_t)n_ctx);
+            gs = rc_api->AllGather(c->total.p, c->misc.p, 1, w3rccl::kUint64, cm->comms[r], c->stream);
+        }
+        const int ge = rc_api->GroupEnd();
+        if (gs != w3rccl::kSuccess || ge != w3rccl::kSuccess) { ctxs[0]->err = std::string("ncclAllGather: ") + rc_api->GetErrorString(gs != w3rccl::kSuccess ? gs : ge); return W3_E_HIP; }
+        std::vector<uint64_t> seen(n_ctx);
+        HIPCHK(rt, hipSetDevice(rt->device));
+        HIPCHK(rt, hipStreamSynchronize(rt->stream));
+        HIPCHK(rt, hipMemcpy(seen.data(), rt->misc.p, 8 * (size_t)n_ctx, hipMemcpyDeviceToHost));
+        for (int r = 0; r < n_ctx; r++)
+            if (seen[r] != totals[r]) { ctxs[0]->err = "sizes all-gather disagrees with the shards' totals (internal error)"; return W3_E_HIP; }
+    }
+    uint64_t sum = 0;
+    for (int r = 0; r < n_ctx; r++) sum += totals[r];
+    if (sum > out_cap) { ctxs[0]->err = "out_cap too small for the gathered streams"; return W3_E_NOSPACE; }
+
+    // 3. the streams and length tables to the root, at the exclusive scan of the totals / block counts
+    if (use_rccl) {
+        w3rccl::Api *rc_api = w3rccl::api();
+        int gs = rc_api->GroupStart();
+        uint64_t so = 0; size_t lo = 0;
+        for (int r = 0; r < n_ctx && gs == w3rccl::kSuccess; r++) {
+            w3_ctx *c = ctxs[r];
+            if (r == root) {
+                HIPCHK(rt, hipSetDevice(rt->device));
+                if (totals[r]) HIPCHK(rt, hipMemcpyAsync(d_out + so, c->io_out.p, (size_t)totals[r], hipMemcpyDeviceToDevice, rt->stream));
+                if (nbs[r]) HIPCHK(rt, hipMemcpyAsync(d_block_lens + lo, c->lens.p, nbs[r] * 4, hipMemcpyDeviceToDevice, rt->stream));
+            } else if (nbs[r]) {
+                // seven peers each have their own xGMI link to the root: the transfers of one group run concurrently
+                gs = rc_api->Send(c->io_out.p, (size_t)totals[r], w3rccl::kUint8, root, cm->comms[r], c->stream);
+                if (gs == w3rccl::kSuccess) gs = rc_api->Recv(d_out + so, (size_t)totals[r], w3rccl::kUint8, r, cm->comms[root], rt->stream);
+                if (gs == w3rccl::kSuccess) gs = rc_api->Send(c->lens.p, nbs[r] * 4, w3rccl::kUint8, root, cm->comms[r], c->stream);
+                if (gs == w3rccl::kSuccess) gs = rc_api->Recv(d_block_lens + lo, nbs[r] * 4, w3rccl::kUint8, r, cm->comms[root], rt->stream);
+            }
+            so += totals[r]; lo += nbs[r];
+        }
+        const int ge = rc_api->GroupEnd();
+        if (gs != w3rccl::kSuccess || ge != w3rccl::kSuccess) { ctxs[0]->err = std::string("RCCL gather: ") + rc_api->GetErrorString(gs != w3rccl::kSuccess ? gs : ge); return W3_E_HIP; }
+        for (int r = 0; r < n_ctx; r++) {
+            HIPCHK(ctxs[r], hipSetDevice(ctxs[r]->device));
+            HIPCHK(ctxs[r], hipStreamSynchronize(ctxs[r]->stream));
+        }
+    } else {
+        // device copies (same device: D2D; other devices: peer copies over xGMI / PCIe, no RCCL needed)
+        uint64_t so = 0; size_t lo = 0;
+        for (int r = 0; r < n_ctx; r++) {
+            w3_ctx *c = ctxs[r];
+            if (nbs[r]) {
+                if (c->device == rt->device) {
+                    HIPCHK(rt, hipMemcpyAsync(d_out + so, c->io_out.p, (size_t)totals[r], hipMemcpyDeviceToDevice, rt->stream));
+                    HIPCHK(rt, hipMemcpyAsync(d_block_lens + lo, c->lens.p, nbs[r] * 4, hipMemcpyDeviceToDevice, rt->stream));
+                } else {
+                    HIPCHK(rt, hipMemcpyPeerAsync(d_out + so, rt->device, c->io_out.p, c->device, (size_t)totals[r], rt->stream));
+                    HIPCHK(rt, hipMemcpyPeerAsync(d_block_lens + lo, rt->device, c->lens.p, c->device, nbs[r] * 4, rt->stream));
+                }
+            }
+            so += totals[r]; lo += nbs[r];
+        }
+        HIPCHK(rt, hipStreamSynchronize(rt->stream));
+    }
     return W3_OK;
 }
 
