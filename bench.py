@@ -53,6 +53,15 @@ def make_model(w3, name):
                 "BestOfTwo(BestOfTwo(Order0,Order1),OrderN(27,3))")
     if name == "default":
         return w3.init_model(), "OrderNEntropy(11,3,ACHistory(8,book1))"
+    # the reference's best published configurations (wave-per-block predict kernel, w3_predict_wave.h)
+    if name == "ac26":         # bin/entropy-hashing-ac/main.rs:21-25, enwik7.log:115: best ratio on enwik7
+        return w3.OrderNEntropy(26, 3, w3.ACHistory(23, w3.StationaryModel.for_enwik7())), "OrderNEntropy(26,3,ACHistory(23,enwik7))"
+    if name == "ac20":         # book1.log:139
+        return w3.OrderNEntropy(20, 3, w3.ACHistory(17, w3.StationaryModel.for_book1())), "OrderNEntropy(20,3,ACHistory(17,book1))"
+    if name == "ordern32_1":   # bin/ordern/enwik7.log:163: best plain OrderN
+        return w3.OrderN(32, 1), "OrderN(32,1)"
+    if name == "ordern22_2":
+        return w3.OrderN(22, 2), "OrderN(22,2)"
     if name == "order012apm":  # BASELINE configs[1] with its "single APM mixer" (build-defined APM)
         return w3.APM(make_model(w3, "order012")[0]), "APM(" + make_model(w3, "order012")[1] + ",order0 ctx,rate 7)"
     if name == "fullcm":       # BASELINE configs[2]: Counter orders 0/1/2 + slot-state orders 1-4 + two APM stages
@@ -74,11 +83,21 @@ def make_oracle_model(orc, name):
         for order in (1, 2, 3, 4):
             m = orc.BestOfTwoModel(m, orc.SlotModel(order, 14))
         return orc.APM(orc.APM(m, orc.APM_ORDER0, 7), orc.APM_ORDER1, 6)
+    if name == "ac26":
+        return orc.OrderNEntropy(26, 3, orc.ACHistory(23, orc.StationaryModel.for_enwik7()))
+    if name == "ac20":
+        return orc.OrderNEntropy(20, 3, orc.ACHistory(17, orc.StationaryModel.for_book1()))
+    if name == "ordern32_1":
+        return orc.OrderN(32, 1)
+    if name == "ordern22_2":
+        return orc.OrderN(22, 2)
     return orc.OrderNEntropy(11, 3, orc.ACHistory(8, orc.StationaryModel.for_book1()))
 
 
+WAVE_MODELS = {"ac26": 65, "ac20": 65, "ordern32_1": 0, "ordern22_2": 0}   # key bytes per input byte (1 read + 32 written + 32 read) of the hash kernel
+
 # per input byte, (time-ordered Counter leaves, wide Counter leaves, slot-state leaves, APM stages) of each bench model
-MODEL_SHAPE = {"order0": (1, 0, 0, 0), "order01": (1, 1, 0, 0), "order012": (1, 2, 0, 0), "default": (1, 0, 0, 0), "order012apm": (1, 2, 0, 1),
+MODEL_SHAPE = {"ac26": (1, 0, 0, 0), "ac20": (1, 0, 0, 0), "ordern32_1": (1, 0, 0, 0), "ordern22_2": (1, 0, 0, 0), "order0": (1, 0, 0, 0), "order01": (1, 1, 0, 0), "order012": (1, 2, 0, 0), "default": (1, 0, 0, 0), "order012apm": (1, 2, 0, 1),
                "fullcm": (1, 2, 4, 2)}
 
 
@@ -195,7 +214,7 @@ def parse_args(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=6)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--model", default="order012apm", help="order0 | order01 | order012 | default | order012apm (BASELINE configs[1]) | fullcm (configs[2])")
+    ap.add_argument("--model", default="order012apm", help="order0 | order01 | order012 | default | order012apm (BASELINE configs[1]) | fullcm (configs[2]) | ac26 | ac20 | ordern32_1 | ordern22_2 (the reference's best published configurations)")
     ap.add_argument("--size", type=int, default=1_000_000_000, help="input bytes: of the one stream (strong) / per GPU (weak); enwik9-class = 1e9")
     ap.add_argument("--scaling", default="both", choices=["both", "weak", "strong"])
     ap.add_argument("--data", default="text", choices=["text", "mixed"], help="text = enwik-shaped, mixed = Silesia-shaped (BASELINE configs[4] with --block-size 262144 --size 211938580)")
@@ -363,6 +382,10 @@ def kernel_table(model, n, bs, steps, acc, coder_name):
         o2 = w >= 1
         rows.append(("k_rank_sorted<%d> (Counter rounds inside sorted groups, 16-byte scatter)" % (2 if o2 else 1), acc["rank_ms"][w] / steps, n * (8 + 16)))
         rows.append(("k_partition8<%d> (stable 8-bit partition through LDS tiles)" % (3 if o2 else 1), acc["part_ms"][w] / steps, n * (1 + (8 if o2 else 1) + 8)))
+    if model in WAVE_MODELS:   # one wavefront per block, 64 steps per round, Counter table in HBM: per step 8 input bytes read (the lane's
+        # window), 2 written, one 8-byte slot read and written; + the 32-bit hashes of a hashed history
+        rows.append(("k_predict_wave (+ k_achash32: ACHistory hashes of every step)" if WAVE_MODELS[model] else "k_predict_wave (wave per block, Counter table in HBM)",
+                     per("predict_ms"), n * (8 * (8 + 2 + 16) + WAVE_MODELS[model])))
     if acc.get("small_ms", 0) > 0 and nsmall:
         rows.append(("k_predict_small<8> (time-ordered Counter leaf, table in LDS)", per("small_ms") / nsmall, n * 17))
     rows.append(("k_scan_lens + k_pack (wave prefix scan + compaction copy)", per("pack_ms"), 2 * (acc.get("coder_bytes", 0) / steps - n * (16 * (1 if napm else L) + 1))))

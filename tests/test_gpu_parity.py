@@ -55,6 +55,16 @@ def pair(oracle, name):
         "ordern_22_2": (lambda: w3.OrderN(22, 2), lambda: oracle.OrderN(22, 2)),
         "ordern_30_3": (lambda: w3.OrderN(30, 3), lambda: oracle.OrderN(30, 3)),
         "raw_16_3": (lambda: w3.OrderNEntropy(16, 3, w3.RawHistory()), lambda: oracle.OrderNEntropy(16, 3, oracle.RawHistory())),
+        "raw_29_3": (lambda: w3.OrderNEntropy(29, 3, w3.RawHistory()), lambda: oracle.OrderNEntropy(29, 3, oracle.RawHistory())),
+        "ordern_30_1": (lambda: w3.OrderN(30, 1), lambda: oracle.OrderN(30, 1)),
+        "ordern_32_1": (lambda: w3.OrderN(32, 1), lambda: oracle.OrderN(32, 1)),   # the reference's best plain configuration (bin/ordern/enwik7.log:163)
+        # the reference's best ratios: bin/entropy-hashing-ac/main.rs:21-25 (26,3)+ACHistory(23, enwik7) / (20,3)+ACHistory(17, book1)
+        "ac_26_3_mb23_enwik7": (lambda: w3.OrderNEntropy(26, 3, w3.ACHistory(23, w3.StationaryModel.for_enwik7())),
+                                lambda: oracle.OrderNEntropy(26, 3, oracle.ACHistory(23, oracle.StationaryModel.from_table(enwik7)))),
+        "ac_20_3_mb17_book1": (lambda: w3.OrderNEntropy(20, 3, w3.ACHistory(17, w3.StationaryModel.for_book1())),
+                               lambda: oracle.OrderNEntropy(20, 3, oracle.ACHistory(17, oracle.StationaryModel.from_table(book1)))),
+        "best_wave_mix": (lambda: w3.BestOfTwoModel(w3.Order0(), w3.BestOfTwoModel(w3.OrderN(22, 2), w3.BestOfTwoModel(w3.Order1(), w3.OrderNEntropy(20, 3, w3.ACHistory(17, w3.StationaryModel.for_book1()))))),
+                          lambda: oracle.BestOfTwoModel(oracle.Order0(), oracle.BestOfTwoModel(oracle.OrderN(22, 2), oracle.BestOfTwoModel(oracle.Order1(), oracle.OrderNEntropy(20, 3, oracle.ACHistory(17, oracle.StationaryModel.from_table(book1))))))),
         "main_default": (lambda: w3.init_model(),
                          lambda: oracle.OrderNEntropy(11, 3, oracle.ACHistory(8, oracle.StationaryModel.from_table(book1)))),
         "ac_19_3_enwik7": (lambda: w3.OrderNEntropy(19, 3, w3.ACHistory(16, w3.StationaryModel.for_enwik7())),
@@ -109,7 +119,9 @@ ALL = ["order0", "order1", "order2", "ordern_12_0", "ordern_14_4", "ordern_9_1",
 TWOPHASE = ["order0", "order1", "order2", "ordern_8_3", "ordern_5_3", "ordern_3_3", "ordern_10_3", "main_default", "ac_7_3_mb4",
             "ac_11_3_mb16", "ac_edge_table_mb8", "ac_edge_table_mb32", "frozen0", "best01", "best012", "best_right", "best_frozen_first",
             "best_ac_wide", "huff_11_text", "huff_7_text", "huff_11_skew", "huff_mix_text"]
-NOT_TWOPHASE = ["ordern_12_0", "ordern_14_4", "ordern_22_2", "ordern_30_3", "raw_16_3", "ac_19_3_enwik7", "huff_19_text"]
+# any other Counter-table leaf: wave per block, table in HBM (k_predict_wave) — lane-per-block kernel before round 3
+WAVE = ["ordern_12_0", "ordern_14_4", "ordern_9_1", "ordern_22_2", "ordern_30_3", "ordern_30_1", "ordern_32_1", "raw_16_3", "raw_29_3", "ac_19_3_enwik7",
+        "ac_26_3_mb23_enwik7", "ac_20_3_mb17_book1", "ac_10_2_mb0", "huff_19_text", "huff_24_text", "huff_19_skew", "best_wave_mix"]
 
 
 def test_counter_p_exhaustive(ctx):
@@ -414,19 +426,38 @@ def test_submit_wait_redo_paths(ctx, oracle):
     assert e.value.code == L.W3_E_NOSPACE and int(bufs[0][2].item()) == len(w_out)
 
 
-@pytest.mark.parametrize("name", NOT_TWOPHASE)
-def test_twophase_rejects_uncovered_specs(ctx, oracle, name):
+@pytest.mark.parametrize("name", WAVE)
+def test_wave_per_block_predict_kernel(ctx, oracle, name):
+    """k_predict_wave (w3_predict_wave.h): every Counter-table leaf outside the sorted kernels — any alignment_bits, hashed
+    histories wider than 8 bits, 32-bit contexts through the exact map — on the two-phase path, bit-exact, Model::predict included."""
+    data = markov_text(70000, seed=12) + lcg_text(9000, seed=3) + bytes(3000) + b"\xff" * 700 + markov_text(5000, seed=13)
+    out, lens = check_blocks(ctx, oracle, name, data, 16384, "twophase")
+    assert ctx.timing()["path"] == 2
+    dev, orc = pair(oracle, name)
+    back = ctx.decode_blocks(dev(), out, lens, 16384, len(data))
+    assert back.tobytes() == data
+    p = ctx.predict_blocks(dev(), data[:40000], 16384)
+    want = np.concatenate([oracle.predict_all(orc(), data[o:min(o + 16384, 40000)]) for o in range(0, 40000, 16384)])
+    assert np.array_equal(p, want)
+    # ragged and tiny blocks, a block of one byte value (every step of a bit position on ONE Counter: the halving replay)
+    for d_, bs_ in ((data[:8195], 4099), (data[:700], 9), (bytes(70000) + b"\xff" * 70000, 65536)):
+        check_blocks(ctx, oracle, name, d_, bs_, "twophase")
+
+
+def test_twophase_rejects_what_it_does_not_cover(ctx, oracle):
+    """Inputs under 8 bytes (the window loads read 8 bytes at once) stay on the lane-per-block kernel."""
     from weath3rb0i_amd import _lib as L
-    dev, _ = pair(oracle, name)
+    dev, _ = pair(oracle, "ordern_22_2")
     ctx.set_path("twophase")
     try:
         with pytest.raises(w3.W3Error) as e:
-            ctx.encode_blocks(dev(), b"abc" * 100, 64)
+            ctx.encode_blocks(dev(), b"abcdefg", 64)
         assert e.value.code == L.W3_E_UNSUPPORTED
     finally:
         ctx.set_path("auto")
-    out, lens = ctx.encode_blocks(dev(), b"abc" * 100, 64)  # auto falls to the generic kernel
+    out, lens = ctx.encode_blocks(dev(), b"abcdefg", 64)  # auto falls to the generic kernel
     assert ctx.timing()["path"] == 1
+    check_blocks(ctx, oracle, "ordern_22_2", b"abcdefgh", 3, "twophase")
 
 
 def test_twophase_counter_saturation(ctx, oracle):

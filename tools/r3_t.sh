@@ -1,4 +1,4 @@
 #!/bin/bash
 DST=$PWD/gpurun_out/r3_t; mkdir -p $DST
-timeout -k 10 600 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "sharded" > "$DST/pytest.txt" 2>&1
-echo "pytest rc=$?"; tail -25 "$DST/pytest.txt"
+timeout -k 10 900 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "wave or rejects or huff or twophase_path" > "$DST/pytest.txt" 2>&1
+echo "pytest rc=$?"; tail -30 "$DST/pytest.txt"

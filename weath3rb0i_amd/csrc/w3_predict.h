@@ -951,21 +951,35 @@ __global__ void __launch_bounds__(64 * NW) k_rank_sorted(PredictArgs a) {
 #define W3_HUFF_WALK 40u   // 32 bits are covered after at most 32 bytes of non-empty codes
 struct HuffKeyArgs { const uint8_t *in; uint64_t n; uint32_t block_size; uint32_t hmask; const w3_huff_table *tb; uint2 *keys;
                      uint32_t *redo;   /* [nblocks] zeroed before k_huffkeys: != 0 -> k_huffkeys_fix recomputes the block */
-                     uint32_t nblocks; };
+                     uint32_t nblocks;
+                     uint32_t *keys32; /* WIDE form: [8 n] the whole 32-bit hash of every step (w3_predict_wave.h) instead of `keys` */ };
 
-// the 8 keys of byte c0 at position i of its block, given compressed_bits before it
-__device__ __forceinline__ uint2 huff_keys_of(uint32_t cb, uint32_t c0, uint32_t i, uint32_t hmask, const uint16_t *rcode, const uint8_t *rlen) {
-    uint32_t out[2] = {0u, 0u};
+// the 8 hashes of byte c0 at position i of its block, given compressed_bits before it
+__device__ __forceinline__ void huff_hashes_of(uint32_t cb, uint32_t c0, const uint16_t *rcode, const uint8_t *rlen, uint32_t (&h)[8]) {
 #pragma unroll
     for (int j = 0; j < 8; j++) {
-        if (i == 0u && j == 0) continue;                                  // ctx starts at 0 (ordern_entropy.rs:19)
         const uint32_t rem = (1u << j) | (c0 >> (8 - j));                 // partial byte with a leading 1 (:71-73)
-        const uint32_t h = (cb << rlen[rem]) | rcode[rem];                // :74-75
-        out[j >> 2] |= (h & hmask & 0xFFu) << (8 * (j & 3));
+        h[j] = (cb << rlen[rem]) | rcode[rem];                            // :74-75
     }
-    return make_uint2(out[0], out[1]);
+}
+template <bool WIDE>
+__device__ __forceinline__ void huff_keys_store(const HuffKeyArgs &a, uint64_t g, uint32_t i, const uint32_t (&h)[8]) {
+    if constexpr (WIDE) {
+        uint4 *dst = reinterpret_cast<uint4 *>(a.keys32 + g * 8u);
+        dst[0] = make_uint4(h[0], h[1], h[2], h[3]);
+        dst[1] = make_uint4(h[4], h[5], h[6], h[7]);
+    } else {
+        uint32_t out[2] = {0u, 0u};
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            if (i == 0u && j == 0) continue;                              // ctx starts at 0 (ordern_entropy.rs:19)
+            out[j >> 2] |= (h[j] & a.hmask & 0xFFu) << (8 * (j & 3));
+        }
+        a.keys[g] = make_uint2(out[0], out[1]);
+    }
 }
 
+template <bool WIDE>
 __global__ void __launch_bounds__(256) k_huffkeys(HuffKeyArgs a) {
     __shared__ uint16_t s_code[256], s_rcode[256];
     __shared__ uint8_t s_len[256], s_rlen[256];
@@ -984,10 +998,13 @@ __global__ void __launch_bounds__(256) k_huffkeys(HuffKeyArgs a) {
         have += s_len[byte];
     }
     if (have < 32u && k <= i) a.redo[b] = 1u;   // uncovered with bytes left: a run of zero-length codes (benign race: every writer stores 1)
-    a.keys[g] = huff_keys_of(cb, blk[i], i, a.hmask, s_rcode, s_rlen);
+    uint32_t h[8];
+    huff_hashes_of(cb, blk[i], s_rcode, s_rlen, h);
+    huff_keys_store<WIDE>(a, g, i, h);
 }
 
 // one lane per block; only flagged blocks do anything (65,536 serial steps of a few instructions each)
+template <bool WIDE>
 __global__ void __launch_bounds__(64) k_huffkeys_fix(HuffKeyArgs a) {
     const uint32_t b = blockIdx.x * 64u + threadIdx.x;
     if (b >= a.nblocks || a.redo[b] == 0u) return;
@@ -996,7 +1013,9 @@ __global__ void __launch_bounds__(64) k_huffkeys_fix(HuffKeyArgs a) {
     uint32_t cb = 0u;
     for (uint32_t i = 0; i < len; i++) {
         const uint32_t c0 = a.in[off + i];
-        a.keys[off + i] = huff_keys_of(cb, c0, i, a.hmask, a.tb->rem_code, a.tb->rem_len);
+        uint32_t h[8];
+        huff_hashes_of(cb, c0, a.tb->rem_code, a.tb->rem_len, h);
+        huff_keys_store<WIDE>(a, off + i, i, h);
         const uint32_t l = a.tb->len[c0];
         cb = (l < 32u ? cb << l : 0u) | a.tb->code[c0];
     }

@@ -17,6 +17,7 @@
 #include "w3_coder4.h"
 #include "w3_coder5.h"
 #include "w3_predict.h"
+#include "w3_predict_wave.h"
 #include "w3_slot.h"
 #include "w3_spec.h"
 
@@ -83,6 +84,8 @@ struct TwoPhaseWs {
     size_t dummy_cap = 0;
     void *slot_tables = nullptr;        // per-lane HashMaps of the slot-state leaves
     size_t slot_tables_cap = 0;
+    void *keys32 = nullptr; size_t keys32_cap = 0;            // [8 n] u32 hashes of a wide OrderNEntropy leaf (k_achash32 / k_huffkeys<true>)
+    void *wave_tables = nullptr; size_t wave_tables_cap = 0;  // k_predict_wave: one Counter table per resident wavefront
     void *huff_redo = nullptr;          // k_huffkeys: per-block "recompute serially" flags
     size_t huff_redo_cap = 0;
     int coder_mode = 0;        // 0 = k_coder_x4 (mix + asm recurrence + output waves), 1 = k_coder_fast, 2 = k_coder only, 3 = k_coder_x2, 4 = k_coder_x3, 5 = k_coder_x5 (x4 with 72 KiB rings)
@@ -128,6 +131,10 @@ struct TwoPhaseWs {
         dummy = nullptr; dummy_cap = 0;
         if (slot_tables) (void)hipFree(slot_tables);
         slot_tables = nullptr; slot_tables_cap = 0;
+        if (keys32) (void)hipFree(keys32);
+        keys32 = nullptr; keys32_cap = 0;
+        if (wave_tables) (void)hipFree(wave_tables);
+        wave_tables = nullptr; wave_tables_cap = 0;
         if (huff_redo) (void)hipFree(huff_redo);
         huff_redo = nullptr; huff_redo_cap = 0;
         if (streams) (void)hipFree(streams);
@@ -141,6 +148,8 @@ struct TwoPhaseWs {
     }
 };
 
+static inline uint64_t tp_next_pow2(uint64_t v) { uint64_t p = 1; while (p < v) p <<= 1; return p; }
+
 static inline int tp_ensure(void *&p, size_t &cap, size_t bytes, std::string &err) {
     if (p && bytes <= cap) return W3_OK;
     if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
@@ -150,23 +159,24 @@ static inline int tp_ensure(void *&p, size_t &cap, size_t bytes, std::string &er
     return W3_OK;
 }
 
-enum { LEAF_FROZEN = 0, LEAF_SMALL = 1, LEAF_SMALL_AC = 2, LEAF_WIDE1 = 3, LEAF_WIDE2 = 4, LEAF_SLOT = 5, LEAF_SMALL_HUFF = 6, LEAF_NONE = -1 };
+enum { LEAF_FROZEN = 0, LEAF_SMALL = 1, LEAF_SMALL_AC = 2, LEAF_WIDE1 = 3, LEAF_WIDE2 = 4, LEAF_SLOT = 5, LEAF_SMALL_HUFF = 6,
+       LEAF_WAVE = 7 /* any other Counter-table leaf: wave per block, table in HBM (w3_predict_wave.h) */, LEAF_NONE = -1 };
 
 static inline int leaf_class(const w3_node &nd) {
     if (nd.kind == W3_NODE_SLOT_STATE) return LEAF_SLOT;
     if (nd.frozen) return LEAF_FROZEN;
-    if (nd.align != 3 || nd.bits < 3) return LEAF_NONE;
+    if (nd.align != 3 || nd.bits < 3) return LEAF_WAVE;
     const int H = nd.bits - 3;
-    if (nd.history == W3_HIST_HUFF) return H <= 8 ? LEAF_SMALL_HUFF : LEAF_NONE;   // wide Huffman-hashed contexts: generic kernel
+    if (nd.history == W3_HIST_HUFF) return H <= 8 ? LEAF_SMALL_HUFF : LEAF_WAVE;
     if (H <= 8) return nd.history == W3_HIST_AC ? LEAF_SMALL_AC : LEAF_SMALL;
-    if (nd.history == W3_HIST_AC) return LEAF_NONE;
+    if (nd.history == W3_HIST_AC) return LEAF_WAVE;
     if (H == 16) return LEAF_WIDE1;
     if (H == 24) return LEAF_WIDE2;
-    return LEAF_NONE;
+    return LEAF_WAVE;
 }
 
 static inline bool twophase_supported(const ParsedSpec &ps, size_t block_size, size_t n) {
-    if (block_size > (1u << 24) || n < 4) return false;   // the window loads read 4 bytes at once
+    if (block_size > (1u << 24) || n < 8) return false;   // the window loads read 4 (k_predict_wave: 8) bytes at once
     int n_slot = 0;
     for (int l = 0; l < ps.n_leaves; l++) n_slot += ps.leaf[l].kind == W3_NODE_SLOT_STATE;
     if (n_slot > W3_MAX_SLOT_LEAVES) return false;
@@ -320,7 +330,7 @@ static inline int twophase_predict_a(TwoPhaseWs &ws, hipStream_t s, const Parsed
     for (int k = 0; k < n_live; k++) {
         const w3_node &nd = ps.leaf[live[k]];
         const int c = leaf_class(nd);
-        if (lds_atomics && c != LEAF_SLOT) ws.used_lds_atomics = true;   // every Counter leaf's kernels run LDS-add rounds
+        if (lds_atomics && c != LEAF_SLOT && c != LEAF_WAVE) ws.used_lds_atomics = true;   // the sorted / time-ordered Counter kernels run LDS-add rounds
         w3::PredictArgs pa;
         memset(&pa, 0, sizeof pa);
         pa.in = d_in; pa.n = n; pa.block_size = (uint32_t)block_size; pa.nblocks = nb;
@@ -330,6 +340,65 @@ static inline int twophase_predict_a(TwoPhaseWs &ws, hipStream_t s, const Parsed
             w3::SlotLeaf &sl = sa.leaf[sa.n_leaves++];
             sl.order = nd.bits; sl.log_cells = nd.log_cells; sl.tbl_off = slot_stride; sl.P = pa.P;
             slot_stride += W3_CELL_STRIDE << nd.log_cells;
+            continue;
+        }
+        if (c == LEAF_WAVE) {
+            // wave per block, time order, Counter table in HBM (w3_predict_wave.h)
+            const uint64_t hash_slots = std::max<uint64_t>(1024, tp_next_pow2(16ull * block_size));
+            const uint64_t hash_bytes = 8ull * hash_slots + 16ull, direct_bytes = std::max<uint64_t>(4ull << nd.bits, 16ull);
+            w3::WaveArgs wa;
+            memset(&wa, 0, sizeof wa);
+            wa.in = d_in; wa.n = n; wa.block_size = (uint32_t)block_size; wa.nblocks = nb; wa.P = (uint16_t *)pa.P;
+            wa.align = nd.align; wa.hist_mask = (uint32_t)((1ull << (nd.bits - nd.align)) - 1ull);
+            wa.use_hash = (nd.bits >= 32 || direct_bytes > hash_bytes) ? 1u : 0u;
+            wa.hash_slots = (uint32_t)hash_slots;
+            wa.table_stride = wa.use_hash ? hash_bytes : direct_bytes;
+            size_t free_b = 0, total_b = 0;
+            if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); err = "hipMemGetInfo failed"; return W3_E_HIP; }
+            const uint64_t budget = std::min<uint64_t>(((uint64_t)free_b + ws.wave_tables_cap) / 2, 80ull << 30);
+            const uint64_t waves = std::min<uint64_t>(std::min<uint64_t>(nb, 256 * 32), budget / wa.table_stride);   // latency-bound: as many wavefronts as the chip holds
+            if (waves == 0) { err = "the Counter table of one block (" + std::to_string(wa.table_stride) + " B) exceeds the device budget"; return W3_E_NOMEM; }
+            if ((rc = tp_ensure(ws.wave_tables, ws.wave_tables_cap, (size_t)(waves * wa.table_stride), err))) return rc;
+            wa.tables = (uint8_t *)ws.wave_tables;
+            const bool keyed = nd.history == W3_HIST_AC || nd.history == W3_HIST_HUFF;
+            if (keyed) {
+                if ((rc = tp_ensure(ws.keys32, ws.keys32_cap, n * 32, err))) return rc;
+                wa.keys32 = (const uint32_t *)ws.keys32;
+                if (nd.history == W3_HIST_AC) {
+                    w3::HashArgs ha;
+                    memset(&ha, 0, sizeof ha);
+                    ha.max_bits = nd.max_bits; ha.hmask = 0xFFu;
+                    memcpy(ha.table, nd.table, sizeof ha.table);
+                    if ((rc = tp_ensure(ws.achash_lut, ws.achash_lut_cap, (size_t)(8u << W3_ACHASH_LUT_BITS) * 18, err))) return rc;
+                    ha.lut = (uint4 *)ws.achash_lut;
+                    ha.lut_key = (uint16_t *)((uint8_t *)ws.achash_lut + (size_t)(8u << W3_ACHASH_LUT_BITS) * 16);
+                    hipLaunchKernelGGL(w3::k_achash_lut, dim3((8u << W3_ACHASH_LUT_BITS) / 256), dim3(256), 0, s, ha);
+                    w3::Hash32Args h3;
+                    memset(&h3, 0, sizeof h3);
+                    h3.in = d_in; h3.n = n; h3.block_size = (uint32_t)block_size; h3.max_bits = nd.max_bits;
+                    memcpy(h3.table, nd.table, sizeof h3.table);
+                    h3.lut = (const uint4 *)ws.achash_lut; h3.keys32 = (uint32_t *)ws.keys32;
+                    hipLaunchKernelGGL(w3::k_achash32, dim3((unsigned)((n * 8 + 255) / 256)), dim3(256), 0, s, h3);
+                } else {
+                    if (!ws.huff) { err = "HuffHistory tables not staged"; return W3_E_HIP; }
+                    w3::HuffKeyArgs hk;
+                    memset(&hk, 0, sizeof hk);
+                    hk.in = d_in; hk.n = n; hk.block_size = (uint32_t)block_size; hk.hmask = 0xFFFFFFFFu;
+                    hk.tb = ws.huff + nd.reserved; hk.keys32 = (uint32_t *)ws.keys32;
+                    if ((rc = tp_ensure(ws.huff_redo, ws.huff_redo_cap, (size_t)nb * 4, err))) return rc;
+                    hk.redo = (uint32_t *)ws.huff_redo; hk.nblocks = nb;
+                    (void)hipMemsetAsync(ws.huff_redo, 0, (size_t)nb * 4, s);
+                    hipLaunchKernelGGL(w3::k_huffkeys<true>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, hk);
+                    hipLaunchKernelGGL(w3::k_huffkeys_fix<true>, dim3((nb + 63u) / 64u), dim3(64), 0, s, hk);
+                }
+                hipLaunchKernelGGL(w3::k_predict_wave<true>, dim3((unsigned)waves), dim3(64), 0, s, wa);
+                bytes += n * (1 + 32 + 32);
+            } else {
+                hipLaunchKernelGGL(w3::k_predict_wave<false>, dim3((unsigned)waves), dim3(64), 0, s, wa);
+            }
+            bytes += n * (8 + 16 + 8 * 16);   // per step: 8 input bytes read, 2 written, one 8-byte slot read and written (as 32-byte sectors: reported by the PMC passes)
+            hipError_t e = hipGetLastError();
+            if (e != hipSuccess) { err = std::string("wave predict launch: ") + hipGetErrorString(e); return W3_E_HIP; }
             continue;
         }
         pa.hbits = nd.bits - 3;
@@ -359,14 +428,15 @@ static inline int twophase_predict_a(TwoPhaseWs &ws, hipStream_t s, const Parsed
         } else if (c == LEAF_SMALL_HUFF) {
             if (!ws.huff) { err = "HuffHistory tables not staged"; return W3_E_HIP; }
             w3::HuffKeyArgs hk;
+            memset(&hk, 0, sizeof hk);
             hk.in = d_in; hk.n = n; hk.block_size = (uint32_t)block_size; hk.hmask = (1u << (nd.bits - 3)) - 1u;
             hk.tb = ws.huff + nd.reserved; hk.keys = (uint2 *)ws.keys;
             // blocks whose bounded walk-back met a run of zero-length codes are redone serially (k_huffkeys_fix)
             if ((rc = tp_ensure(ws.huff_redo, ws.huff_redo_cap, (size_t)nb * 4, err))) return rc;
             hk.redo = (uint32_t *)ws.huff_redo; hk.nblocks = nb;
             (void)hipMemsetAsync(ws.huff_redo, 0, (size_t)nb * 4, s);
-            hipLaunchKernelGGL(w3::k_huffkeys, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, hk);
-            hipLaunchKernelGGL(w3::k_huffkeys_fix, dim3((nb + 63u) / 64u), dim3(64), 0, s, hk);
+            hipLaunchKernelGGL(w3::k_huffkeys<false>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, hk);
+            hipLaunchKernelGGL(w3::k_huffkeys_fix<false>, dim3((nb + 63u) / 64u), dim3(64), 0, s, hk);
             pa.keys = (const uint2 *)ws.keys;
             launch_small<true>(nd.bits - 3, dim3(grid_small), s, pa);
             bytes += n * 17;
@@ -570,14 +640,14 @@ static inline int twophase_verify(TwoPhaseWs &ws, hipStream_t s, const ParsedSpe
     v.variant = (ws.variant | W3_VAR_NO_LDS_ATOMICS | W3_VAR_PARTITION4) & ~(uint32_t)W3_VAR_INJECT_LDS_FAULT;
     v.lds_order = 0; v.verify = 0;
     v.stretch = ws.stretch; v.squash = ws.squash; v.st = ws.st; v.huff = ws.huff; v.slot_budget_mb = ws.slot_budget_mb;
-    // only the Counter leaves are re-predicted: slot-state leaves do not use the property
+    // only the leaves whose kernels use the property are re-predicted (not the slot-state leaves, not k_predict_wave's)
     ParsedSpec vps;
     int map[W3_MAX_LEAVES], nmap = 0;   // vps leaf -> index among ws.mix.src (the live leaves of ps, in order)
     int live_idx = 0;
     for (int l = 0; l < ps.n_leaves; l++) {
         const int c = leaf_class(ps.leaf[l]);
         if (c == LEAF_FROZEN) continue;
-        if (c != LEAF_SLOT) { vps.leaf[vps.n_leaves++] = ps.leaf[l]; map[nmap++] = live_idx; }
+        if (c != LEAF_SLOT && c != LEAF_WAVE) { vps.leaf[vps.n_leaves++] = ps.leaf[l]; map[nmap++] = live_idx; }
         live_idx++;
     }
     vps.n_huff = ps.n_huff; vps.huff = ps.huff;
