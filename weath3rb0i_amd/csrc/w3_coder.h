@@ -392,6 +392,7 @@ struct Coder3Args {
     uint32_t *redo;
     uint32_t acc_limit;
     uint32_t *out_bits;    // [nblocks] ACStats bit count of each block (helpers.rs:60-90), or null
+    uint32_t prio_mo;      // k_coder_x5: the mix and output waves run at s_setprio 2 (experiment, W3_OPT_TUNE bit 7)
 };
 
 // SLEEP: s_sleep units (64 clocks) between polls.  The recurrence wave polls eagerly (it is the critical path); the mix and

@@ -183,6 +183,7 @@ __global__ void __launch_bounds__(L > 1 ? 256 : 192) k_coder_x5(Coder3Args a) {
         return i % RING == 0u ? i + (run_end - i) / RING * RING : i;
     };
 
+    if (wave != NM && a.prio_mo) __builtin_amdgcn_s_setprio(2);
     if (wave < NM) {
         // ------------------------------ M-wave(s) ------------------------------
         // Loads are issued NB chunks of this wave ahead (unconditional, clamped: hipcc waits vmcnt(0) after a load it has to branch

@@ -464,7 +464,7 @@ static inline int twophase_predict_a(TwoPhaseWs &ws, hipStream_t s, const Parsed
             if (const char *ev_ = w3_tune_env("W3_RANK_GRID")) rank_waves = (uint32_t)std::max(64, atoi(ev_));   // tuning hook
             // half-CU shapes: the FIRST rank kernel starts beside the previous call's coder and must leave it its half of every CU's
             // LDS whichever of the two is dispatched first; the later ones are single wavefronts again (they fill what is free)
-            const uint32_t grid_rank = (ws.half_cu && (w == 0 || (ws.tune & 32u)) && !(ws.tune & 8u)) ? std::min<uint32_t>((nb * W3_SLICES + W3_NW_RANK - 1) / W3_NW_RANK, W3_HALF_CU_GRID)
+            const uint32_t grid_rank = (ws.half_cu && (w == 0 || (ws.tune & (32u | 64u))) && !(ws.tune & 8u)) ? std::min<uint32_t>((nb * W3_SLICES + W3_NW_RANK - 1) / W3_NW_RANK, W3_HALF_CU_GRID)
                                                               : std::min<uint32_t>(nb * W3_SLICES, rank_waves);
             // an order-2 leaf behind an Order1 leaf starts from that leaf's records (sorted by c1; same stream, so they are ready)
             const bool chained = c == LEAF_WIDE2 && ws.wide1_slot >= 0 && !(ws.variant & W3_VAR_NO_CHAINED_PARTITION);
@@ -533,7 +533,7 @@ static inline int twophase_predict_b(TwoPhaseWs &ws, hipStream_t s, const Parsed
     for (int w = 0; w < n_def; w++) {
         if (forked) (void)hipStreamWaitEvent(s, ws.ev_join[n_def - 1], 0);   // every leaf's records are sorted
         if (ev) (void)hipEventRecord(ev[2 * (W3_EV_RANK0 + w)], s);
-        if (ws.half_cu && (w == 0 || (ws.tune & 32u)) && !(ws.tune & 8u)) {
+        if (ws.half_cu && (w == 0 || (ws.tune & (32u | 64u))) && !(ws.tune & 8u)) {
             if (deferred[w].cls == LEAF_WIDE1) hipLaunchKernelGGL((w3::k_rank_sorted<1, W3_NW_RANK>), dim3(deferred[w].grid_rank), dim3(64 * W3_NW_RANK), 0, s, deferred[w].pa);
             else hipLaunchKernelGGL((w3::k_rank_sorted<2, W3_NW_RANK>), dim3(deferred[w].grid_rank), dim3(64 * W3_NW_RANK), 0, s, deferred[w].pa);
         } else if (deferred[w].cls == LEAF_WIDE1) hipLaunchKernelGGL(w3::k_rank_sorted<1>, dim3(deferred[w].grid_rank), dim3(64), 0, s, deferred[w].pa);
@@ -823,6 +823,7 @@ static inline int tp_code_stage(TwoPhaseWs &ws, hipStream_t s_pred, hipStream_t 
         c3.stripes = stripes; c3.stripe_cap = stripe_cap; c3.out_len = d_lens; c3.flags = d_flag; c3.redo = (uint32_t *)ws.redo;
         c3.acc_limit = limit;
         c3.out_bits = ws.out_bits;
+        c3.prio_mo = (ws.tune >> 7) & 1u;
         const dim3 grid((nb + 63) / 64), blk(192);
         if (coder == 4) {
             switch (ws.mix.n_src) {
