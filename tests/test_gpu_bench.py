@@ -74,6 +74,24 @@ def test_bench_self_launch_one_rank_with_exchange():
     assert d["config"]["ranks_seen_by_rccl"] == 1 and "over 1 rank(s)" in d["config"]["exchange"] and d["value"] > 0
 
 
+@pytest.mark.gpu
+def test_bench_two_ranks_rehearsal_both_readings():
+    """The multi-rank control flow end to end on the 1-GPU box: `bench.py --gpus 2` starts two ranks ITSELF (WORLD_SIZE unset), they
+    share the one GPU and exchange through gloo (--backend gloo: a rehearsal, its numbers mean nothing): strong reading = ONE stream
+    cut over the ranks, weak reading attached, the exchange's totals from both ranks in the line."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--size", "6000000", "--backend", "gloo"],
+                       capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["bytes_total"] == 6000000
+    assert d["config"]["ranks_seen_by_rccl"] == 2 and "over 2 rank(s)" in d["config"]["exchange"]
+    assert d["weak"]["bytes_total"] == 12000000 and d["weak"]["value"] > 0 and d["value"] > 0
+    assert "cpu_baseline" not in d and "decode" not in d   # rank-0, N = 1 extras only
+
+
 def test_launcher_command_for_n_ranks():
     """CPU: the command bench.py runs for --gpus N when nobody launched it (the driver's own form: one process per GPU,
     127.0.0.1 rendezvous); and the parent never reaches a GPU call before it (self_launch is the first thing main() does)."""
