@@ -56,6 +56,39 @@ def test_sweep_csizes_match_the_oracle(oracle):
 
 
 @pytest.mark.gpu
+def test_entropy_hashing_sweeps_match_the_oracle(oracle):
+    """bin/entropy-hashing-ac and bin/entropy-hashing-huff as sweeps over the counting sink: csizes equal the oracle's ACStats per block,
+    hashes of 5 .. 16 bits (k_achash / k_huffkeys with k_predict_small, k_achash32 / k_huffkeys<true> with k_predict_wave), best per level
+    with the reference's tie rule, the reference's line format."""
+    import weath3rb0i_amd as w3
+    data = markov_text(3 * 4096 + 100, seed=52)
+    bs = 4096
+    blocks = [data[o:o + bs] for o in range(0, len(data), bs)]
+    ctx = w3.Context(0)
+    try:
+        lines = []
+        best, params, got = sweep.sweep_entropy_ac(ctx, data, bs, range(8, 20, 4), range(0, 4), repeats=1, out=lines.append)
+        want = {}
+        for (b, a) in got:
+            want[(b, a)] = sum(oracle.encode_stats_bits(oracle.OrderNEntropy(b, a, oracle.ACHistory(b - a, oracle.StationaryModel(buf=data))), blk)
+                               for blk in blocks) // 8
+        assert got == want
+        assert best == min(want.values()) and want[params] == best
+        assert lines[0].startswith("[eh-ac] [ctx:  8, align: 0] csize: %d (ratio " % want[(8, 0)])
+        assert lines[-1] == "-> gloabl best: %d for [ctx: %d, align: %d]" % (best, params[0], params[1])
+        lines = []
+        best, params, got = sweep.sweep_entropy_huff(ctx, data, bs, range(9, 11), range(10, 12), range(8, 21, 6), repeats=1, out=lines.append)
+        want = {}
+        for (r, h, b) in got:
+            want[(r, h, b)] = sum(oracle.encode_stats_bits(oracle.OrderNEntropy(b, 0, oracle.HuffHistory(data, h, r)), blk) for blk in blocks) // 8
+        assert got == want and len(got) == 12
+        assert best == min(want.values()) and want[params] == best
+        assert lines[-1].startswith("---> global best: %d for [rem_hsize: " % best)
+    finally:
+        ctx.close()
+
+
+@pytest.mark.gpu
 def test_counting_sink_and_sweep_and_export_match_the_oracle(oracle):
     """A14 (ACStats) on every coder kernel and both paths; the one-launch sweep per (configuration, block); the context
     statistics export against the oracle's Counter table semantics."""
