@@ -499,12 +499,19 @@ def main():
     coder_name = args.coder if (args.coder != "x4" or (pipeline == 1 and "half_cu" not in args.variant)) else "x5"
 
     extras = world == 1 and not exchange and rank == 0
-    ref_model = decode = None
+    ref_model = decode = sync_line = None
     kept = []   # (compressed stream, lens) of the live output buffers of the timed steps
     if extras:
         for k in sorted({rg.last_buf, rg.last_buf ^ 1} if (args.steps > 1) else {rg.last_buf}):
             tot = int(rg.d_totals[k].item())
             kept.append((rg.d_outs[k][:tot].clone(), rg.d_lenss[k][:nb].clone()))
+        if pipeline == 2 and not args.no_ref_model:
+            # the same workload with ONE synchronous call per step (3 steps, outside the timed region): what a lone call takes, and the
+            # coder's launch with nothing beside it — the floor of a strong-scaled run
+            dts, accs = rg.timed(ctx, model, 3, 1, 1)
+            sync_line = {"value": round(n * 3 / dts / 2**20, 2), "unit": "MiB/s", "ms_per_step": round(dts / 3 * 1e3, 3),
+                         "kernel_ms_per_step": {k: round(accs.get(k, 0.0) / 3, 3) for k in ("predict_ms", "apm_ms", "coder_ms", "pack_ms")},
+                         "note": "w3_encode_blocks_device, one call at a time (k_coder_x4, full kernel shapes)"}
         if not args.no_ref_model and args.model != "order012" and args.data == "text":
             # the largest model whose streams are entirely the reference's (no build-defined node): same input, 3 steps, outside the
             # timed region (the main model's outputs are kept aside for the checks first)
@@ -606,16 +613,22 @@ def main():
             "predict_phase": predict_phase,
             # the coder is ONE dependent chain of 8 x block_size bit-steps per lane: its time does not shrink with the block count,
             # so it is the floor of a strong-scaled run (predict / APM / pack scale with the bytes per GPU)
-            "floors": {"coder_floor_ms": round(coder_ms, 3) if path == 2 else None, "bit_steps_per_lane": steps_per_lane,
-                       "cycles_per_bit_step": round(coder_ms * 1e-3 * SHADER_GHZ * 1e9 / steps_per_lane, 1) if path == 2 else None,
+            "floors": {"coder_floor_ms": (sync_line["kernel_ms_per_step"]["coder_ms"] if sync_line else round(coder_ms, 3)) if path == 2 else None,
+                       "coder_launch_ms_in_this_run": round(coder_ms, 3) if path == 2 else None,
+                       "bit_steps_per_lane": steps_per_lane,
+                       "cycles_per_bit_step": (round((sync_line["kernel_ms_per_step"]["coder_ms"] if sync_line else coder_ms) * 1e-3 * SHADER_GHZ * 1e9 / steps_per_lane, 1)
+                                               if path == 2 else None),
                        "clock_ghz_assumed": SHADER_GHZ,
-                       "note": "the coder's launch duration; with two encodes in flight it runs beside the next step's predict kernels"},
+                       "note": "coder_floor_ms = the coder's launch with nothing beside it (synchronous call): 8 x block_size dependent steps per lane, it does not "
+                               "shrink with the block count; with two encodes in flight its launch stretches beside the next step's rank kernels"},
         }
         if "weak" in results and main_rd != "weak":
             rw = results["weak"]
             res["weak"] = {"value": round(rw["n_global"] * args.steps / rw["dt"] / 2**20, 2), "unit": "MiB/s", "ms_per_step": round(rw["dt"] / args.steps * 1e3, 3),
                            "bytes_per_gpu": rw["n"], "bytes_total": rw["n_global"], "steps": args.steps, "warmup": args.warmup,
                            "note": "weak reading: every GPU codes its own --size bytes; same K steps, same barriers"}
+        if sync_line:
+            res["one_call_at_a_time"] = sync_line
         if ref_model:
             res["reference_stream_model"] = ref_model
         if decode:

@@ -46,6 +46,7 @@ def test_bench_line_contract():
     assert cb["kind"] == "port" and cb["bit_exact_vs_gpu"] is True and cb["buffers_checked"] == 2 and len(cb["legs"]) == 2 and cb["legs"][0]["cores"] == 1
     assert d["decode"]["roundtrip_all_blocks"] is True and d["decode"]["blocks"] == 92
     assert d["floors"]["coder_floor_ms"] > 0 and d["floors"]["bit_steps_per_lane"] == 8 * 65536
+    assert d["one_call_at_a_time"]["ms_per_step"] > 0 and d["floors"]["coder_floor_ms"] == d["one_call_at_a_time"]["kernel_ms_per_step"]["coder_ms"]
     assert d["predict_phase"]["algorithmic_bytes_per_step"] == 115 * 6000000          # 3 leaves x 17 B + 2 wide leaves x 32 B of record passes
     assert d["reference_stream_model"]["value"] > 0
     assert "other_configs" not in d   # (only at enwik8 size and above)
