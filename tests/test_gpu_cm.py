@@ -72,8 +72,17 @@ def check(ctx, oracle, name, data, bs, decode=True):
     assert lens.tolist() == wlens.tolist(), name
     assert out.tobytes() == want.tobytes(), name
     if len(data) >= 8:
-        # encode runs on the two-phase path (Counter kernels, k_slot, k_apm0 / k_apm1); the lane-per-block k_cm must agree with it
+        # encode runs on the two-phase path (Counter kernels, slot leaves by sorted replay — few blocks here —, k_apm0 / k_apm1);
+        # k_slot (hash map in HBM, the form for many blocks) and the lane-per-block k_cm must agree with it
         assert ctx.timing()["path"] == 2, name
+        if "slot" in name or "full_cm" in name:
+            ctx.set_variant("slot_table")
+            try:
+                out3, lens3 = ctx.encode_blocks(dev(), data, bs)
+                assert ctx.timing()["path"] == 2
+            finally:
+                ctx.set_variant()
+            assert lens3.tolist() == wlens.tolist() and out3.tobytes() == want.tobytes(), name + " (k_slot)"
         ctx.set_path("generic")
         try:
             out2, lens2 = ctx.encode_blocks(dev(), data, bs)
@@ -177,16 +186,44 @@ def test_slot_tables_in_batches(ctx, oracle):
     (tables zero-filled per batch); forced here with the tuning hook."""
     data = markov_text(130 * 512 + 77, seed=14)
     ctx.set_slot_budget_mb(40)                         # slot2: 2^12 cells x 128 B = 512 KiB per block -> 64 blocks per batch
+    ctx.set_variant("slot_table")                      # (at this block count the default is the sorted replay, which has no tables)
     try:
         check(ctx, oracle, "slot2", data, 512, decode=False)
         assert ctx.timing()["path"] == 1                   # (check() ends on its k_cm cross-check)
         dev, _ = pair(oracle, "slot2")
+        ctx.set_variant("slot_table")                  # (check() leaves the defaults behind)
         ctx.set_timing(True)
         ctx.encode_blocks(dev(), data, 512)
         assert ctx.timing()["n_slot_launches"] == 3
     finally:
         ctx.set_timing(False)
         ctx.set_slot_budget_mb(0)
+        ctx.set_variant()
+
+
+def test_slot_sorted_replay_shapes(ctx, oracle):
+    """The sorted replay of the slot-state leaves (w3_slot2.h) where its bookkeeping has corners: Cells that fill one sort bin
+    (2^8 and fewer: a single pass), leaves of different table sizes in one launch (one and two passes mixed), 2^16 Cells, a block
+    longer than 64 KiB (events past 2^17), ragged last blocks of 1 .. 9 bytes, constant input (every event of a context in one Cell)."""
+    text = markov_text(3 * 8192 + 5, seed=91)
+    models = {
+        "cells_2^8": (lambda: w3.SlotModel(2, 8), lambda: oracle.SlotModel(2, 8)),
+        "cells_2^9": (lambda: w3.SlotModel(1, 9), lambda: oracle.SlotModel(1, 9)),
+        "cells_2^16": (lambda: w3.SlotModel(3, 16), lambda: oracle.SlotModel(3, 16)),
+        "mixed_sizes": (lambda: w3.BestOfTwoModel(w3.SlotModel(1, 4), w3.BestOfTwoModel(w3.SlotModel(2, 12), w3.SlotModel(3, 8))),
+                        lambda: oracle.BestOfTwoModel(oracle.SlotModel(1, 4), oracle.BestOfTwoModel(oracle.SlotModel(2, 12), oracle.SlotModel(3, 8)))),
+    }
+    cases = [(text, 8192), (markov_text(2 * 131072 + 9, seed=92), 131072), (b"\x00" * 9000, 4096), (text[:8192 + 1], 8192), (text[:4096 * 2 + 9], 4096)]
+    for mname, (dev, orc) in models.items():
+        for data, bs in cases:
+            want, wlens = oracle.encode_blocks(orc(), data, bs, nthreads=8)
+            for variant in ("slot_sorted", "slot_table"):
+                ctx.set_variant(variant)
+                try:
+                    out, lens = ctx.encode_blocks(dev(), data, bs)
+                finally:
+                    ctx.set_variant()
+                assert lens.tolist() == wlens.tolist() and out.tobytes() == want.tobytes(), (mname, len(data), bs, variant)
 
 
 def test_apm_models_submit_wait_pipeline(ctx, oracle):

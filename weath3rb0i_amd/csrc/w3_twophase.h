@@ -19,6 +19,7 @@
 #include "w3_predict.h"
 #include "w3_predict_wave.h"
 #include "w3_slot.h"
+#include "w3_slot2.h"
 #include "w3_spec.h"
 
 // Tuning / timing-experiment hooks read from the environment exist only in -DW3_TUNING builds: the shipped library never
@@ -36,7 +37,11 @@ static inline const char *w3_tune_env(const char *name) {
 enum { W3_VAR_NO_LDS_ATOMICS = 1, W3_VAR_PARTITION4 = 2, W3_VAR_NO_CHAINED_PARTITION = 4, W3_VAR_CM_UNSTAGED = 8, W3_VAR_NO_SIDE_STREAM = 16,
        W3_VAR_INJECT_LDS_FAULT = 32 /* tests: corrupt one LDS-add round per block, the sampled verification must catch it */,
        W3_VAR_HALF_CU = 64    /* synchronous calls too run the half-CU kernel shapes of the submit / wait pipeline (w3_predict.h) */,
-       W3_VAR_FULL_CU = 128   /* w3_encode_submit keeps the plain kernel shapes (experiments: what the shapes are worth) */ };
+       W3_VAR_FULL_CU = 128   /* w3_encode_submit keeps the plain kernel shapes (experiments: what the shapes are worth) */,
+       W3_VAR_SLOT_TABLE = 256  /* slot-state leaves always on k_slot (hash map in HBM, lane per block) */,
+       W3_VAR_SLOT_SORTED = 512 /* slot-state leaves always on the sorted replay of w3_slot2.h (default: by block count) */ };
+
+#define W3_SLOT_SORTED_MAX_BLOCKS 7000u   // below: slot-state leaves by sorted replay (w3_slot2.h), from here on k_slot
 
 // event slots (pairs: ev[2 * slot], ev[2 * slot + 1]) of one encode
 enum { W3_EV_PREDICT = 0, W3_EV_CODER = 1, W3_EV_PACK = 2, W3_EV_TOTAL = 3, W3_EV_APM = 4, W3_EV_SLOT = 5, W3_EV_ACHASH = 6,
@@ -73,6 +78,7 @@ struct TwoPhaseWs {
         uint64_t bytes = 0, slot_stride = 0;
         w3::SlotArgs sa;
     } pst;
+    uint32_t *order_fault = nullptr;   // the call's flag word 2 (k_slot_replay reports a sort that lost its order there), or null
     uint32_t *apm_oob = nullptr;   // -DW3_TUNING builds: the call's flag word 3 (W3_APM_CHECK_STORE), else null
     uint32_t tune = 0;         // W3_OPT_TUNE: scheduling experiments (bit 1: k_apm0 padded to one workgroup per CU in the half-CU shapes)
     bool half_cu = false;      // half-CU kernel shapes (w3_predict.h W3_HALF_CU_LDS, k_coder_x5): the call shares every CU with another call's stage
@@ -85,6 +91,8 @@ struct TwoPhaseWs {
     void *slot_tables = nullptr;        // per-lane HashMaps of the slot-state leaves
     size_t slot_tables_cap = 0;
     void *keys32 = nullptr; size_t keys32_cap = 0;            // [8 n] u32 hashes of a wide OrderNEntropy leaf (k_achash32 / k_huffkeys<true>)
+    void *slot_keys = nullptr; size_t slot_keys_cap = 0;      // w3_slot2.h: [2][n_leaves][2 n] u64 event records (ping-pong) + [n_leaves][nb][512] digit counts
+    bool slot_sorted = false;                                 // what the last predict ran its slot leaves on
     void *wave_tables = nullptr; size_t wave_tables_cap = 0;  // k_predict_wave: one Counter table per resident wavefront
     void *huff_redo = nullptr;          // k_huffkeys: per-block "recompute serially" flags
     size_t huff_redo_cap = 0;
@@ -133,6 +141,8 @@ struct TwoPhaseWs {
         slot_tables = nullptr; slot_tables_cap = 0;
         if (keys32) (void)hipFree(keys32);
         keys32 = nullptr; keys32_cap = 0;
+        if (slot_keys) (void)hipFree(slot_keys);
+        slot_keys = nullptr; slot_keys_cap = 0;
         if (wave_tables) (void)hipFree(wave_tables);
         wave_tables = nullptr; wave_tables_cap = 0;
         if (huff_redo) (void)hipFree(huff_redo);
@@ -442,8 +452,15 @@ static inline int twophase_predict_a(TwoPhaseWs &ws, hipStream_t s, const Parsed
             bytes += n * 17;
         } else if (c == LEAF_SMALL) {
             // beside a wide leaf's rank kernel (bound by its scattered stores) instead of beside the partition passes: see below
-            if (n_small_def < 8) small_def[n_small_def++] = pa;
-            else launch_small_shaped(ws, nd.bits - 3, nb, s, pa);
+            // (Two encodes in flight — join_all: at once on the launch stream, beside the partition passes on the side stream: the first
+            // predict half 15.4 -> 14.3 ms, 68.3 -> 67.6 ms per step; W3_OPT_TUNE bit 11 keeps the deferred order there too.)
+            if (n_small_def < 8 && (!join_all || (ws.tune & 2048u))) small_def[n_small_def++] = pa;
+            else {
+                const bool timed = ev && !ws.small_timed;
+                if (timed) { (void)hipEventRecord(ev[2 * W3_EV_SMALL], s); ws.small_timed = true; }
+                launch_small_shaped(ws, nd.bits - 3, nb, s, pa);
+                if (timed) (void)hipEventRecord(ev[2 * W3_EV_SMALL + 1], s);
+            }
         } else {
             const int w = n_def;
             pa.perm = (uint32_t *)ws.perm_w[w];
@@ -544,7 +561,48 @@ static inline int twophase_predict_b(TwoPhaseWs &ws, hipStream_t s, const Parsed
     }
     ws.n_wide = n_def;
     if (n_small_def && forked) (void)hipStreamWaitEvent(s, ws.ev_small, 0);
-    if (sa.n_leaves) {
+    // Slot-state leaves.  Few blocks: the sorted replay of w3_slot2.h (a wavefront per block; k_slot's lane per block costs the
+    // lone-lane latency of a whole block, ~200 ms per 64 KiB of block, however few there are).  Many blocks (measured crossover
+    // ~7,000: k_slot 375 ms against 460 at 15,259 blocks): k_slot.  The replay needs the lane-ordered LDS adds (its partition).
+    bool slot_sorted = false;
+    ws.slot_sorted = false;
+    if (sa.n_leaves && !(ws.variant & W3_VAR_SLOT_TABLE) && st.lds_atomics && block_size <= (1ull << 31)) {
+        slot_sorted = nb < W3_SLOT_SORTED_MAX_BLOCKS || (ws.variant & W3_VAR_SLOT_SORTED);
+        bool two_passes = false;
+        for (int l = 0; l < sa.n_leaves; l++) { slot_sorted &= sa.leaf[l].log_cells <= 16u; two_passes |= sa.leaf[l].log_cells > 8u; }
+        const size_t key_bytes = (size_t)sa.n_leaves * 2 * n * 8, hist_bytes = (size_t)sa.n_leaves * nb * 512 * 4;
+        if (slot_sorted && ws.slot_keys_cap < 2 * key_bytes + hist_bytes + 64) {
+            size_t free_b = 0, total_b = 0;
+            if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); err = "hipMemGetInfo failed"; return W3_E_HIP; }
+            if (2 * key_bytes + hist_bytes + (8ull << 30) + n * 40 > free_b + ws.slot_keys_cap) slot_sorted = false;   // (the records would not fit: k_slot batches its tables)
+        }
+        if (slot_sorted) {
+            if (!ws.st) { err = "state table not staged"; return W3_E_HIP; }
+            if ((rc = tp_ensure(ws.slot_keys, ws.slot_keys_cap, 2 * key_bytes + hist_bytes + 64, err))) return rc;
+            w3::Slot2Args s2;
+            memset(&s2, 0, sizeof s2);
+            s2.in = d_in; s2.n = n; s2.block_size = (uint32_t)block_size; s2.nblocks = nb;
+            s2.keys_a = (uint64_t *)ws.slot_keys; s2.keys_b = (uint64_t *)((uint8_t *)ws.slot_keys + key_bytes);
+            s2.hist = (uint32_t *)((uint8_t *)ws.slot_keys + 2 * key_bytes);
+            if ((rc = tp_ensure(ws.dummy, ws.dummy_cap, 2048, err))) return rc;
+            s2.st = ws.st; s2.n_leaves = sa.n_leaves; s2.fault = ws.order_fault; s2.dummy = (uint8_t *)ws.dummy;
+            for (int l = 0; l < sa.n_leaves; l++) s2.leaf[l] = sa.leaf[l];
+            if (ev) (void)hipEventRecord(ev[2 * W3_EV_SLOT], s);
+            const dim3 gw(std::min<uint32_t>(nb, 256 * 16), sa.n_leaves);
+            hipLaunchKernelGGL(w3::k_slot_events, gw, dim3(64), 0, s, s2);
+            hipLaunchKernelGGL(w3::k_slot_sort<0>, gw, dim3(64), 0, s, s2);
+            if (two_passes) hipLaunchKernelGGL(w3::k_slot_sort<1>, gw, dim3(64), 0, s, s2);   // (a leaf of at most 2^8 Cells passes through unchanged: one bin)
+            hipLaunchKernelGGL(w3::k_slot_replay, dim3((nb + W3_S2_WAVES - 1) / W3_S2_WAVES, sa.n_leaves), dim3(64 * W3_S2_WAVES), 0, s, s2, two_passes ? 1 : 0);
+            if (ev) (void)hipEventRecord(ev[2 * W3_EV_SLOT + 1], s);
+            if (tm) tm->n_slot_launches = 0;   // (no table batches)
+            hipError_t e = hipGetLastError();
+            if (e != hipSuccess) { err = std::string("slot predict launch: ") + hipGetErrorString(e); return W3_E_HIP; }
+            // per input byte and leaf: 2 events x (8 B record written, 1 or 2 passes of 8 r + 8 w, 8 B read, 8 B written) + the input
+            bytes += (uint64_t)sa.n_leaves * n * (1 + 2 * (8 + (two_passes ? 32 : 16) + 8 + 8));
+            ws.slot_sorted = true;
+        }
+    }
+    if (sa.n_leaves && !slot_sorted) {
         // HashMaps in HBM, one per (block, leaf), zeroed per batch of blocks; as many blocks at once as the budget allows
         if (!ws.st) { err = "state table not staged"; return W3_E_HIP; }
         size_t free_b = 0, total_b = 0;

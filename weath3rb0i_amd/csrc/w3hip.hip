@@ -187,7 +187,7 @@ extern "C" int w3_ctx_set_option(w3_ctx *ctx, int opt, int64_t value) {
         ctx->tp.acc_limit = (uint32_t)value;
         return W3_OK;
     case W3_OPT_VARIANT:
-        if (value < 0 || value > 255) return W3_E_INVALID;
+        if (value < 0 || value > 1023) return W3_E_INVALID;
         // the fault-injection hook exists for the test of the sampled verification: without the verification it would only corrupt output
         if ((value & W3_VAR_INJECT_LDS_FAULT) && !ctx->tp.verify) { ctx->err = "W3_OPT_VARIANT bit 32 (fault injection) needs W3_OPT_VERIFY on"; return W3_E_INVALID; }
         ctx->tp.variant = (uint32_t)value;
@@ -674,6 +674,7 @@ static int encode_core(w3_ctx *ctx, JobRef J, const w3_model_spec *spec, const u
         uint32_t fl[4] = {0, 0, 0, 0};
         if (two) {
             J.tp.out_bits = (uint32_t *)J.bits.p;
+            J.tp.order_fault = (uint32_t *)J.flag.p + 2;
 #ifdef W3_TUNING
             J.tp.apm_oob = (uint32_t *)J.flag.p + 3;
 #endif
@@ -867,6 +868,7 @@ extern "C" int w3_encode_submit(w3_ctx *ctx, const w3_model_spec *spec, const ui
     HIPCHK(ctx, hipMemsetAsync(J.flag.p, 0, 16, sp));
     if (evp) HIPCHK(ctx, hipEventRecord(evp[2 * W3_EV_TOTAL], sp));
     J.tp.out_bits = (uint32_t *)J.bits.p;
+    J.tp.order_fault = (uint32_t *)J.flag.p + 2;
 #ifdef W3_TUNING
     J.tp.apm_oob = (uint32_t *)J.flag.p + 3;
 #endif
