@@ -40,6 +40,7 @@ sys.path.insert(0, ROOT)
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
+NSETS = 4                # output buffer sets of a regime = the deepest submit / wait pipeline (W3_MAX_JOBS)
 SHADER_GHZ = 2.4        # MI355X_MICROARCH.md: max clock; the lone coder waves run at it (profiles/r2_xstep_bench.txt)
 
 
@@ -220,7 +221,8 @@ def parse_args(argv=None):
     ap.add_argument("--data", default="text", choices=["text", "mixed"], help="text = enwik-shaped, mixed = Silesia-shaped (BASELINE configs[4] with --block-size 262144 --size 211938580)")
     ap.add_argument("--block-size", type=int, default=65536)
     ap.add_argument("--path", default="auto", help="auto | generic | twophase")
-    ap.add_argument("--pipeline", type=int, default=2, choices=[1, 2], help="encodes in flight: 2 = w3_encode_submit / w3_encode_wait (default), 1 = one synchronous call per step")
+    ap.add_argument("--pipeline", type=int, default=0, choices=[0, 1, 2, 3, 4], help="encodes in flight (w3_encode_submit / w3_encode_wait): 0 = as many as w3_encode_max_in_flight allows for the shard "
+                    "(default: 2 for large inputs, 4 up to 8,192 blocks), 1 = one synchronous call per step")
     ap.add_argument("--coder", default="x4", help="two-phase coder kernel: x4 (default; pipelined and half-CU runs use x5 in its place) | x5 | x3 | x2 | fast | robust")
     ap.add_argument("--variant", default="", help="experiments: comma-separated W3_OPT_VARIANT names (Context.set_variant), e.g. no_side_stream, half_cu, full_cu")
     ap.add_argument("--tune", type=int, default=0, help="W3_OPT_TUNE bit mask (scheduling experiments)")
@@ -271,13 +273,14 @@ class Regime:
         n = self.n
         self.nb = (n + block_size - 1) // block_size
         self.d_in = torch.from_numpy(np.ascontiguousarray(self.host)).cuda()
-        # two output buffer sets: two encodes in flight, and the exchange of step k (RCCL, its own stream) overlaps step k+1
-        self.d_outs = [torch.empty(n + n // 4 + 64 * self.nb + 1024, dtype=torch.uint8, device="cuda") for _ in range(2)]
-        self.d_lenss = [torch.zeros(max(self.nb, 1), dtype=torch.int32, device="cuda") for _ in range(2)]
-        self.d_totals = [torch.zeros(1, dtype=torch.int64, device="cuda") for _ in range(2)]
+        # one output buffer set per encode in flight (2 .. 4); the exchange of step k (RCCL, its own stream) overlaps step k+1
+        self.nsets = NSETS
+        self.d_outs = [torch.empty(n + n // 4 + 64 * self.nb + 1024, dtype=torch.uint8, device="cuda") for _ in range(NSETS)]
+        self.d_lenss = [torch.zeros(max(self.nb, 1), dtype=torch.int32, device="cuda") for _ in range(NSETS)]
+        self.d_totals = [torch.zeros(1, dtype=torch.int64, device="cuda") for _ in range(NSETS)]
         self.gather_buf = (torch.empty(int(self.n_global * 0.75) + 4096, dtype=torch.uint8, device="cuda")
                            if (env["exchange"] and rank == 0 and not env.get("host_staged")) else None)
-        self.reqs = [[], []]         # outstanding exchange requests per buffer set
+        self.reqs = [[] for _ in range(NSETS)]   # outstanding exchange requests per buffer set
         self.gathered = None         # (rank totals) of the last exchange
         self.last_buf = 0
         self.stream = torch.cuda.current_stream().cuda_stream
@@ -290,7 +293,7 @@ class Regime:
     def _exchange(self, k):
         """the one exchange step: sizes all-gather + grouped send/recv of the packed streams to rank 0 (RCCL), asynchronous"""
         from weath3rb0i_amd import shard
-        other = k ^ 1
+        other = (k - 1) % self.nsets
         shard.wait_all(self.reqs[other])   # rank 0's gather buffer is reused: the previous step's transfers must have landed
         self.reqs[other] = []
         total = int(self.d_totals[k].item())
@@ -304,9 +307,10 @@ class Regime:
     def run_steps(self, ctx, model, steps, pipeline, acc=None):
         """`steps` encodes of this shard (+ exchange), at most `pipeline` in flight; acc: dict that sums w3_timing fields"""
         from weath3rb0i_amd import shard
-        pending = None
+        pending = []
+        pipeline = min(pipeline, ctx.max_in_flight(self.n, self.bs)) if pipeline > 1 else pipeline
         for i in range(steps):
-            k = i % 2
+            k = i % self.nsets
             if self.reqs[k]:
                 shard.wait_all(self.reqs[k])   # buffer set k is about to be overwritten
                 self.reqs[k] = []
@@ -314,14 +318,14 @@ class Regime:
                 ctx.encode_blocks_device(model, self.d_in, self.bs, self.d_outs[k], self.d_lenss[k], self.d_totals[k], stream=self.stream)
                 self._done(ctx, k, acc)
             else:
-                job = ctx.encode_submit(model, self.d_in, self.bs, self.d_outs[k], self.d_lenss[k], self.d_totals[k], stream=self.stream)
-                if pending is not None:
-                    ctx.encode_wait(pending[0])
-                    self._done(ctx, pending[1], acc)
-                pending = (job, k)
-        if pending is not None:
-            ctx.encode_wait(pending[0])
-            self._done(ctx, pending[1], acc)
+                if len(pending) >= pipeline:   # the oldest job's slot (and, with NSETS == the deepest pipeline, its buffer set) is needed
+                    job0, k0 = pending.pop(0)
+                    ctx.encode_wait(job0)
+                    self._done(ctx, k0, acc)
+                pending.append((ctx.encode_submit(model, self.d_in, self.bs, self.d_outs[k], self.d_lenss[k], self.d_totals[k], stream=self.stream), k))
+        for job0, k0 in pending:
+            ctx.encode_wait(job0)
+            self._done(ctx, k0, acc)
 
     def _done(self, ctx, k, acc):
         self.last_buf = k
@@ -342,7 +346,7 @@ class Regime:
         import torch.distributed as dist
         from weath3rb0i_amd import shard
         if self.env["exchange"]:
-            for k in (0, 1):
+            for k in range(self.nsets):
                 shard.wait_all(self.reqs[k])
                 self.reqs[k] = []
             dist.barrier()
@@ -420,7 +424,7 @@ def short_run(w3, model_name, data_kind, size, bs, seed, steps, env):
     ctx = w3.Context(env["local_rank"])
     try:
         model, mname = make_model(w3, model_name)
-        pipeline = 1 if model_name == "fullcm" else 2   # (slot-state leaves run synchronously inside submit anyway)
+        pipeline = 1 if model_name == "fullcm" else ctx.max_in_flight(rg.n, bs)   # (slot-state leaves run synchronously inside submit anyway)
         dt, acc = rg.timed(ctx, model, steps, 1, pipeline)
         rows = kernel_table(model_name, rg.n, bs, steps, acc, "x4" if pipeline == 1 else "x5")
         dom = max(rows, key=lambda r: r[1])
@@ -468,7 +472,6 @@ def main():
 
     bs = args.block_size
     model, model_name = make_model(w3, args.model)
-    pipeline = args.pipeline
     ctx = w3.Context(local_rank)
     ctx.set_path(args.path)
     ctx.set_coder(args.coder)
@@ -484,8 +487,11 @@ def main():
         if rg is not None:
             rg.release()
         rg = Regime(env, rd, args.size, args.data, bs, args.seed)
+        # encodes in flight for THIS reading's shard (a strong-scaled shard may be small enough for four free-running jobs)
+        pipeline = args.pipeline if args.pipeline else ctx.max_in_flight(rg.n, bs)
+        pipeline = min(pipeline, ctx.max_in_flight(rg.n, bs)) if pipeline > 1 else pipeline
         dt, acc = rg.timed(ctx, model, args.steps, args.warmup, pipeline)
-        results[rd] = {"dt": dt, "acc": acc, "n": rg.n, "n_global": rg.n_global, "nb": rg.nb,
+        results[rd] = {"dt": dt, "acc": acc, "n": rg.n, "n_global": rg.n_global, "nb": rg.nb, "pipeline": pipeline,
                        "ratio": int(rg.d_totals[rg.last_buf].item()) / max(rg.n, 1),
                        "exchange_totals": list(rg.gathered) if rg.gathered else None}
     main_rd = readings[0]
@@ -494,7 +500,7 @@ def main():
         # the main line's per-kernel figures belong to the FIRST reading; the regime object left alive is the last one's: nothing
         # below (extras run only at world == 1) needs it
         pass
-    dt, acc, n, n_global, nb = r0["dt"], r0["acc"], r0["n"], r0["n_global"], r0["nb"]
+    dt, acc, n, n_global, nb, pipeline = r0["dt"], r0["acc"], r0["n"], r0["n_global"], r0["nb"], r0["pipeline"]
     path = int(acc.get("path", 0))
     coder_name = args.coder if (args.coder != "x4" or (pipeline == 1 and "half_cu" not in args.variant)) else "x5"
 
@@ -502,10 +508,10 @@ def main():
     ref_model = decode = sync_line = None
     kept = []   # (compressed stream, lens) of the live output buffers of the timed steps
     if extras:
-        for k in sorted({rg.last_buf, rg.last_buf ^ 1} if (args.steps > 1) else {rg.last_buf}):
+        for k in sorted({(rg.last_buf - d) % rg.nsets for d in range(min(max(pipeline, 1), args.steps, rg.nsets))}):
             tot = int(rg.d_totals[k].item())
             kept.append((rg.d_outs[k][:tot].clone(), rg.d_lenss[k][:nb].clone()))
-        if pipeline == 2 and not args.no_ref_model:
+        if pipeline >= 2 and not args.no_ref_model:
             # the same workload with ONE synchronous call per step (3 steps, outside the timed region): what a lone call takes, and the
             # coder's launch with nothing beside it — the floor of a strong-scaled run
             dts, accs = rg.timed(ctx, model, 3, 1, 1)
@@ -578,7 +584,7 @@ def main():
                         "weak": "%d bytes per GPU (%d in all)" % (n, n_global)}[main_rd]
         workload = ("%s synthetic (tools/synth.c seed %d), %s scaling: %s, %d-byte blocks, model %s, %s"
                     % ("enwik9-shaped text" if args.data == "text" else "Silesia-shaped mix", args.seed, main_rd, readings_txt, bs, model_name,
-                       "two encodes in flight (w3_encode_submit / w3_encode_wait)" if pipeline == 2 else "one synchronous call per step"))
+                       "%d encodes in flight (w3_encode_submit / w3_encode_wait)" % pipeline if pipeline >= 2 else "one synchronous call per step"))
         # the predict phase is several kernels; as a whole: algorithmic bytes (per leaf input + 16-byte stream, plus 8 B written + 8 B read
         # per record pass of a wide leaf) over the phase's time.  w3_timing.predict_bytes also carries the APM stages' bytes: take the
         # single ORDER0 stage's out again; models with slot leaves or several stages get no predict-phase figure
@@ -645,6 +651,21 @@ def main():
             except Exception as e:   # an extra must not lose the main line
                 oc.append({"context_model": mname, "data": kind, "error": str(e)[:300]})
         res["other_configs"] = oc
+        # Small inputs of the bench model (w3_encode_max_in_flight = 4 free-running jobs): configs[1] at its literal enwik8 size, and ONE
+        # RANK'S SHARE of the stream at 8 GPUs — the strong reading's per-GPU work, measured here on one GPU; 8 x its rate (minus the
+        # exchange, which overlaps the next step) is what an 8-GPU strong-scaled run can reach
+        sm = []
+        for label, size in (("configs[1] at enwik8 size", 100_000_000), ("one rank's share of the stream at 8 GPUs (strong reading)", args.size // 8 // bs * bs)):
+            try:
+                r = short_run(w3, args.model, "text", size, bs, args.seed, 12, env)
+                r["what"] = label
+                if "share" in label:
+                    r["projected_8gpu_strong_MiBps"] = round(8 * r["value"], 1)
+                    r["note"] = "projection = 8 x this rate: the ranks code disjoint block ranges with no data-path collective; the gather of ~0.38 x bytes to rank 0 overlaps the next step"
+                sm.append(r)
+            except Exception as e:
+                sm.append({"what": label, "error": str(e)[:300]})
+        res["small_inputs"] = sm
 
     if rank == 0:
         if extras and not args.no_cpu_baseline:

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define W3_ABI_VERSION 6
+#define W3_ABI_VERSION 7
 
 /* ---- error codes --------------------------------------------------------- */
 enum {
@@ -189,16 +189,22 @@ int w3_decode_blocks_device(w3_ctx *ctx, const w3_model_spec *spec,
                             const uint8_t *d_in, size_t in_len, const uint32_t *d_block_lens, size_t nblocks,
                             size_t block_size, uint64_t orig_len, uint8_t *d_out, void *stream);
 
-/* ---- the same encode, asynchronous: up to TWO calls in flight per context -----------------------------
+/* ---- the same encode, asynchronous: two to four calls in flight per context --------------------------
  * The reference codes one bit at a time on one thread (main.rs:103-109); here a call is three phases with different
  * bottlenecks (predict: the store path; APM: LDS round trips; coder: one latency chain per lane on 239 of 256 CUs), and a
  * single call runs them one after the other.  w3_encode_submit only ENQUEUES: call k+1's predict phase then executes beside
  * call k's APM and coder kernels (each job has its own workspace; kernel shapes that share a CU's LDS: DESIGN.md 2.8).
- *   w3_encode_submit  arguments as w3_encode_blocks_device (d_total is required); *job receives a handle (0 or 1).  The
+ *   w3_encode_submit  arguments as w3_encode_blocks_device (d_total is required); *job receives a handle (0 .. 3).  The
  *                     input must stay valid and the outputs untouched until the job has been waited for.  `stream`: the
  *                     stream d_in was produced on (the job starts after the work enqueued there so far).  W3_E_INVALID when
- *                     two jobs are in flight already.  Specs the predict kernels do not cover, and specs with slot-state
- *                     leaves, run synchronously inside the call (still completed by w3_encode_wait).
+ *                     w3_encode_max_in_flight(n, block_size) jobs are in flight already.  Specs the predict kernels do not
+ *                     cover, and specs with slot-state leaves, run synchronously inside the call (still completed by
+ *                     w3_encode_wait).
+ *   w3_encode_max_in_flight  how many submitted calls of this size one context keeps in flight: 2 for large inputs (the
+ *                     ordered pair of DESIGN.md 2.8: step k's coder beside step k+1's rank kernels; a job workspace is
+ *                     ~70 bytes per input byte), 4 up to 8,192 blocks — there a call's coder is a latency chain on a few
+ *                     CUs of an otherwise idle chip (one 64 KiB block: 17 ms), so the jobs run free, every code stage on a
+ *                     stream of its own, and the coders of up to four calls overlap (enwik8 size: 3,9xx -> see DESIGN.md 5).
  *   w3_encode_wait    blocks until the job is complete; returns what w3_encode_blocks_device would have returned
  *                     (W3_E_NOSPACE included; d_total holds the need).  Jobs may be waited for in any order.
  * Every other entry point returns W3_E_INVALID while a job is in flight.  Output is byte-identical to the synchronous
@@ -208,6 +214,7 @@ int w3_encode_submit(w3_ctx *ctx, const w3_model_spec *spec,
                      uint8_t *d_out, size_t out_cap,
                      uint32_t *d_block_lens, uint64_t *d_total, void *stream, int *job);
 int w3_encode_wait(w3_ctx *ctx, int job);
+int w3_encode_max_in_flight(size_t n, size_t block_size);
 
 /* ---- sharding over several GPUs from ONE process (C, C++ or Rust hosts) ---------------------------
  * Blocks are independent (fresh model + coder each), so they shard with no data-path collective: context r codes the

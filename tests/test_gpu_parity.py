@@ -355,6 +355,7 @@ def test_submit_wait_pipeline(ctx, oracle):
     torch.cuda.synchronize()
     want = {(k, nm): oracle.encode_blocks(pair(oracle, nm)[1](), datas[k], bs, nthreads=8) for k in range(2) for nm in names}
     ctx.set_timing(True)
+    ctx.set_tune(4096)   # the ordered pair of large inputs (inputs of this size would run as four free-running jobs: next test)
     try:
         pending = []   # (job, buffer index, data index, name)
         seq = [(i % 2, names[i % len(names)]) for i in range(10)]
@@ -387,6 +388,7 @@ def test_submit_wait_pipeline(ctx, oracle):
             ctx.encode_wait(0)   # nothing in flight
     finally:
         ctx.set_timing(False)
+        ctx.set_tune(0)
     # the synchronous call in the pipeline's kernel shapes, and the submitted call in the plain shapes: same streams
     for variant in ("half_cu", "full_cu"):
         ctx.set_variant(variant)
@@ -397,6 +399,65 @@ def test_submit_wait_pipeline(ctx, oracle):
             assert bufs[0][0][: int(bufs[0][2].item())].cpu().numpy().tobytes() == want[(0, "best012")][0].tobytes(), variant
         finally:
             ctx.set_variant()
+
+
+def test_submit_wait_four_free_running_jobs(ctx, oracle):
+    """Inputs of at most 8,192 blocks (w3_encode_max_in_flight == 4): four submitted calls in flight, every code stage on its own
+    stream so that the calls' coders overlap.  Different inputs and specs in flight together, waited for out of order, slots
+    reused over many submissions; a fifth submission is refused; an ordered job (W3_OPT_TUNE bit 12) followed by free-running
+    ones; every output equals the oracle's."""
+    import torch
+    from weath3rb0i_amd import _lib as L
+    bs = 2048
+    datas = [markov_text(200 * 1024 + 333, seed=41) + bytes(30 * 1024), lcg_text(150 * 1024 + 7, seed=19) + markov_text(90 * 1024, seed=42),
+             markov_text(64 * 1024 + 1, seed=43)]
+    names = ["best012", "o012_apm", "order0", "main_default", "apm_chain"]
+    models = {"o012_apm": (lambda: w3.APM(w3.BestOfTwoModel(w3.BestOfTwoModel(w3.Order0(), w3.Order1()), w3.OrderN(27, 3))),
+                           lambda: oracle.APM(oracle.BestOfTwoModel(oracle.BestOfTwoModel(oracle.Order0(), oracle.Order1()), oracle.OrderN(27, 3)))),
+              "apm_chain": (lambda: w3.APM(w3.APM(w3.Order1(), 0, 7), 1, 6), lambda: oracle.APM(oracle.APM(oracle.Order1(), 0, 7), oracle.APM_ORDER1, 6))}
+    mk = lambda nm: models[nm] if nm in models else pair(oracle, nm)
+    assert ctx.max_in_flight(len(datas[0]), bs) == 4 and ctx.max_in_flight(10**9, 65536) == 2 and ctx.max_in_flight(8192 * 65536, 65536) == 4
+    d_ins = [torch.from_numpy(np.frombuffer(d, dtype=np.uint8).copy()).cuda() for d in datas]
+    bufs = _device_bufs(max(len(d) for d in datas), bs, 4)
+    torch.cuda.synchronize()
+    want = {(k, nm): oracle.encode_blocks(mk(nm)[1](), datas[k], bs, nthreads=8) for k in range(3) for nm in names}
+
+    def finish(entry):
+        job, bi, kk, nn = entry
+        ctx.encode_wait(job)
+        d_out, d_lens, d_total = bufs[bi]
+        w_out, w_lens = want[(kk, nn)]
+        assert d_lens[:len(w_lens)].cpu().numpy().astype(np.uint32).tolist() == w_lens.tolist(), (kk, nn)
+        assert d_out[: int(d_total.item())].cpu().numpy().tobytes() == w_out.tobytes(), (kk, nn)
+
+    rng = np.random.default_rng(5)
+    pending, free = [], [0, 1, 2, 3]
+    refused = False
+    for i in range(22):
+        if len(pending) == 4:
+            if not refused:
+                with pytest.raises(w3.W3Error) as e:   # all four slots busy
+                    ctx.encode_submit(mk("order0")[0](), d_ins[0], bs, *bufs[0])
+                assert e.value.code == L.W3_E_INVALID
+                refused = True
+            entry = pending.pop(int(rng.integers(0, len(pending))))   # any order
+            finish(entry)
+            free.append(entry[1])
+        k, nm = i % 3, names[i % len(names)]
+        bi = free.pop(0)
+        if i == 9:
+            while len(pending) > 1:   # (an ordered job is one of at most two in flight)
+                entry = pending.pop(0)
+                finish(entry)
+                free.append(entry[1])
+            ctx.set_tune(4096)    # one ordered job among the free-running ones: its code stage is enqueued by the next submit (or its wait)
+        job = ctx.encode_submit(mk(nm)[0](), d_ins[k], bs, *bufs[bi])
+        if i == 9:
+            ctx.set_tune(0)
+        assert 0 <= job < 4 and job not in [p[0] for p in pending]
+        pending.append((job, bi, k, nm))
+    for entry in reversed(pending):
+        finish(entry)
 
 
 def test_submit_wait_redo_paths(ctx, oracle):

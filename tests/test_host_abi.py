@@ -29,7 +29,7 @@ def test_exports_match_header(lib):
         assert hasattr(lib, name), "libw3hip.so does not export %s" % name
     assert declared == set(L.EXPORTS)
     m = re.search(r"#define W3_ABI_VERSION (\d+)", open(os.path.join(ROOT, "include", "w3hip.h")).read())
-    assert lib.w3_abi_version() == int(m.group(1)) == 6
+    assert lib.w3_abi_version() == int(m.group(1)) == 7
 
 
 def test_integration_doc_binds_every_export():

@@ -46,7 +46,7 @@ class Timing(C.Structure):
 EXPORTS = [
     "w3_abi_version", "w3_strerror", "w3_last_error", "w3_ctx_create", "w3_ctx_destroy", "w3_spec_validate",
     "w3_ctx_set_option", "w3_max_compressed_size", "w3_encode_blocks", "w3_decode_blocks", "w3_encode_blocks_device",
-    "w3_decode_blocks_device", "w3_encode_submit", "w3_encode_wait", "w3_compress_stream", "w3_decompress_stream", "w3_predict_blocks", "w3_stationary_table",
+    "w3_decode_blocks_device", "w3_encode_submit", "w3_encode_wait", "w3_encode_max_in_flight", "w3_compress_stream", "w3_decompress_stream", "w3_predict_blocks", "w3_stationary_table",
     "w3_get_timing", "w3_selftest_counter_p", "w3_debug_get_stamps", "w3_state_table", "w3_stretch_squash", "w3_huff_tables",
     "w3_shard_range", "w3_encode_blocks_sharded", "w3_encode_blocks_sharded_device", "w3_encode_stats", "w3_encode_stats_device", "w3_sweep_ordern", "w3_sweep_ordern_device", "w3_export_counters",
 ]
@@ -89,6 +89,8 @@ def load():
     lib.w3_decode_blocks_device.argtypes = [vp, C.POINTER(ModelSpec), vp, sz, vp, sz, sz, C.c_uint64, vp, vp]
     lib.w3_encode_submit.argtypes = [vp, C.POINTER(ModelSpec), vp, sz, sz, vp, sz, vp, vp, vp, C.POINTER(C.c_int)]
     lib.w3_encode_wait.argtypes = [vp, C.c_int]
+    lib.w3_encode_max_in_flight.argtypes = [sz, sz]
+    lib.w3_encode_max_in_flight.restype = C.c_int
     lib.w3_compress_stream.argtypes = [vp, C.POINTER(ModelSpec), vp, sz, vp, sz, C.POINTER(sz)]
     lib.w3_decompress_stream.argtypes = [vp, C.POINTER(ModelSpec), vp, sz, vp, sz, C.POINTER(sz)]
     lib.w3_predict_blocks.argtypes = [vp, C.POINTER(ModelSpec), vp, sz, sz, vp]

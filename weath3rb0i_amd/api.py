@@ -212,6 +212,10 @@ class Context:
         self._chk(rc)
         return job.value
 
+    def max_in_flight(self, n, block_size):
+        """w3_encode_max_in_flight: submitted calls of this size one context keeps in flight (4 up to 8,192 blocks, else 2)."""
+        return int(self.lib.w3_encode_max_in_flight(int(n), int(block_size)))
+
     def encode_wait(self, job):
         """w3_encode_wait: block until the job's output is complete (raises what the synchronous call would have raised)."""
         self._chk(self.lib.w3_encode_wait(self.h, int(job)))

@@ -51,7 +51,14 @@ struct JobState {
     uint32_t *d_block_lens = nullptr; uint64_t *d_total = nullptr;
     w3_timing tm{};
     bool has_apm = false, has_slot = false, timed = false;
+    hipStream_t sc = nullptr;      // the stream this job's code stage runs on (free-running jobs: one each; ordered jobs share s_code[0])
 };
+
+// Jobs in flight: W3_MAX_JOBS when the input is small enough that a call's coder leaves most of the chip idle (at most
+// W3_FREE_RUN_BLOCKS blocks = 128 coder workgroups: the code stages then run each on its own stream and overlap one another),
+// two otherwise (the ordered pipeline of DESIGN.md section 2.8; its workspaces are 70 bytes per input byte each).
+#define W3_MAX_JOBS 4
+#define W3_FREE_RUN_BLOCKS 8192u
 
 struct w3_ctx {
     int device = 0;
@@ -65,10 +72,10 @@ struct w3_ctx {
     DevBuf tables, stripes, lens, offs, total, flag, io_in, io_out, coffs, misc, cm_luts, achash_luts, huff, bits, sweep;
     TwoPhaseWs tp;
     // the second job of the submit / wait pipeline
-    struct Job1 { TwoPhaseWs tp; DevBuf stripes, flag, bits, offs, huff; hipEvent_t ev[W3_NEV]{}; } j1;
-    JobState js[2];
-    hipStream_t s_pred = nullptr, s_code = nullptr;   // created by the first w3_encode_submit
-    int next_job = 0;
+    struct JobWs { TwoPhaseWs tp; DevBuf stripes, flag, bits, offs, huff; hipEvent_t ev[W3_NEV]{}; } jx[W3_MAX_JOBS - 1];
+    JobState js[W3_MAX_JOBS];
+    hipStream_t s_pred = nullptr, s_code[W3_MAX_JOBS] = {};   // created by the first w3_encode_submit
+    int next_job = 0, last_job = -1;
 };
 
 // the members of job j under one name
@@ -77,7 +84,8 @@ struct JobRef {
 };
 static JobRef jobref(w3_ctx *c, int j) {
     if (j == 0) return JobRef{c->tp, c->stripes, c->flag, c->bits, c->offs, c->huff, c->ev, c->js[0]};
-    return JobRef{c->j1.tp, c->j1.stripes, c->j1.flag, c->j1.bits, c->j1.offs, c->j1.huff, c->j1.ev, c->js[1]};
+    w3_ctx::JobWs &x = c->jx[j - 1];
+    return JobRef{x.tp, x.stripes, x.flag, x.bits, x.offs, x.huff, x.ev, c->js[j]};
 }
 
 #define HIPCHK(ctx, expr)                                                                       \
@@ -149,11 +157,13 @@ extern "C" void w3_ctx_destroy(w3_ctx *ctx) {
     for (DevBuf *b : bufs)
         if (b->p) (void)hipFree(b->p);
     ctx->tp.release();
-    ctx->j1.tp.release();
-    DevBuf *bufs1[] = {&ctx->j1.stripes, &ctx->j1.flag, &ctx->j1.bits, &ctx->j1.offs, &ctx->j1.huff};
-    for (DevBuf *b : bufs1)
-        if (b->p) (void)hipFree(b->p);
-    for (auto &e : ctx->j1.ev) if (e) (void)hipEventDestroy(e);
+    for (auto &x : ctx->jx) {
+        x.tp.release();
+        DevBuf *bufs1[] = {&x.stripes, &x.flag, &x.bits, &x.offs, &x.huff};
+        for (DevBuf *b : bufs1)
+            if (b->p) (void)hipFree(b->p);
+        for (auto &e : x.ev) if (e) (void)hipEventDestroy(e);
+    }
     for (auto &st : ctx->js) {
         if (st.ev_done) (void)hipEventDestroy(st.ev_done);
         if (st.ev_in) (void)hipEventDestroy(st.ev_in);
@@ -162,7 +172,7 @@ extern "C" void w3_ctx_destroy(w3_ctx *ctx) {
         if (st.h_status) (void)hipHostFree(st.h_status);
     }
     if (ctx->s_pred) (void)hipStreamDestroy(ctx->s_pred);
-    if (ctx->s_code) (void)hipStreamDestroy(ctx->s_code);
+    for (auto &sc : ctx->s_code) if (sc) (void)hipStreamDestroy(sc);
     for (auto &e : ctx->ev)
         if (e) (void)hipEventDestroy(e);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -700,7 +710,7 @@ static int encode_core(w3_ctx *ctx, JobRef J, const w3_model_spec *spec, const u
             fault_seen = true;
             lds_faults += fl[2];
             ctx->tp.variant |= W3_VAR_NO_LDS_ATOMICS; ctx->tp.lds_order = 0;
-            ctx->j1.tp.variant |= W3_VAR_NO_LDS_ATOMICS; ctx->j1.tp.lds_order = 0;
+            for (auto &x : ctx->jx) { x.tp.variant |= W3_VAR_NO_LDS_ATOMICS; x.tp.lds_order = 0; }
             ctx->timing.n_recoded_blocks = 0;
             continue;
         }
@@ -746,7 +756,8 @@ static int encode_core(w3_ctx *ctx, JobRef J, const w3_model_spec *spec, const u
 }
 
 static int jobs_idle(w3_ctx *ctx) {
-    if (ctx->js[0].state == 1 || ctx->js[1].state == 1) { ctx->err = "asynchronous jobs are in flight on this context: w3_encode_wait them first"; return W3_E_INVALID; }
+    for (const auto &st : ctx->js)
+        if (st.state == 1) { ctx->err = "asynchronous jobs are in flight on this context: w3_encode_wait them first"; return W3_E_INVALID; }
     return W3_OK;
 }
 
@@ -769,30 +780,34 @@ static int ensure_pipeline(w3_ctx *ctx) {
     // The two stages must not share a hardware queue (HIP maps streams onto GPU_MAX_HW_QUEUES = 4 queues per priority level by
     // default, round-robin: two streams of one level can land on the same queue and then run one after the other).  Streams of
     // different PRIORITY levels use different queues: the code stage — it carries the latency chain — gets the high level.
-    if (!ctx->s_pred || !ctx->s_code) {
+    if (!ctx->s_pred || !ctx->s_code[W3_MAX_JOBS - 1]) {
         int lo_p = 0, hi_p = 0;
         HIPCHK(ctx, hipDeviceGetStreamPriorityRange(&lo_p, &hi_p));
         const bool pred_high = (ctx->tp.tune & 1u) != 0;   // W3_OPT_TUNE bit 0
         if (!ctx->s_pred) HIPCHK(ctx, hipStreamCreateWithPriority(&ctx->s_pred, hipStreamNonBlocking, pred_high ? hi_p : 0));
-        if (!ctx->s_code) HIPCHK(ctx, hipStreamCreateWithPriority(&ctx->s_code, hipStreamNonBlocking, (pred_high || (ctx->tp.tune & 16u)) ? 0 : hi_p));
+        // (created one after the other on one level: HIP deals that level's hardware queues out round-robin, so the W3_MAX_JOBS = 4 code
+        // streams get a queue each and the free-running jobs' coders really run side by side)
+        for (auto &sc : ctx->s_code)
+            if (!sc) HIPCHK(ctx, hipStreamCreateWithPriority(&sc, hipStreamNonBlocking, (pred_high || (ctx->tp.tune & 16u)) ? 0 : hi_p));
     }
-    for (int j = 0; j < 2; j++) {
+    for (int j = 0; j < W3_MAX_JOBS; j++) {
         JobState &st = ctx->js[j];
         if (!st.ev_done) HIPCHK(ctx, hipEventCreateWithFlags(&st.ev_done, hipEventDisableTiming));
         if (!st.ev_in) HIPCHK(ctx, hipEventCreateWithFlags(&st.ev_in, hipEventDisableTiming));
         if (!st.ev_a) HIPCHK(ctx, hipEventCreateWithFlags(&st.ev_a, hipEventDisableTiming));
         if (!st.ev_apm) HIPCHK(ctx, hipEventCreateWithFlags(&st.ev_apm, hipEventDisableTiming));
         if (!st.h_status) HIPCHK(ctx, hipHostMalloc((void **)&st.h_status, 32, hipHostMallocDefault));
-        for (auto &e : ctx->j1.ev)
-            if (!e) HIPCHK(ctx, hipEventCreate(&e));
     }
+    for (auto &x : ctx->jx)
+        for (auto &e : x.ev)
+            if (!e) HIPCHK(ctx, hipEventCreate(&e));
     return W3_OK;
 }
 
 // APM stages + coder + pack + status read-back of an enqueued job, on the code stream
 static int enqueue_code(w3_ctx *ctx, JobRef &J, hipEvent_t wait_ev, hipEvent_t rec_after_apm) {
     JobState &st = J.st;
-    hipStream_t sp = ctx->s_pred, sc = ctx->s_code;
+    hipStream_t sp = ctx->s_pred, sc = st.sc;
     hipEvent_t *evp = st.timed ? J.ev : nullptr;
     int rc = tp_code_stage(J.tp, sp, sc, st.ps, st.d_in, st.n, st.block_size, st.nb, (uint8_t *)J.stripes.p, st.cap, st.d_block_lens, (uint32_t *)J.flag.p,
                            wait_ev, rec_after_apm, evp, &st.tm, ctx->err);
@@ -818,22 +833,35 @@ extern "C" int w3_encode_submit(w3_ctx *ctx, const w3_model_spec *spec, const ui
     if (!d_total) { ctx->err = "w3_encode_submit needs d_total"; return W3_E_INVALID; }
     ParsedSpec ps;
     if ((rc = parse_spec(spec, ps))) { ctx->err = "malformed model spec"; return rc; }
-    const int j = ctx->next_job;
-    if (ctx->js[j].state != 0) { ctx->err = "two jobs are in flight already: w3_encode_wait the older one first"; return W3_E_INVALID; }
-    HIPCHK(ctx, hipSetDevice(ctx->device));
     const uint32_t nb = (uint32_t)((n + block_size - 1) / block_size);
+    // small inputs: free-running jobs, up to W3_MAX_JOBS of them, every code stage on its own stream; large ones: the ordered pair
+    const bool free_run = nb <= W3_FREE_RUN_BLOCKS && !(ctx->tp.tune & 4096u);   // (W3_OPT_TUNE bit 12: the ordered pair whatever the size)
+    const int depth = free_run ? W3_MAX_JOBS : 2;
+    int in_flight = 0;
+    for (const auto &o : ctx->js) in_flight += o.state != 0;
+    int j = ctx->next_job % depth;
+    if (ctx->js[j].state != 0) {   // (a free slot further on: jobs may be waited for in any order)
+        for (int k = 0; k < depth; k++)
+            if (ctx->js[k].state == 0) { j = k; break; }
+    }
+    if (in_flight >= depth || ctx->js[j].state != 0) {
+        ctx->err = std::to_string(in_flight) + " jobs are in flight already (at most " + std::to_string(depth) + " for an input of this size): w3_encode_wait the oldest one first";
+        return W3_E_INVALID;
+    }
+    HIPCHK(ctx, hipSetDevice(ctx->device));
     const bool two = nb > 0 && twophase_supported(ps, block_size, n) && ctx->opt_path != W3_PATH_GENERIC;
     if (!two || ps.has_slot) {
         // Not pipelined: the lane-per-block kernels (any spec the predict kernels do not cover) and specs with slot-state leaves
         // (their hash maps are sized from the memory that is free at the time) run to completion here, on job 0's workspace.
-        if (ctx->js[0].state == 1 || ctx->js[1].state == 1) {   // let the other job's kernels finish first; its status is in pinned memory already
-            const JobState &o = ctx->js[ctx->js[0].state == 1 ? 0 : 1];
-            HIPCHK(ctx, hipEventSynchronize(o.ev_done));
+        for (int k = 0; k < W3_MAX_JOBS; k++) {   // let the other jobs' kernels finish first; their status is in pinned memory already
+            if (ctx->js[k].state != 1) continue;
+            if (ctx->js[k].code_pending) { JobRef O = jobref(ctx, k); if ((rc = enqueue_code(ctx, O, nullptr, nullptr))) return rc; }
+            HIPCHK(ctx, hipEventSynchronize(ctx->js[k].ev_done));
         }
         rc = encode_core(ctx, jobref(ctx, 0), spec, d_in, n, block_size, d_out, out_cap, d_block_lens, d_total, stream);
         if (rc) return rc;
         ctx->js[j].state = 2; ctx->js[j].tm = ctx->timing;
-        *job = j; ctx->next_job = j ^ 1;
+        *job = j; ctx->next_job = j + 1; ctx->last_job = j;
         return W3_OK;
     }
     if ((rc = ensure_pipeline(ctx))) return rc;
@@ -846,6 +874,7 @@ extern "C" int w3_encode_submit(w3_ctx *ctx, const w3_model_spec *spec, const ui
     st.d_in = d_in; st.n = n; st.block_size = block_size; st.d_out = d_out; st.out_cap = out_cap; st.d_block_lens = d_block_lens; st.d_total = d_total;
     st.has_apm = ps.n_apm > 0; st.has_slot = false; st.timed = ctx->opt_timing != 0;
     st.nb = nb;
+    st.sc = free_run ? ctx->s_code[j] : ctx->s_code[0];
     memset(&st.tm, 0, sizeof st.tm);
     hipStream_t sp = ctx->s_pred;
     // after whatever produced d_in on the caller's stream
@@ -877,12 +906,19 @@ extern "C" int w3_encode_submit(w3_ctx *ctx, const w3_model_spec *spec, const ui
     // by their scattered stores, and the coder, one latency chain per lane, run well side by side):
     //     first predict half of THIS job  ->  APM stages of the OTHER job  ->  coder of the other job  BESIDE  rank kernels of this job
     // So the other job's code stage is enqueued here, between this job's two predict halves (W3_OPT_TUNE bit 2: no such order).
-    const bool ordered = !(ctx->tp.tune & 4u);
-    JobRef O = jobref(ctx, j ^ 1);
+    // Free-running jobs (small inputs) need no such order: the chip is mostly idle while a call is coded, so every job's code stage
+    // goes to its own stream at once and the coders of up to W3_MAX_JOBS calls run side by side (each a latency chain on a few CUs).
+    const bool ordered = !(ctx->tp.tune & 4u) && !free_run;
+    const int prev = ctx->last_job >= 0 && ctx->last_job != j && ctx->js[ctx->last_job].state == 1 && ctx->js[ctx->last_job].code_pending ? ctx->last_job : -1;
+    if (prev >= 0 && !ordered) {   // (an ordered job before a free-running one: its code stage goes out now)
+        JobRef O = jobref(ctx, prev);
+        if ((rc = enqueue_code(ctx, O, nullptr, nullptr))) return rc;
+    }
     rc = twophase_predict_a(J.tp, sp, ps, d_in, n, block_size, nb, evp, ctx->err, ordered);
     if (!rc && ordered) {
         HIPCHK(ctx, hipEventRecord(st.ev_a, sp));
-        if (O.st.state == 1 && O.st.code_pending) {
+        if (prev >= 0) {
+            JobRef O = jobref(ctx, prev);
             rc = enqueue_code(ctx, O, st.ev_a, O.st.ev_apm);
             if (!rc) HIPCHK(ctx, hipStreamWaitEvent(sp, O.st.ev_apm, 0));
         }
@@ -898,12 +934,17 @@ extern "C" int w3_encode_submit(w3_ctx *ctx, const w3_model_spec *spec, const ui
         st.state = 0; st.code_pending = false;
         return rc;
     }
-    *job = j; ctx->next_job = j ^ 1;
+    *job = j; ctx->next_job = j + 1; ctx->last_job = j;
     return W3_OK;
 }
 
+extern "C" int w3_encode_max_in_flight(size_t n, size_t block_size) {
+    if (!block_size) return 0;
+    return (n + block_size - 1) / block_size <= W3_FREE_RUN_BLOCKS ? W3_MAX_JOBS : 2;
+}
+
 extern "C" int w3_encode_wait(w3_ctx *ctx, int job) {
-    if (!ctx || job < 0 || job > 1) return W3_E_INVALID;
+    if (!ctx || job < 0 || job >= W3_MAX_JOBS) return W3_E_INVALID;
     JobRef J = jobref(ctx, job);
     JobState &st = J.st;
     if (st.state == 0) { ctx->err = "no such job in flight"; return W3_E_INVALID; }
@@ -925,7 +966,10 @@ extern "C" int w3_encode_wait(w3_ctx *ctx, int job) {
         // rounds misbehave.  Let the other job's kernels finish (its output is complete then, its status in pinned memory) and
         // run this call again synchronously on this job's workspace: encode_core's own retry loop deals with each case.
         HIPCHK(ctx, hipDeviceSynchronize());
-        if (mism) { ctx->tp.variant |= W3_VAR_NO_LDS_ATOMICS; ctx->tp.lds_order = 0; ctx->j1.tp.variant |= W3_VAR_NO_LDS_ATOMICS; ctx->j1.tp.lds_order = 0; }
+        if (mism) {
+            ctx->tp.variant |= W3_VAR_NO_LDS_ATOMICS; ctx->tp.lds_order = 0;
+            for (auto &x : ctx->jx) { x.tp.variant |= W3_VAR_NO_LDS_ATOMICS; x.tp.lds_order = 0; }
+        }
         const int rc = encode_core(ctx, J, &st.spec, st.d_in, st.n, st.block_size, st.d_out, st.out_cap, st.d_block_lens, st.d_total, ctx->stream);
         ctx->timing.n_lds_faults += mism;
         return rc;
