@@ -222,7 +222,7 @@ def parse_args(argv=None):
     ap.add_argument("--block-size", type=int, default=65536)
     ap.add_argument("--path", default="auto", help="auto | generic | twophase")
     ap.add_argument("--pipeline", type=int, default=0, choices=[0, 1, 2, 3, 4], help="encodes in flight (w3_encode_submit / w3_encode_wait): 0 = as many as w3_encode_max_in_flight allows for the shard "
-                    "(default: 2 for large inputs, 4 up to 8,192 blocks), 1 = one synchronous call per step")
+                    "(default: 4 up to 4,096 blocks, 3 up to 12,288, 2 beyond), 1 = one synchronous call per step")
     ap.add_argument("--coder", default="x4", help="two-phase coder kernel: x4 (default; pipelined and half-CU runs use x5 in its place) | x5 | x3 | x2 | fast | robust")
     ap.add_argument("--variant", default="", help="experiments: comma-separated W3_OPT_VARIANT names (Context.set_variant), e.g. no_side_stream, half_cu, full_cu")
     ap.add_argument("--tune", type=int, default=0, help="W3_OPT_TUNE bit mask (scheduling experiments)")
@@ -308,7 +308,7 @@ class Regime:
         """`steps` encodes of this shard (+ exchange), at most `pipeline` in flight; acc: dict that sums w3_timing fields"""
         from weath3rb0i_amd import shard
         pending = []
-        pipeline = min(pipeline, ctx.max_in_flight(self.n, self.bs)) if pipeline > 1 else pipeline
+        pipeline = min(pipeline, max(ctx.max_in_flight(self.n, self.bs), self.env.get("force_depth", 0))) if pipeline > 1 else pipeline
         for i in range(steps):
             k = i % self.nsets
             if self.reqs[k]:
@@ -489,7 +489,9 @@ def main():
         rg = Regime(env, rd, args.size, args.data, bs, args.seed)
         # encodes in flight for THIS reading's shard (a strong-scaled shard may be small enough for four free-running jobs)
         pipeline = args.pipeline if args.pipeline else ctx.max_in_flight(rg.n, bs)
-        pipeline = min(pipeline, ctx.max_in_flight(rg.n, bs)) if pipeline > 1 else pipeline
+        if args.tune & 8192:
+            env["force_depth"] = 3   # (experiment: free-running jobs beyond 12,288 blocks)
+        pipeline = min(pipeline, max(ctx.max_in_flight(rg.n, bs), env.get("force_depth", 0))) if pipeline > 1 else pipeline
         dt, acc = rg.timed(ctx, model, args.steps, args.warmup, pipeline)
         results[rd] = {"dt": dt, "acc": acc, "n": rg.n, "n_global": rg.n_global, "nb": rg.nb, "pipeline": pipeline,
                        "ratio": int(rg.d_totals[rg.last_buf].item()) / max(rg.n, 1),

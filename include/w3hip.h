@@ -200,11 +200,11 @@ int w3_decode_blocks_device(w3_ctx *ctx, const w3_model_spec *spec,
  *                     w3_encode_max_in_flight(n, block_size) jobs are in flight already.  Specs the predict kernels do not
  *                     cover, and specs with slot-state leaves, run synchronously inside the call (still completed by
  *                     w3_encode_wait).
- *   w3_encode_max_in_flight  how many submitted calls of this size one context keeps in flight: 2 for large inputs (the
- *                     ordered pair of DESIGN.md 2.8: step k's coder beside step k+1's rank kernels; a job workspace is
- *                     ~70 bytes per input byte), 4 up to 8,192 blocks — there a call's coder is a latency chain on a few
- *                     CUs of an otherwise idle chip (one 64 KiB block: 17 ms), so the jobs run free, every code stage on a
- *                     stream of its own, and the coders of up to four calls overlap (enwik8 size: 3,9xx -> see DESIGN.md 5).
+ *   w3_encode_max_in_flight  how many submitted calls of this size one context keeps in flight: 4 up to 4,096 blocks, 3 up to
+ *                     12,288 — there a call's coder is a latency chain on part of an otherwise idle chip (one 64 KiB block:
+ *                     17 ms), so the jobs run free, every code stage on a stream of its own, and the calls' coders overlap
+ *                     (enwik8 size: 3,893 -> 9,339 MiB/s) — and 2 beyond (the ordered pair of DESIGN.md 2.8:
+ *                     step k's coder beside step k+1's rank kernels; a job workspace is ~70 bytes per input byte).
  *   w3_encode_wait    blocks until the job is complete; returns what w3_encode_blocks_device would have returned
  *                     (W3_E_NOSPACE included; d_total holds the need).  Jobs may be waited for in any order.
  * Every other entry point returns W3_E_INVALID while a job is in flight.  Output is byte-identical to the synchronous

@@ -402,7 +402,7 @@ def test_submit_wait_pipeline(ctx, oracle):
 
 
 def test_submit_wait_four_free_running_jobs(ctx, oracle):
-    """Inputs of at most 8,192 blocks (w3_encode_max_in_flight == 4): four submitted calls in flight, every code stage on its own
+    """Inputs of at most 4,096 blocks (w3_encode_max_in_flight == 4): four submitted calls in flight, every code stage on its own
     stream so that the calls' coders overlap.  Different inputs and specs in flight together, waited for out of order, slots
     reused over many submissions; a fifth submission is refused; an ordered job (W3_OPT_TUNE bit 12) followed by free-running
     ones; every output equals the oracle's."""
@@ -416,7 +416,7 @@ def test_submit_wait_four_free_running_jobs(ctx, oracle):
                            lambda: oracle.APM(oracle.BestOfTwoModel(oracle.BestOfTwoModel(oracle.Order0(), oracle.Order1()), oracle.OrderN(27, 3)))),
               "apm_chain": (lambda: w3.APM(w3.APM(w3.Order1(), 0, 7), 1, 6), lambda: oracle.APM(oracle.APM(oracle.Order1(), 0, 7), oracle.APM_ORDER1, 6))}
     mk = lambda nm: models[nm] if nm in models else pair(oracle, nm)
-    assert ctx.max_in_flight(len(datas[0]), bs) == 4 and ctx.max_in_flight(10**9, 65536) == 2 and ctx.max_in_flight(8192 * 65536, 65536) == 4
+    assert ctx.max_in_flight(len(datas[0]), bs) == 4 and ctx.max_in_flight(10**9, 65536) == 2 and ctx.max_in_flight(4096 * 65536, 65536) == 4 and ctx.max_in_flight(12288 * 65536, 65536) == 3 and ctx.max_in_flight(12289 * 65536, 65536) == 2
     d_ins = [torch.from_numpy(np.frombuffer(d, dtype=np.uint8).copy()).cuda() for d in datas]
     bufs = _device_bufs(max(len(d) for d in datas), bs, 4)
     torch.cuda.synchronize()

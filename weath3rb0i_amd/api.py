@@ -213,7 +213,7 @@ class Context:
         return job.value
 
     def max_in_flight(self, n, block_size):
-        """w3_encode_max_in_flight: submitted calls of this size one context keeps in flight (4 up to 8,192 blocks, else 2)."""
+        """w3_encode_max_in_flight: submitted calls of this size one context keeps in flight (4 up to 4,096 blocks, 3 up to 12,288, else 2)."""
         return int(self.lib.w3_encode_max_in_flight(int(n), int(block_size)))
 
     def encode_wait(self, job):

@@ -54,11 +54,14 @@ struct JobState {
     hipStream_t sc = nullptr;      // the stream this job's code stage runs on (free-running jobs: one each; ordered jobs share s_code[0])
 };
 
-// Jobs in flight: W3_MAX_JOBS when the input is small enough that a call's coder leaves most of the chip idle (at most
-// W3_FREE_RUN_BLOCKS blocks = 128 coder workgroups: the code stages then run each on its own stream and overlap one another),
-// two otherwise (the ordered pipeline of DESIGN.md section 2.8; its workspaces are 70 bytes per input byte each).
+// Jobs in flight: free-running — every code stage on its own stream, the calls' coders overlapping one another — while a call's
+// coder leaves a good part of the chip idle: four up to W3_FREE_RUN4_BLOCKS blocks (64 coder workgroups), three up to
+// W3_FREE_RUN_BLOCKS (measured: 7,629 blocks 36.6 ms per step with three, 39.1 with four, 43.8 with the ordered pair; 11,444 blocks
+// 53.6 against 56.0 ordered; at 15,259 the two forms meet at 68-70 ms); beyond that the ordered pair of DESIGN.md section 2.8
+// (a job workspace is ~70 bytes per input byte).
 #define W3_MAX_JOBS 4
-#define W3_FREE_RUN_BLOCKS 8192u
+#define W3_FREE_RUN_BLOCKS 12288u
+#define W3_FREE_RUN4_BLOCKS 4096u
 
 struct w3_ctx {
     int device = 0;
@@ -835,8 +838,8 @@ extern "C" int w3_encode_submit(w3_ctx *ctx, const w3_model_spec *spec, const ui
     if ((rc = parse_spec(spec, ps))) { ctx->err = "malformed model spec"; return rc; }
     const uint32_t nb = (uint32_t)((n + block_size - 1) / block_size);
     // small inputs: free-running jobs, up to W3_MAX_JOBS of them, every code stage on its own stream; large ones: the ordered pair
-    const bool free_run = nb <= W3_FREE_RUN_BLOCKS && !(ctx->tp.tune & 4096u);   // (W3_OPT_TUNE bit 12: the ordered pair whatever the size)
-    const int depth = free_run ? W3_MAX_JOBS : 2;
+    const bool free_run = (nb <= W3_FREE_RUN_BLOCKS || (ctx->tp.tune & 8192u)) && !(ctx->tp.tune & 4096u);   // (W3_OPT_TUNE bit 12: the ordered pair whatever the size; 13: free-running jobs whatever the size)
+    const int depth = free_run ? (nb <= W3_FREE_RUN4_BLOCKS ? W3_MAX_JOBS : 3) : 2;
     int in_flight = 0;
     for (const auto &o : ctx->js) in_flight += o.state != 0;
     int j = ctx->next_job % depth;
@@ -940,7 +943,8 @@ extern "C" int w3_encode_submit(w3_ctx *ctx, const w3_model_spec *spec, const ui
 
 extern "C" int w3_encode_max_in_flight(size_t n, size_t block_size) {
     if (!block_size) return 0;
-    return (n + block_size - 1) / block_size <= W3_FREE_RUN_BLOCKS ? W3_MAX_JOBS : 2;
+    const size_t nb = (n + block_size - 1) / block_size;
+    return nb <= W3_FREE_RUN4_BLOCKS ? W3_MAX_JOBS : nb <= W3_FREE_RUN_BLOCKS ? 3 : 2;
 }
 
 extern "C" int w3_encode_wait(w3_ctx *ctx, int job) {
