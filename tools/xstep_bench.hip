@@ -4,6 +4,8 @@
 //   V0  the shipped step: state (x1, x2, d), 15 VALU, operands (p32, bitmask) 8 B/step
 //   V1  state (x1 raw, d): 13 VALU, same operands; the top-bit fix-ups of x1 are left to the consumer of the tokens
 //   V2  state (x1 raw, d): 11 VALU with two v_mad_u64_u32, operands (q, b01, z, z) 16 B/step
+//   V3  the step k_coder_x4 ships (round 2): operands (z, z, q), one ds_read_b96 per step
+//   V4  the same step, the operands of FOUR steps in three ds_read_b128 (z0 z0 z1 z1 | z2 z2 z3 z3 | q0 q1 q2 q3): 0.75 LDS reads per step
 // plus issue-rate probes of a lone wave (dependent / K independent chains, VOP2 / VOP3, LDS instructions in between).
 // Build: hipcc --offload-arch=gfx950 -O3 -o tools/xstep_bench tools/xstep_bench.hip ; run on the GPU box.
 #include <hip/hip_runtime.h>
@@ -136,6 +138,50 @@ PROBE(p_dep4_salu, , asm volatile("v_add_u32 %0, %0, %1\n v_add_u32 %0, %0, %1\n
     V2S(B, 4, "v[100:101]", "v100", "v101") V2S(B, 5, "v[104:105]", "v104", "v105") WR2(K, 4)  \
     V2S(B, 6, "v[100:101]", "v100", "v101") V2S(B, 7, "v[104:105]", "v104", "v105") WR2(K, 6)
 
+// ---- V3 / V4: the shipped step (w3_coder4.h W3_X4_STEP): dn = hi32(d*q + (z:z)); x1n = x1 + (dn - d)*z
+#define V3_STEP(Q, Z, ZP, TKP, TK0, TK1)                                             \
+    "v_mad_u64_u32 v[96:97], vcc, %2, " Q ", " ZP "\n"                               \
+    "v_sub_u32 v98, v97, %2\n"                                                       \
+    "v_mad_u64_u32 " TKP ", vcc, v98, " Z ", v[110:111]\n"                           \
+    "v_add_u32 v98, " TK0 ", v97\n"                                                  \
+    "v_bfi_b32 v99, " TK0 ", v98, -1\n"                                              \
+    "v_lshl_or_b32 v99, v99, 1, 1\n"                                                 \
+    "v_bitop3_b32 v99, v99, " TK0 ", v98 bitop3:0x60\n"                              \
+    "v_ffbh_u32 " TK1 ", v99\n"                                                      \
+    "v_lshlrev_b32 v110, " TK1 ", " TK0 "\n"                                         \
+    "v_add_u32 v97, 1, v97\n"                                                        \
+    "v_lshl_add_u32 %2, v97, " TK1 ", -1\n"
+#define RD8_3(B, K)                                                                                         \
+    "ds_read_b96 v[" S(B) "+0:" S(B) "+2], %3 offset:" S(K) "*8192+0\n"                                      \
+    "ds_read_b96 v[" S(B) "+4:" S(B) "+6], %3 offset:" S(K) "*8192+1024\n"                                   \
+    "ds_read_b96 v[" S(B) "+8:" S(B) "+10], %3 offset:" S(K) "*8192+2048\n"                                  \
+    "ds_read_b96 v[" S(B) "+12:" S(B) "+14], %3 offset:" S(K) "*8192+3072\n"                                 \
+    "ds_read_b96 v[" S(B) "+16:" S(B) "+18], %3 offset:" S(K) "*8192+4096\n"                                 \
+    "ds_read_b96 v[" S(B) "+20:" S(B) "+22], %3 offset:" S(K) "*8192+5120\n"                                 \
+    "ds_read_b96 v[" S(B) "+24:" S(B) "+26], %3 offset:" S(K) "*8192+6144\n"                                 \
+    "ds_read_b96 v[" S(B) "+28:" S(B) "+30], %3 offset:" S(K) "*8192+7168\n"
+#define V3S(B, E, TKP, TK0, TK1) V3_STEP("v[" S(B) "+4*" S(E) "+2]", "v[" S(B) "+4*" S(E) "]", "v[" S(B) "+4*" S(E) ":" S(B) "+4*" S(E) "+1]", TKP, TK0, TK1)
+#define BYTE_3(B, K)                                                                  \
+    V3S(B, 0, "v[100:101]", "v100", "v101") V3S(B, 1, "v[104:105]", "v104", "v105") WR2(K, 0)  \
+    V3S(B, 2, "v[100:101]", "v100", "v101") V3S(B, 3, "v[104:105]", "v104", "v105") WR2(K, 2)  \
+    V3S(B, 4, "v[100:101]", "v100", "v101") V3S(B, 5, "v[104:105]", "v104", "v105") WR2(K, 4)  \
+    V3S(B, 6, "v[100:101]", "v100", "v101") V3S(B, 7, "v[104:105]", "v104", "v105") WR2(K, 6)
+// V4: group G (steps 4G .. 4G+3) of byte K in v[B+12G .. B+12G+11] = (z z z z | z z z z | q q q q) by three b128 reads (planes of 1 KiB)
+#define RD8_5(B, K)                                                                                         \
+    "ds_read_b128 v[" S(B) "+0:" S(B) "+3], %3 offset:" S(K) "*8192+0\n"                                     \
+    "ds_read_b128 v[" S(B) "+4:" S(B) "+7], %3 offset:" S(K) "*8192+1024\n"                                  \
+    "ds_read_b128 v[" S(B) "+8:" S(B) "+11], %3 offset:" S(K) "*8192+2048\n"                                 \
+    "ds_read_b128 v[" S(B) "+12:" S(B) "+15], %3 offset:" S(K) "*8192+3072\n"                                \
+    "ds_read_b128 v[" S(B) "+16:" S(B) "+19], %3 offset:" S(K) "*8192+4096\n"                                \
+    "ds_read_b128 v[" S(B) "+20:" S(B) "+23], %3 offset:" S(K) "*8192+5120\n"
+#define V4S(B, G, E, TKP, TK0, TK1) V3_STEP("v[" S(B) "+12*" S(G) "+8+" S(E) "]", "v[" S(B) "+12*" S(G) "+2*" S(E) "]", \
+                                            "v[" S(B) "+12*" S(G) "+2*" S(E) ":" S(B) "+12*" S(G) "+2*" S(E) "+1]", TKP, TK0, TK1)
+#define BYTE_5(B, K)                                                                  \
+    V4S(B, 0, 0, "v[100:101]", "v100", "v101") V4S(B, 0, 1, "v[104:105]", "v104", "v105") WR2(K, 0)  \
+    V4S(B, 0, 2, "v[100:101]", "v100", "v101") V4S(B, 0, 3, "v[104:105]", "v104", "v105") WR2(K, 2)  \
+    V4S(B, 1, 0, "v[100:101]", "v100", "v101") V4S(B, 1, 1, "v[104:105]", "v104", "v105") WR2(K, 4)  \
+    V4S(B, 1, 2, "v[100:101]", "v100", "v101") V4S(B, 1, 3, "v[104:105]", "v104", "v105") WR2(K, 6)
+
 #define CLOB16 "v64","v65","v66","v67","v68","v69","v70","v71","v72","v73","v74","v75","v76","v77","v78","v79", \
                "v80","v81","v82","v83","v84","v85","v86","v87","v88","v89","v90","v91","v92","v93","v94","v95"
 #define CLOBT "v96","v97","v98","v99","v100","v101","v102","v103","v104","v105","v110","v111","vcc","memory"
@@ -156,6 +202,21 @@ PROBE(p_dep4_salu, , asm volatile("v_add_u32 %0, %0, %1\n v_add_u32 %0, %0, %1\n
     RD8_4(32, 2) "s_waitcnt lgkmcnt(8)\n" BYTE_4(64, 1)                                 \
     RD8_4(64, 3) "s_waitcnt lgkmcnt(8)\n" BYTE_4(32, 2)                                 \
     "s_waitcnt lgkmcnt(0)\n" BYTE_4(64, 3)                                              \
+    "v_mov_b32 %0, v110\n"
+
+#define CHUNK4_3                                                                       \
+    "v_mov_b32 v110, %0\n"                                                             \
+    RD8_3(32, 0) RD8_3(64, 1) "s_waitcnt lgkmcnt(8)\n" BYTE_3(32, 0)                    \
+    RD8_3(32, 2) "s_waitcnt lgkmcnt(8)\n" BYTE_3(64, 1)                                 \
+    RD8_3(64, 3) "s_waitcnt lgkmcnt(8)\n" BYTE_3(32, 2)                                 \
+    "s_waitcnt lgkmcnt(0)\n" BYTE_3(64, 3)                                              \
+    "v_mov_b32 %0, v110\n"
+#define CHUNK4_5                                                                       \
+    "v_mov_b32 v110, %0\n"                                                             \
+    RD8_5(32, 0) RD8_5(64, 1) "s_waitcnt lgkmcnt(6)\n" BYTE_5(32, 0)                    \
+    RD8_5(32, 2) "s_waitcnt lgkmcnt(6)\n" BYTE_5(64, 1)                                 \
+    RD8_5(64, 3) "s_waitcnt lgkmcnt(6)\n" BYTE_5(32, 2)                                 \
+    "s_waitcnt lgkmcnt(0)\n" BYTE_5(64, 3)                                              \
     "v_mov_b32 %0, v110\n"
 
 #define RING 8u   // ring depth in input bytes
@@ -187,7 +248,7 @@ template <int V, bool CHECK>
 __global__ void __launch_bounds__(64) k_xstep(Res *res, Stamp *st, uint32_t nbytes, int prio) {
     extern __shared__ uint8_t lds_raw[];
     // V0/V1: ops [RING][8][64] x 8 B = 32 KiB, tokens [RING][8][64] x 8 B = 32 KiB;  V2: ops x 16 B = 64 KiB
-    constexpr uint32_t OPB = V == 2 ? 16u : 8u;
+    constexpr uint32_t OPB = V >= 2 ? 16u : 8u;
     uint8_t *opq = lds_raw;
     uint8_t *tok = lds_raw + RING * 8u * 64u * OPB;
     const uint32_t lane = threadIdx.x;
@@ -195,7 +256,17 @@ __global__ void __launch_bounds__(64) k_xstep(Res *res, Stamp *st, uint32_t nbyt
         for (uint32_t j = 0; j < 8; j++) {
             uint32_t p32, mask; gen_op(lane + blockIdx.x * 64u, rb, j, p32, mask);
             uint8_t *o = opq + ((rb * 8u + j) * 64u + lane) * OPB;
-            if (V == 2) {
+            if (V == 3 || V == 4) {
+                const uint32_t z = ~mask, q = (p32 ^ z) + (z & 1u);   // bit ? p32 : 2^32 - p32
+                uint32_t *ob = (uint32_t *)(opq + (rb * 8u * 64u) * OPB);   // this ring byte's 8 KiB: [step or plane][lane] x 16 B
+                if (V == 3) { uint32_t *o3 = ob + (j * 64u + lane) * 4u; o3[0] = z; o3[1] = z; o3[2] = q; o3[3] = 0u; }
+                else {
+                    const uint32_t g = j >> 2, e = j & 3u;
+                    ob[((3u * g + (e >> 1)) * 64u + lane) * 4u + 2u * (e & 1u)] = z;
+                    ob[((3u * g + (e >> 1)) * 64u + lane) * 4u + 2u * (e & 1u) + 1u] = z;
+                    ob[((3u * g + 2u) * 64u + lane) * 4u + e] = q;
+                }
+            } else if (V == 2) {
                 const uint32_t z = ~mask;
                 ((uint32_t *)o)[0] = (p32 ^ z) + (z & 1u);   // bit ? p32 : 2^32 - p32
                 ((uint32_t *)o)[1] = z & 1u;
@@ -218,6 +289,8 @@ __global__ void __launch_bounds__(64) k_xstep(Res *res, Stamp *st, uint32_t nbyt
         if (V == 0) asm volatile(CHUNK4_2(V0_STEP) : "+v"(x1), "+v"(x2), "+v"(d) : "v"(opa), "v"(tka) : CLOB16, CLOBT);
         if (V == 1) asm volatile(CHUNK4_2(V1_STEP) : "+v"(x1), "+v"(x2), "+v"(d) : "v"(opa), "v"(tka) : CLOB16, CLOBT);
         if (V == 2) asm volatile(CHUNK4_4 : "+v"(x1), "+v"(x2), "+v"(d) : "v"(opa), "v"(tka) : CLOB64, CLOB16, CLOBT);
+        if (V == 3) asm volatile(CHUNK4_3 : "+v"(x1), "+v"(x2), "+v"(d) : "v"(opa), "v"(tka) : CLOB64, CLOB16, CLOBT);
+        if (V == 4) asm volatile(CHUNK4_5 : "+v"(x1), "+v"(x2), "+v"(d) : "v"(opa), "v"(tka) : CLOB64, CLOB16, CLOBT);
         if (CHECK) {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             for (uint32_t k = 0; k < 4; k++)
@@ -240,7 +313,7 @@ __global__ void __launch_bounds__(64) k_xstep(Res *res, Stamp *st, uint32_t nbyt
 
 template <int V>
 static void run_variant(const char *name, Res *d_res, Stamp *d_st, int wgs, uint32_t nbytes, int prio) {
-    const size_t lds = (size_t)RING * 8 * 64 * (V == 2 ? 16 : 8) + (size_t)RING * 8 * 64 * 8;
+    const size_t lds = (size_t)RING * 8 * 64 * (V >= 2 ? 16 : 8) + (size_t)RING * 8 * 64 * 8;
     CK(hipFuncSetAttribute((const void *)k_xstep<V, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     CK(hipFuncSetAttribute((const void *)k_xstep<V, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     // correctness against the C reference step
@@ -286,6 +359,8 @@ int main() {
             run_variant<0>("V0 shipped 15 VALU (x1,x2,d)", res, st, wgs, nbytes, prio);
             run_variant<1>("V1 13 VALU (x1 raw, d)", res, st, wgs, nbytes, prio);
             run_variant<2>("V2 11 VALU, 2 x mad_u64_u32", res, st, wgs, nbytes, prio);
+            run_variant<3>("V3 shipped x4 step, b96 per step", res, st, wgs, nbytes, prio);
+            run_variant<4>("V4 x4 step, 3 x b128 per 4 steps", res, st, wgs, nbytes, prio);
         }
     }
     return 0;
