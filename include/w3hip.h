@@ -135,7 +135,8 @@ enum {
                            scratch, 8 = CM decoder without LDS staging, 16 = no side stream, 64 = synchronous calls use the half-CU
                            kernel shapes of the submit / wait pipeline, 128 = submitted calls use the plain shapes, 256 = slot-state
                            leaves always on k_slot (lane per block, hash map in HBM), 512 = always on the sorted replay (wavefront per
-                           block, no table; default: the replay below 7,000 blocks, k_slot from there on).  0 = defaults.
+                           block, no table; default: the replay below 7,000 blocks, k_slot from there on), 1024 = decode on the
+                           lane-per-block kernels only (default: sixteen lanes per block where k_decode_spec applies).  0 = defaults.
                            32 = FAULT INJECTION (test hook of the sampled verification): one LDS-add round of every block returns two
                            lanes each other's value; refused (W3_E_INVALID) unless W3_OPT_VERIFY is on, so it cannot corrupt output */
     W3_OPT_SLOT_BUDGET_MB = 8, /* cap (MiB) on the device memory one batch of slot-state hash maps may take; 0 = derive from free memory */

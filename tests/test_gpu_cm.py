@@ -92,6 +92,11 @@ def check(ctx, oracle, name, data, bs, decode=True):
         assert lens2.tolist() == wlens.tolist() and out2.tobytes() == want.tobytes(), name + " (k_cm)"
     if decode:
         assert ctx.decode_blocks(dev(), out, lens, bs, len(data)).tobytes() == bytes(data), name
+        ctx.set_variant("decode_lane")   # the lane-per-block decoder (k_cm_nl), where the default is k_decode_spec (sixteen lanes per block)
+        try:
+            assert ctx.decode_blocks(dev(), out, lens, bs, len(data)).tobytes() == bytes(data), name + " (lane-per-block decoder)"
+        finally:
+            ctx.set_variant()
     return out, lens
 
 

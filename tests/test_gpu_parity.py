@@ -111,6 +111,19 @@ def check_blocks(ctx, oracle, name, data, bs, path):
     return out, lens
 
 
+def decode_both(ctx, model, out, lens, bs, n):
+    """Decode with the default kernels (k_decode_spec: sixteen lanes per block, where it applies) and with the lane-per-block kernels
+    (W3_OPT_VARIANT decode_lane); both must agree."""
+    a = ctx.decode_blocks(model, out, lens, bs, n).tobytes()
+    ctx.set_variant("decode_lane")
+    try:
+        b = ctx.decode_blocks(model, out, lens, bs, n).tobytes()
+    finally:
+        ctx.set_variant()
+    assert a == b, "k_decode_spec and the lane-per-block decoder disagree"
+    return np.frombuffer(a, dtype=np.uint8)
+
+
 ALL = ["order0", "order1", "order2", "ordern_12_0", "ordern_14_4", "ordern_9_1", "ordern_8_3", "ordern_22_2", "ordern_30_3",
        "raw_16_3", "main_default", "ac_19_3_enwik7", "ac_10_2_mb0", "frozen0", "best01", "best012", "best_right",
        "huff_11_text", "huff_19_text", "huff_24_text", "huff_11_skew", "huff_mix_text"]
@@ -136,7 +149,7 @@ def test_generic_path_all_models(ctx, oracle, name):
     data = markov_text(40000, seed=11) + lcg_text(9000, seed=2)
     out, lens = check_blocks(ctx, oracle, name, data, 4096, "generic")
     dev, orc = pair(oracle, name)
-    back = ctx.decode_blocks(dev(), out, lens, 4096, len(data))
+    back = decode_both(ctx, dev(), out, lens, 4096, len(data))
     assert back.tobytes() == data
 
 
@@ -495,7 +508,7 @@ def test_wave_per_block_predict_kernel(ctx, oracle, name):
     out, lens = check_blocks(ctx, oracle, name, data, 16384, "twophase")
     assert ctx.timing()["path"] == 2
     dev, orc = pair(oracle, name)
-    back = ctx.decode_blocks(dev(), out, lens, 16384, len(data))
+    back = decode_both(ctx, dev(), out, lens, 16384, len(data))
     assert back.tobytes() == data
     p = ctx.predict_blocks(dev(), data[:40000], 16384)
     want = np.concatenate([oracle.predict_all(orc(), data[o:min(o + 16384, 40000)]) for o in range(0, 40000, 16384)])
@@ -606,7 +619,7 @@ def test_edge_blocks(ctx, oracle, path):
         for name in ("order0", "best012"):
             out, lens = check_blocks(ctx, oracle, name, data, b, path)
             dev, _ = pair(oracle, name)
-            assert ctx.decode_blocks(dev(), out, lens, b, len(data)).tobytes() == data, (cname, name)
+            assert decode_both(ctx, dev(), out, lens, b, len(data)).tobytes() == data, (cname, name)
     out, lens = ctx.encode_blocks(w3.Order0(), b"", 4096)
     assert len(out) == 0 and len(lens) == 0
     assert len(ctx.decode_blocks(w3.Order0(), b"", [], 4096, 0)) == 0
@@ -731,4 +744,4 @@ def test_large_blocks_twophase(ctx, oracle, bs):
     out, lens = ctx.encode_blocks(dev(), data, bs)
     want, wlens = oracle.encode_blocks(orc(), data, bs, nthreads=8)
     assert lens.tolist() == wlens.tolist() and out.tobytes() == want.tobytes()
-    assert ctx.decode_blocks(dev(), out, lens, bs, len(data)).tobytes() == data
+    assert decode_both(ctx, dev(), out, lens, bs, len(data)).tobytes() == data

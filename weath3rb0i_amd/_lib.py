@@ -16,7 +16,7 @@ W3_OK, W3_E_INVALID, W3_E_NOSPACE, W3_E_HIP, W3_E_UNSUPPORTED, W3_E_NOMEM, W3_E_
 W3_OPT_PATH, W3_OPT_TIMING, W3_OPT_CODER, W3_OPT_ACC_LIMIT, W3_OPT_DEBUG_STAMPS, W3_OPT_VARIANT, W3_OPT_SLOT_BUDGET_MB, W3_OPT_VERIFY, W3_OPT_FAULT_BLOCK, W3_OPT_TUNE = 1, 2, 3, 4, 5, 7, 8, 9, 10, 11
 W3_VAR_NO_LDS_ATOMICS, W3_VAR_PARTITION4, W3_VAR_NO_CHAINED_PARTITION, W3_VAR_CM_UNSTAGED, W3_VAR_NO_SIDE_STREAM, W3_VAR_INJECT_LDS_FAULT = 1, 2, 4, 8, 16, 32
 W3_VAR_HALF_CU, W3_VAR_FULL_CU = 64, 128
-W3_VAR_SLOT_TABLE, W3_VAR_SLOT_SORTED = 256, 512
+W3_VAR_SLOT_TABLE, W3_VAR_SLOT_SORTED, W3_VAR_DECODE_LANE = 256, 512, 1024
 W3_GATHER_AUTO, W3_GATHER_RCCL, W3_GATHER_PEER_COPY = 0, 1, 2
 W3_PATH_AUTO, W3_PATH_GENERIC, W3_PATH_TWOPHASE = 0, 1, 2
 

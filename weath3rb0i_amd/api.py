@@ -53,10 +53,10 @@ class Context:
         """Cross-check hook (W3_OPT_VARIANT): alternative bit-exact implementations, by name: no_lds_atomics, partition4,
         no_chained_partition, cm_unstaged, no_side_stream, half_cu (synchronous calls in the pipeline's kernel shapes), full_cu
         (submitted calls in the plain shapes), slot_table / slot_sorted (slot-state leaves on k_slot / on the sorted replay whatever
-        the block count).  No names = defaults."""
+        the block count), decode_lane (decode on the lane-per-block kernels, not k_decode_spec).  No names = defaults."""
         bits = {"no_lds_atomics": L.W3_VAR_NO_LDS_ATOMICS, "partition4": L.W3_VAR_PARTITION4, "no_chained_partition": L.W3_VAR_NO_CHAINED_PARTITION,
                 "cm_unstaged": L.W3_VAR_CM_UNSTAGED, "no_side_stream": L.W3_VAR_NO_SIDE_STREAM, "inject_lds_fault": L.W3_VAR_INJECT_LDS_FAULT,
-                "half_cu": L.W3_VAR_HALF_CU, "full_cu": L.W3_VAR_FULL_CU, "slot_table": L.W3_VAR_SLOT_TABLE, "slot_sorted": L.W3_VAR_SLOT_SORTED}
+                "half_cu": L.W3_VAR_HALF_CU, "full_cu": L.W3_VAR_FULL_CU, "slot_table": L.W3_VAR_SLOT_TABLE, "slot_sorted": L.W3_VAR_SLOT_SORTED, "decode_lane": L.W3_VAR_DECODE_LANE}
         v = 0
         for nm in names:
             v |= bits[nm]

@@ -1,0 +1,209 @@
+// w3_decode_spec.h — the DECODER of Counter-leaf models (+ APM chain) with the nibble's whole context tree evaluated at once.
+//
+// Decoding is serial: the context of bit t+1 contains bit t (main.rs:131-140).  k_generic_nl / k_cm_nl run that loop literally, one lane
+// per block: per BIT a round trip for the leaves' Counters and a dependent one for every APM stage, 239 wavefronts on 256 CUs at enwik9
+// size — 7.6 us per bit-step, 250 MiB/s, latency from end to end.  But the contexts a NIBBLE can reach are known when it starts: bit k of
+// the nibble has 2^k candidate contexts (the k bits decoded before it), 15 in all, and — with alignment_bits >= 2 (t mod 4 is part of every
+// context) and APM rows keyed by the partial byte — no two of them share a Counter or an APM entry.  So a block is decoded by SIXTEEN lanes:
+//   lane r < 15 = node (k, x) of the nibble's tree (k = floor(log2(r + 1)), x = r + 1 - 2^k): it forms the node's context of every leaf
+//   (OrderN::update / OrderNEntropy::update in closed form, leaf_ctx of w3_generic.h, on the history  hist << k | x), looks the Counters up
+//   (models/counter.rs), mixes (OpinionMixer2) and runs the APM chain — all 15 nodes side by side, ONE round trip per table level per
+//   nibble instead of four;
+//   then the four bits are decoded one after the other (arithmetic_coder.rs:74-106; the decoder state is replicated in the 16 lanes), each
+//   step taking the probability of the node the bits so far select (ds_bpermute inside the 16-lane row);
+//   the four nodes on the decoded path update their Counters (Counter::update) and APM entries; an exact-map slot is claimed by
+//   compare-and-swap (two path nodes may meet one empty slot).
+// A wavefront holds four blocks: 3,815 wavefronts at enwik9 size instead of 239, and the chip hides the round trips it still has.
+// Model tables: the lane-per-block decoder's layout (layout_generic / layout_cm), one region per block.
+// Covered: 1..4 Counter-table leaves of any history kind with alignment_bits >= 2 (FrozenModel leaves too), 0..2 APM stages.  Everything
+// else (alignment 0 / 1: the nibble's own updates feed its later contexts; slot-state leaves; longer chains) stays on the lane-per-block
+// kernels, which also remain the cross-check (W3_OPT_VARIANT bit 1024).
+#pragma once
+#include "w3_cm.h"
+
+namespace w3 {
+
+__device__ __forceinline__ uint32_t ds_ld32(const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ uint64_t ds_ld64(const uint64_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ uint32_t ds_ld16(const uint16_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void ds_st32(uint32_t *p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void ds_st16(uint16_t *p, uint16_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// Direct-indexed Counter tables and APM tables are only ever touched by plain loads and stores of ONE wavefront (no compare-and-swap at
+// the L2): they may live in the CU's L1, which that wavefront's own stores go through.  (The exact maps keep the L2-level accesses above:
+// their keys are claimed with atomics, which the L1 does not see.)
+__device__ __forceinline__ uint32_t pl_ld32(const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ void pl_st32(uint32_t *p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ void pl_st16(uint16_t *p, uint16_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+
+template <int NL, int NA>
+__global__ void __launch_bounds__(64) k_decode_spec(CmArgs a) {
+    __shared__ int16_t s_str[NA > 0 ? 4096 : 1];
+    if (NA > 0) for (uint32_t i = threadIdx.x; i < 4096u; i += 64u) s_str[i] = a.stretch[i];
+    __shared__ LeafParam s_leaf[W3_MAX_LEAVES];
+    __shared__ ApmParam s_apm[W3_MAX_APM];
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int k = 0; k < W3_MAX_APM; k++) s_apm[k] = a.apm[k];
+    }
+    stage_leaves(s_leaf, a.g);   // (also the barrier for the tables above)
+    const GenericArgs &g = a.g;
+    const LeafParam *lp = s_leaf;
+    const uint32_t lane = threadIdx.x & 63u, r = lane & 15u, grp = lane >> 4;
+    const uint32_t bl = blockIdx.x * 4u + grp;               // block of this 16-lane row inside the batch
+    const bool live = bl < g.n_lanes;
+    const uint32_t blc = live ? bl : g.n_lanes - 1u;
+    const uint32_t b = g.first_block + blc;
+    const uint64_t off = (uint64_t)b * g.block_size;
+    uint32_t len = (uint32_t)((g.n - off) < g.block_size ? (g.n - off) : g.block_size);
+    if (!live) len = 0u;
+    uint8_t *blk_tbl = g.tables + (uint64_t)blc * g.lane_stride;
+    // this lane's node of the nibble tree
+    const uint32_t rr = r < 15u ? r : 14u;                   // (lane 15 shadows lane 14 and never updates anything)
+    const uint32_t k = 31u - (uint32_t)__builtin_clz(rr + 1u), x = rr + 1u - (1u << k);
+    const bool node = r < 15u;
+    const uint32_t row0 = lane & 48u;
+    bool fence_each = false;
+#pragma unroll
+    for (int l = 0; l < NL; l++) fence_each |= !lp[l].frozen && lp[l].align < 3;
+    Decoder dec;
+    dec.init(g.cin + g.coffs[b], live ? g.clens[b] : 0u);
+
+    uint64_t hist64 = 0; uint32_t t = 0, c0 = 1u, c1 = 0u;
+    HuffState hs;
+    for (uint32_t i = 0; i < len; i++) {
+        for (int half = 0; half < 2; half++) {
+            // ---- the node's prediction: contexts, Counters, mix, APM chain ----
+            const uint64_t hist_n = (hist64 << k) | x;
+            const uint32_t t_n = t + k;
+            uint32_t *slot[NL]; uint32_t val[NL], ctx[NL];
+            uint32_t p = 32768u, best = 0u;
+#pragma unroll
+            for (int l = 0; l < NL; l++) {
+                slot[l] = nullptr; val[l] = 0u; ctx[l] = 0u;
+                if (!lp[l].frozen) {
+                    ctx[l] = leaf_ctx(lp[l], hist_n, t_n, hs, g.huff);
+                    uint32_t *tbl = reinterpret_cast<uint32_t *>(blk_tbl + lp[l].tbl_off);
+                    if (!lp[l].use_hash) { slot[l] = tbl + ctx[l]; val[l] = pl_ld32(slot[l]); }
+                    else {
+                        // exact map {ctx + 1, counts}: found, or absent (the empty slot ends the probe; only a path node claims one, below)
+                        uint32_t h = (ctx[l] * 2654435761u) ^ (ctx[l] >> 15);
+                        for (;;) {
+                            h &= lp[l].hash_mask;
+                            const uint64_t kv = ds_ld64(reinterpret_cast<const uint64_t *>(tbl + 2u * h));
+                            const uint32_t key = (uint32_t)kv;
+                            if (key == ctx[l] + 1u) { slot[l] = tbl + 2u * h + 1u; val[l] = (uint32_t)(kv >> 32); break; }
+                            if (key == 0u) break;
+                            h++;
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int l = 0; l < NL; l++) {
+                const uint32_t pl = lp[l].frozen ? 32768u : counter_p_packed(val[l]);
+                const uint32_t d = opinion_dist(pl);
+                if (l == 0 || d > best) { p = pl; best = d; }
+            }
+            const uint32_t c0_n = (c0 << k) | x;
+            uint16_t *aslot[NA > 0 ? NA : 1]; int tv[NA > 0 ? NA : 1];
+#pragma unroll
+            for (int s = 0; s < NA; s++) {   // APM chain (build-defined), as k_cm_nl
+                const uint32_t row = s_apm[s].ctx_kind ? (c0_n | (c1 << 8)) : c0_n;
+                const uint32_t pos = (uint32_t)((int)s_str[p >> 4] + 2048) * 32u;
+                const uint32_t j = pos >> 12, w = pos & 4095u;
+                uint16_t *tr = reinterpret_cast<uint16_t *>(blk_tbl + s_apm[s].off) + row * 33u + j;
+                uint32_t pairv;   // the two adjacent entries in one (possibly unaligned) 4-byte load
+                __builtin_memcpy(&pairv, tr, 4);
+                const uint32_t v0 = pairv & 0xFFFFu, v1 = pairv >> 16;
+                const uint32_t pa = (v0 * (4096u - w) + v1 * w) >> 12;
+                aslot[s] = tr + (w >> 11);
+                tv[s] = (int)((w >> 11) ? v1 : v0);
+                const uint32_t o = (p + 3u * pa + 2u) >> 2;
+                p = o < 1u ? 1u : o > 65535u ? 65535u : o;
+            }
+            // ---- the nibble's four bits, one after the other ----
+            uint32_t xk = 0u, mybit = 0u;
+            bool on = false;
+#pragma unroll
+            for (uint32_t kk = 0; kk < 4u; kk++) {
+                const uint32_t src = row0 | ((1u << kk) - 1u + xk);
+                const uint32_t psel = (uint32_t)__shfl((int)p, (int)src, 64);
+                const uint32_t bit = dec.decode(psel);
+                if (node && k == kk && x == xk) { on = true; mybit = bit; }
+                xk = (xk << 1) | bit;
+            }
+            // ---- the path's nodes adapt (Counter::update, counter.rs:20-26; the APM entry nearer to the looked-up position) ----
+            if (on) {
+#pragma unroll
+                for (int l = 0; l < NL; l++) {
+                    if (lp[l].frozen) continue;
+                    const uint32_t nv = counter_update_packed(val[l], mybit);
+                    if (slot[l]) { if (lp[l].use_hash) ds_st32(slot[l], nv); else pl_st32(slot[l], nv); }
+                    else {   // claim a slot of the exact map: another path node of this nibble may be after the same empty one
+                        uint32_t *tbl = reinterpret_cast<uint32_t *>(blk_tbl + lp[l].tbl_off);
+                        uint32_t h = (ctx[l] * 2654435761u) ^ (ctx[l] >> 15);
+                        for (;;) {
+                            h &= lp[l].hash_mask;
+                            uint32_t key = ds_ld32(tbl + 2u * h);
+                            if (key == 0u) {
+                                uint32_t expect = 0u;
+                                __hip_atomic_compare_exchange_strong(tbl + 2u * h, &expect, ctx[l] + 1u, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                key = expect == 0u ? ctx[l] + 1u : expect;
+                            }
+                            if (key == ctx[l] + 1u) { ds_st32(tbl + 2u * h + 1u, nv); break; }
+                            h++;
+                        }
+                    }
+                }
+#pragma unroll
+                for (int s = 0; s < NA; s++)
+                    pl_st16(aslot[s], (uint16_t)(tv[s] + (((mybit ? 65535 : 0) - tv[s]) >> s_apm[s].rate)));   // arithmetic shift = floor
+            }
+            // With alignment_bits >= 3 the two nibbles of a byte have disjoint contexts (t mod 8 is part of them) and disjoint APM rows
+            // (1..15 / 16..255): what this nibble stored can only be read two nibbles on — after the next nibble's loads have been waited
+            // for, and gfx9's one counter for loads and stores then covers these stores too.  Only alignment 2 has to wait here.
+            if (fence_each) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                __builtin_amdgcn_s_waitcnt(0);
+            }
+            hist64 = (hist64 << 4) | xk;
+            t += 4u;
+            c0 = (c0 << 4) | xk;
+        }
+        const uint32_t byte = c0 & 0xFFu;
+        c1 = byte; c0 = 1u;
+        if (g.n_huff) hs.push_byte(g.huff, g.n_huff, byte);
+        if (r == 0u) g.dout[off + i] = (uint8_t)byte;
+    }
+}
+
+// what k_decode_spec covers (see the header comment)
+static inline bool decode_spec_covers(const CmArgs &ca) {
+    if (ca.g.n_leaves < 1 || ca.g.n_leaves > 4 || ca.n_apm > 2) return false;
+    for (int l = 0; l < ca.g.n_leaves; l++) {
+        const LeafParam &lp = ca.g.leaf[l];
+        if (lp.kind != 0) return false;
+        if (!lp.frozen && lp.align < 2) return false;
+    }
+    return true;
+}
+
+template <int NL>
+static inline void launch_decode_spec_na(const CmArgs &ca, uint32_t cnt, hipStream_t s) {
+    const dim3 grid((cnt + 3u) / 4u), blk(64);
+    switch (ca.n_apm) {
+    case 0: hipLaunchKernelGGL((k_decode_spec<NL, 0>), grid, blk, 0, s, ca); break;
+    case 1: hipLaunchKernelGGL((k_decode_spec<NL, 1>), grid, blk, 0, s, ca); break;
+    default: hipLaunchKernelGGL((k_decode_spec<NL, 2>), grid, blk, 0, s, ca); break;
+    }
+}
+static inline void launch_decode_spec(const CmArgs &ca, uint32_t cnt, hipStream_t s) {
+    switch (ca.g.n_leaves) {
+    case 1: launch_decode_spec_na<1>(ca, cnt, s); break;
+    case 2: launch_decode_spec_na<2>(ca, cnt, s); break;
+    case 3: launch_decode_spec_na<3>(ca, cnt, s); break;
+    default: launch_decode_spec_na<4>(ca, cnt, s); break;
+    }
+}
+
+}  // namespace w3

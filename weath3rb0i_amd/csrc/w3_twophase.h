@@ -39,7 +39,8 @@ enum { W3_VAR_NO_LDS_ATOMICS = 1, W3_VAR_PARTITION4 = 2, W3_VAR_NO_CHAINED_PARTI
        W3_VAR_HALF_CU = 64    /* synchronous calls too run the half-CU kernel shapes of the submit / wait pipeline (w3_predict.h) */,
        W3_VAR_FULL_CU = 128   /* w3_encode_submit keeps the plain kernel shapes (experiments: what the shapes are worth) */,
        W3_VAR_SLOT_TABLE = 256  /* slot-state leaves always on k_slot (hash map in HBM, lane per block) */,
-       W3_VAR_SLOT_SORTED = 512 /* slot-state leaves always on the sorted replay of w3_slot2.h (default: by block count) */ };
+       W3_VAR_SLOT_SORTED = 512 /* slot-state leaves always on the sorted replay of w3_slot2.h (default: by block count) */,
+       W3_VAR_DECODE_LANE = 1024 /* decode with the lane-per-block kernels only (k_generic_nl / k_cm_nl), not k_decode_spec */ };
 
 #define W3_SLOT_SORTED_MAX_BLOCKS 7000u   // below: slot-state leaves by sorted replay (w3_slot2.h), from here on k_slot
 

@@ -17,6 +17,7 @@
 #include "w3_huff.h"
 #include "w3_generic.h"
 #include "w3_cm.h"
+#include "w3_decode_spec.h"
 #include "w3_pack.h"
 #include "w3_twophase.h"
 #include "w3_selftest.h"
@@ -200,7 +201,7 @@ extern "C" int w3_ctx_set_option(w3_ctx *ctx, int opt, int64_t value) {
         ctx->tp.acc_limit = (uint32_t)value;
         return W3_OK;
     case W3_OPT_VARIANT:
-        if (value < 0 || value > 1023) return W3_E_INVALID;
+        if (value < 0 || value > 2047) return W3_E_INVALID;
         // the fault-injection hook exists for the test of the sampled verification: without the verification it would only corrupt output
         if ((value & W3_VAR_INJECT_LDS_FAULT) && !ctx->tp.verify) { ctx->err = "W3_OPT_VARIANT bit 32 (fault injection) needs W3_OPT_VERIFY on"; return W3_E_INVALID; }
         ctx->tp.variant = (uint32_t)value;
@@ -366,7 +367,10 @@ static int run_pack(w3_ctx *ctx, JobRef &J, hipStream_t s, const uint8_t *stripe
 static int table_budget(w3_ctx *ctx, uint64_t lane_stride, uint32_t want_lanes, uint32_t &lanes_out) {
     size_t free_b = 0, total_b = 0;
     HIPCHK(ctx, hipMemGetInfo(&free_b, &total_b));
-    uint64_t budget = std::min<uint64_t>((uint64_t)(free_b + ctx->tables.cap) / 2, 96ull << 30);
+    // (Every block of a call resident at once matters to the decoders: they are latency chains per block, so two batches take twice as
+    // long as one.  The default model's tables are 10 MiB per block = 153 GB at enwik9 size.)
+    const uint64_t avail_b = (uint64_t)free_b + ctx->tables.cap;
+    uint64_t budget = std::min<uint64_t>(avail_b > (12ull << 30) ? avail_b - (12ull << 30) : avail_b / 2, 224ull << 30);
     uint64_t lanes = budget / lane_stride;
     if (lanes >= want_lanes) lanes = want_lanes;
     else lanes = lanes / 64 * 64;
@@ -454,6 +458,16 @@ static int generic_decode(w3_ctx *ctx, hipStream_t s, const ParsedSpec &ps, cons
         uint32_t cnt = std::min(lanes, nb - first);
         ga.first_block = first; ga.n_lanes = cnt;
         HIPCHK(ctx, hipMemsetAsync(ctx->tables.p, 0, (size_t)cnt * lane_stride, s));
+        {   // the nibble's context tree at once, sixteen lanes per block (w3_decode_spec.h), where it applies
+            CmArgs ca;
+            memset(&ca, 0, sizeof ca);
+            ca.g = ga;
+            if (decode_spec_covers(ca) && !(ctx->tp.variant & W3_VAR_DECODE_LANE)) {
+                launch_decode_spec(ca, cnt, s);
+                HIPCHK(ctx, hipGetLastError());
+                continue;
+            }
+        }
         switch (ga.n_leaves) {
         case 1: hipLaunchKernelGGL((k_generic_nl<true, 1>), dim3((cnt + 63) / 64), dim3(64), 0, s, ga); break;
         case 2: hipLaunchKernelGGL((k_generic_nl<true, 2>), dim3((cnt + 63) / 64), dim3(64), 0, s, ga); break;
@@ -527,7 +541,8 @@ static int cm_run(w3_ctx *ctx, hipStream_t s, CmArgs &ca, uint64_t lane_stride, 
         bool has_slot = false;
         for (int l = 0; l < ca.g.n_leaves; l++) has_slot |= ca.g.leaf[l].kind == 1;
         const dim3 grid((cnt + 63) / 64), blk(64);
-        if (!has_slot && ca.g.n_leaves <= 4) {   // Counter leaves + APM chain: all Counter loads of a step in flight together
+        if (DECODE && decode_spec_covers(ca) && !(ctx->tp.variant & W3_VAR_DECODE_LANE)) launch_decode_spec(ca, cnt, s);   // (w3_decode_spec.h)
+        else if (!has_slot && ca.g.n_leaves <= 4) {   // Counter leaves + APM chain: all Counter loads of a step in flight together
             switch (ca.g.n_leaves) {
             case 1: hipLaunchKernelGGL((k_cm_nl<DECODE, 1>), grid, blk, 0, s, ca); break;
             case 2: hipLaunchKernelGGL((k_cm_nl<DECODE, 2>), grid, blk, 0, s, ca); break;
