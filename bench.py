@@ -308,7 +308,7 @@ class Regime:
         """`steps` encodes of this shard (+ exchange), at most `pipeline` in flight; acc: dict that sums w3_timing fields"""
         from weath3rb0i_amd import shard
         pending = []
-        pipeline = min(pipeline, max(ctx.max_in_flight(self.n, self.bs), self.env.get("force_depth", 0))) if pipeline > 1 else pipeline
+        pipeline = min(pipeline, max(ctx.max_in_flight(self.n, self.bs, model), self.env.get("force_depth", 0))) if pipeline > 1 else pipeline
         for i in range(steps):
             k = i % self.nsets
             if self.reqs[k]:
@@ -429,7 +429,7 @@ def short_run(w3, model_name, data_kind, size, bs, seed, steps, env):
     ctx = w3.Context(env["local_rank"])
     try:
         model, mname = make_model(w3, model_name)
-        pipeline = 1 if model_name == "fullcm" else ctx.max_in_flight(rg.n, bs)   # (slot-state leaves run synchronously inside submit anyway)
+        pipeline = ctx.max_in_flight(rg.n, bs, model)   # (2 for the full CM: pipelined below 7,000 blocks — the sorted replay —, synchronous inside submit beyond)
         dt, acc = rg.timed(ctx, model, steps, 1, pipeline)
         rows = kernel_table(model_name, rg.n, bs, steps, acc, "x4" if pipeline == 1 else "x5")
         dom = max(rows, key=lambda r: r[1])
@@ -493,10 +493,10 @@ def main():
             rg.release()
         rg = Regime(env, rd, args.size, args.data, bs, args.seed)
         # encodes in flight for THIS reading's shard (a strong-scaled shard may be small enough for four free-running jobs)
-        pipeline = args.pipeline if args.pipeline else ctx.max_in_flight(rg.n, bs)
+        pipeline = args.pipeline if args.pipeline else ctx.max_in_flight(rg.n, bs, model)
         if args.tune & 8192:
             env["force_depth"] = 3   # (experiment: free-running jobs beyond 12,288 blocks)
-        pipeline = min(pipeline, max(ctx.max_in_flight(rg.n, bs), env.get("force_depth", 0))) if pipeline > 1 else pipeline
+        pipeline = min(pipeline, max(ctx.max_in_flight(rg.n, bs, model), env.get("force_depth", 0))) if pipeline > 1 else pipeline
         dt, acc = rg.timed(ctx, model, args.steps, args.warmup, pipeline)
         results[rd] = {"dt": dt, "acc": acc, "n": rg.n, "n_global": rg.n_global, "nb": rg.nb, "pipeline": pipeline,
                        "ratio": int(rg.d_totals[rg.last_buf].item()) / max(rg.n, 1),

@@ -198,14 +198,15 @@ int w3_decode_blocks_device(w3_ctx *ctx, const w3_model_spec *spec,
  *   w3_encode_submit  arguments as w3_encode_blocks_device (d_total is required); *job receives a handle (0 .. 3).  The
  *                     input must stay valid and the outputs untouched until the job has been waited for.  `stream`: the
  *                     stream d_in was produced on (the job starts after the work enqueued there so far).  W3_E_INVALID when
- *                     w3_encode_max_in_flight(n, block_size) jobs are in flight already.  Specs the predict kernels do not
- *                     cover, and specs with slot-state leaves, run synchronously inside the call (still completed by
- *                     w3_encode_wait).
+ *                     w3_encode_max_in_flight(spec, n, block_size) jobs are in flight already.  Specs the predict kernels do not
+ *                     cover, and specs whose slot-state leaves walk hash maps in HBM (7,000 blocks and more), run synchronously
+ *                     inside the call (still completed by w3_encode_wait).
  *   w3_encode_max_in_flight  how many submitted calls of this size one context keeps in flight: 4 up to 4,096 blocks, 3 up to
  *                     12,288 — there a call's coder is a latency chain on part of an otherwise idle chip (one 64 KiB block:
  *                     17 ms), so the jobs run free, every code stage on a stream of its own, and the calls' coders overlap
  *                     (enwik8 size: 3,893 -> 9,339 MiB/s) — and 2 beyond (the ordered pair of DESIGN.md 2.8:
- *                     step k's coder beside step k+1's rank kernels; a job workspace is ~70 bytes per input byte).
+ *                     step k's coder beside step k+1's rank kernels; a job workspace is ~70 bytes per input byte).  Specs with
+ *                     slot-state leaves: 2 (their event records are 32 bytes per input byte and leaf).
  *   w3_encode_wait    blocks until the job is complete; returns what w3_encode_blocks_device would have returned
  *                     (W3_E_NOSPACE included; d_total holds the need).  Jobs may be waited for in any order.
  * Every other entry point returns W3_E_INVALID while a job is in flight.  Output is byte-identical to the synchronous
@@ -215,7 +216,7 @@ int w3_encode_submit(w3_ctx *ctx, const w3_model_spec *spec,
                      uint8_t *d_out, size_t out_cap,
                      uint32_t *d_block_lens, uint64_t *d_total, void *stream, int *job);
 int w3_encode_wait(w3_ctx *ctx, int job);
-int w3_encode_max_in_flight(size_t n, size_t block_size);
+int w3_encode_max_in_flight(const w3_model_spec *spec /* NULL: a Counter-leaf model */, size_t n, size_t block_size);
 
 /* ---- sharding over several GPUs from ONE process (C, C++ or Rust hosts) ---------------------------
  * Blocks are independent (fresh model + coder each), so they shard with no data-path collective: context r codes the

@@ -243,7 +243,8 @@ def test_apm_models_submit_wait_pipeline(ctx, oracle):
     bufs = [(torch.empty(2 * n + 64 * nb + 64, dtype=torch.uint8, device="cuda"), torch.zeros(nb, dtype=torch.int32, device="cuda"),
              torch.zeros(1, dtype=torch.int64, device="cuda")) for _ in range(2)]
     torch.cuda.synchronize()
-    for name in ("o012_apm", "apm_chain4", "slot2"):
+    assert ctx.max_in_flight(n, bs, w3.full_cm()) == 2 and ctx.max_in_flight(n, bs) == 4
+    for name in ("o012_apm", "apm_chain4", "slot2", "full_cm_small_tables", "slot_mix"):   # (slot leaves: pipelined too at this block count — sorted replay)
         dev, orc = pair(oracle, name)
         want, wlens = oracle.encode_blocks(orc(), data, bs, nthreads=8)
         jobs = [ctx.encode_submit(dev(), d_in, bs, *bufs[k]) for k in range(2)]

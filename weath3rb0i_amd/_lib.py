@@ -89,7 +89,7 @@ def load():
     lib.w3_decode_blocks_device.argtypes = [vp, C.POINTER(ModelSpec), vp, sz, vp, sz, sz, C.c_uint64, vp, vp]
     lib.w3_encode_submit.argtypes = [vp, C.POINTER(ModelSpec), vp, sz, sz, vp, sz, vp, vp, vp, C.POINTER(C.c_int)]
     lib.w3_encode_wait.argtypes = [vp, C.c_int]
-    lib.w3_encode_max_in_flight.argtypes = [sz, sz]
+    lib.w3_encode_max_in_flight.argtypes = [C.POINTER(ModelSpec), sz, sz]
     lib.w3_encode_max_in_flight.restype = C.c_int
     lib.w3_compress_stream.argtypes = [vp, C.POINTER(ModelSpec), vp, sz, vp, sz, C.POINTER(sz)]
     lib.w3_decompress_stream.argtypes = [vp, C.POINTER(ModelSpec), vp, sz, vp, sz, C.POINTER(sz)]

@@ -212,9 +212,11 @@ class Context:
         self._chk(rc)
         return job.value
 
-    def max_in_flight(self, n, block_size):
-        """w3_encode_max_in_flight: submitted calls of this size one context keeps in flight (4 up to 4,096 blocks, 3 up to 12,288, else 2)."""
-        return int(self.lib.w3_encode_max_in_flight(int(n), int(block_size)))
+    def max_in_flight(self, n, block_size, model=None):
+        """w3_encode_max_in_flight: submitted calls of this size one context keeps in flight (4 up to 4,096 blocks, 3 up to 12,288, else 2;
+        models with slot-state leaves: 2)."""
+        spec = None if model is None else (model.spec() if isinstance(model, Model) else model)
+        return int(self.lib.w3_encode_max_in_flight(C.byref(spec) if spec is not None else None, int(n), int(block_size)))
 
     def encode_wait(self, job):
         """w3_encode_wait: block until the job's output is complete (raises what the synchronous call would have raised)."""

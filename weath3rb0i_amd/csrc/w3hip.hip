@@ -794,6 +794,14 @@ extern "C" int w3_encode_blocks_device(w3_ctx *ctx, const w3_model_spec *spec, c
 // pack stages on another, so in steady state the chip always holds one call's predict kernels and the previous call's APM
 // or coder kernel — in the half-CU shapes (w3_predict.h, w3_coder5.h) that let the two share every CU.
 // ---------------------------------------------------------------------------
+// twophase_predict_b's choice for the slot-state leaves, as far as the spec and the shape decide it (w3_twophase.h)
+static bool slot_sorted_by_default(const ParsedSpec &ps, uint32_t nb, size_t block_size) {
+    if (nb >= W3_SLOT_SORTED_MAX_BLOCKS || block_size > (1ull << 31)) return false;
+    for (int l = 0; l < ps.n_leaves; l++)
+        if (ps.leaf[l].kind == W3_NODE_SLOT_STATE && ps.leaf[l].log_cells > 16) return false;
+    return true;
+}
+
 static int ensure_pipeline(w3_ctx *ctx) {
     // The two stages must not share a hardware queue (HIP maps streams onto GPU_MAX_HW_QUEUES = 4 queues per priority level by
     // default, round-robin: two streams of one level can land on the same queue and then run one after the other).  Streams of
@@ -852,9 +860,12 @@ extern "C" int w3_encode_submit(w3_ctx *ctx, const w3_model_spec *spec, const ui
     ParsedSpec ps;
     if ((rc = parse_spec(spec, ps))) { ctx->err = "malformed model spec"; return rc; }
     const uint32_t nb = (uint32_t)((n + block_size - 1) / block_size);
+    // Specs with slot-state leaves are pipelined when the leaves run as the sorted replay (w3_slot2.h: no hash maps sized from the memory
+    // that happens to be free) — two jobs at most: a job's event records are 32 bytes per input byte and leaf.
+    const bool slot_async = ps.has_slot && slot_sorted_by_default(ps, nb, block_size) && !(ctx->tp.variant & (W3_VAR_SLOT_TABLE | W3_VAR_NO_LDS_ATOMICS)) && ctx->tp.lds_order != 0;
     // small inputs: free-running jobs, up to W3_MAX_JOBS of them, every code stage on its own stream; large ones: the ordered pair
     const bool free_run = (nb <= W3_FREE_RUN_BLOCKS || (ctx->tp.tune & 8192u)) && !(ctx->tp.tune & 4096u);   // (W3_OPT_TUNE bit 12: the ordered pair whatever the size; 13: free-running jobs whatever the size)
-    const int depth = free_run ? (nb <= W3_FREE_RUN4_BLOCKS ? W3_MAX_JOBS : 3) : 2;
+    const int depth = ps.has_slot ? 2 : free_run ? (nb <= W3_FREE_RUN4_BLOCKS ? W3_MAX_JOBS : 3) : 2;
     int in_flight = 0;
     for (const auto &o : ctx->js) in_flight += o.state != 0;
     int j = ctx->next_job % depth;
@@ -868,9 +879,9 @@ extern "C" int w3_encode_submit(w3_ctx *ctx, const w3_model_spec *spec, const ui
     }
     HIPCHK(ctx, hipSetDevice(ctx->device));
     const bool two = nb > 0 && twophase_supported(ps, block_size, n) && ctx->opt_path != W3_PATH_GENERIC;
-    if (!two || ps.has_slot) {
-        // Not pipelined: the lane-per-block kernels (any spec the predict kernels do not cover) and specs with slot-state leaves
-        // (their hash maps are sized from the memory that is free at the time) run to completion here, on job 0's workspace.
+    if (!two || (ps.has_slot && !slot_async)) {
+        // Not pipelined: the lane-per-block kernels (any spec the predict kernels do not cover) and specs whose slot-state leaves walk
+        // hash maps in HBM (k_slot: sized from the memory that is free at the time) run to completion here, on job 0's workspace.
         for (int k = 0; k < W3_MAX_JOBS; k++) {   // let the other jobs' kernels finish first; their status is in pinned memory already
             if (ctx->js[k].state != 1) continue;
             if (ctx->js[k].code_pending) { JobRef O = jobref(ctx, k); if ((rc = enqueue_code(ctx, O, nullptr, nullptr))) return rc; }
@@ -890,7 +901,7 @@ extern "C" int w3_encode_submit(w3_ctx *ctx, const w3_model_spec *spec, const ui
     if (ps.n_huff) { memcpy(st.huff_copy, ps.huff, sizeof(w3_huff_table) * ps.n_huff); st.spec.huff = st.huff_copy; ps.huff = st.huff_copy; }
     st.ps = ps;
     st.d_in = d_in; st.n = n; st.block_size = block_size; st.d_out = d_out; st.out_cap = out_cap; st.d_block_lens = d_block_lens; st.d_total = d_total;
-    st.has_apm = ps.n_apm > 0; st.has_slot = false; st.timed = ctx->opt_timing != 0;
+    st.has_apm = ps.n_apm > 0; st.has_slot = ps.has_slot; st.timed = ctx->opt_timing != 0;
     st.nb = nb;
     st.sc = free_run ? ctx->s_code[j] : ctx->s_code[0];
     memset(&st.tm, 0, sizeof st.tm);
@@ -956,9 +967,14 @@ extern "C" int w3_encode_submit(w3_ctx *ctx, const w3_model_spec *spec, const ui
     return W3_OK;
 }
 
-extern "C" int w3_encode_max_in_flight(size_t n, size_t block_size) {
+extern "C" int w3_encode_max_in_flight(const w3_model_spec *spec, size_t n, size_t block_size) {
     if (!block_size) return 0;
     const size_t nb = (n + block_size - 1) / block_size;
+    if (spec) {
+        ParsedSpec ps;
+        if (parse_spec(spec, ps)) return 0;
+        if (ps.has_slot) return 2;
+    }
     return nb <= W3_FREE_RUN4_BLOCKS ? W3_MAX_JOBS : nb <= W3_FREE_RUN_BLOCKS ? 3 : 2;
 }
 
