@@ -422,11 +422,13 @@ def lookup_traffic(model, n, bs, kernel_name):
     return None, None
 
 
-def short_run(w3, model_name, data_kind, size, bs, seed, steps, env):
-    """3-step line of another BASELINE configuration (fresh context; after the main run has released its memory)."""
+def short_run(w3, model_name, data_kind, size, bs, seed, steps, env, ctx=None):
+    """short line of another BASELINE configuration (a fresh context after the main run has released its memory, or the main run's own)"""
     import torch
     rg = Regime(env, "weak", size, data_kind, bs, seed)
-    ctx = w3.Context(env["local_rank"])
+    own_ctx = ctx is None
+    if own_ctx:
+        ctx = w3.Context(env["local_rank"])
     try:
         model, mname = make_model(w3, model_name)
         pipeline = ctx.max_in_flight(rg.n, bs, model)   # (2 for the full CM: pipelined below 7,000 blocks — the sorted replay —, synchronous inside submit beyond)
@@ -439,7 +441,8 @@ def short_run(w3, model_name, data_kind, size, bs, seed, steps, env):
                "dominant_kernel": dom[0], "dominant_ms": round(dom[1], 3), "dominant_frac_of_hbm_peak": round(dom[2] / (dom[1] * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
                "kernel_ms_per_step": {k: round(acc.get(k, 0.0) / steps, 3) for k in ("predict_ms", "slot_ms", "apm_ms", "coder_ms", "pack_ms")}}
     finally:
-        ctx.close()
+        if own_ctx:
+            ctx.close()
         rg.release()
         torch.cuda.empty_cache()
     return res
@@ -534,6 +537,23 @@ def main():
                          "kernel_ms_per_step": {k: round(a2.get(k, 0.0) / 3, 3) for k in ("predict_ms", "apm_ms", "coder_ms", "pack_ms")},
                          "compressed_ratio": round(int(rg.d_totals[rg.last_buf].item()) / n, 4),
                          "note": "every node of this model is the reference's (Order0/Order1/OrderN + OpinionMixer2): its block streams are the reference's streams"}
+    small_lines = None
+    if extras and not args.no_other_configs and args.model == "order012apm" and args.data == "text" and args.size >= 100_000_000:
+        # Small inputs of the bench model (w3_encode_max_in_flight = 4 free-running jobs): configs[1] at its literal enwik8 size, and ONE
+        # RANK'S SHARE of the stream at 8 GPUs — the strong reading's per-GPU work, measured here on one GPU; 8 x its rate (minus the
+        # exchange, which overlaps the next step) is what an 8-GPU strong-scaled run can reach.  On the main run's context (its job
+        # workspaces are large enough already), outside the timed region.
+        small_lines = []
+        for label, size in (("configs[1] at enwik8 size", 100_000_000), ("one rank's share of the stream at 8 GPUs (strong reading)", args.size // 8 // bs * bs)):
+            try:
+                r = short_run(w3, args.model, "text", size, bs, args.seed, 12, env, ctx=ctx)
+                r["what"] = label
+                if "share" in label:
+                    r["projected_8gpu_strong_MiBps"] = round(8 * r["value"], 1)
+                    r["note"] = "projection = 8 x this rate: the ranks code disjoint block ranges with no data-path collective; the gather of ~0.38 x bytes to rank 0 overlaps the next step"
+                small_lines.append(r)
+            except Exception as e:
+                small_lines.append({"what": label, "error": str(e)[:300]})
     # release the encoder's workspaces (two jobs' worth) before the decoder and the other configurations need the memory
     ctx.close()
     host = rg.host
@@ -658,21 +678,8 @@ def main():
             except Exception as e:   # an extra must not lose the main line
                 oc.append({"context_model": mname, "data": kind, "error": str(e)[:300]})
         res["other_configs"] = oc
-        # Small inputs of the bench model (w3_encode_max_in_flight = 4 free-running jobs): configs[1] at its literal enwik8 size, and ONE
-        # RANK'S SHARE of the stream at 8 GPUs — the strong reading's per-GPU work, measured here on one GPU; 8 x its rate (minus the
-        # exchange, which overlaps the next step) is what an 8-GPU strong-scaled run can reach
-        sm = []
-        for label, size in (("configs[1] at enwik8 size", 100_000_000), ("one rank's share of the stream at 8 GPUs (strong reading)", args.size // 8 // bs * bs)):
-            try:
-                r = short_run(w3, args.model, "text", size, bs, args.seed, 12, env)
-                r["what"] = label
-                if "share" in label:
-                    r["projected_8gpu_strong_MiBps"] = round(8 * r["value"], 1)
-                    r["note"] = "projection = 8 x this rate: the ranks code disjoint block ranges with no data-path collective; the gather of ~0.38 x bytes to rank 0 overlaps the next step"
-                sm.append(r)
-            except Exception as e:
-                sm.append({"what": label, "error": str(e)[:300]})
-        res["small_inputs"] = sm
+        if small_lines is not None:
+            res["small_inputs"] = small_lines
 
     if rank == 0:
         if extras and not args.no_cpu_baseline:

@@ -108,11 +108,12 @@ struct TwoPhaseWs {
     void *vin = nullptr; size_t vin_cap = 0;   // the sampled blocks, gathered
     bool used_lds_atomics = false;              // the last predict ran LDS-add rounds in some kernel
     hipStream_t vstream = nullptr; hipEvent_t ev_v0 = nullptr, ev_v1 = nullptr;   // the re-prediction runs beside the APM and coder kernels
+    bool ext_streams = false;   // side / vstream belong to the context (w3hip.hip hands them from context to context): not destroyed here
     void release() {
         if (vws) { vws->release(); delete vws; vws = nullptr; }
         if (vin) (void)hipFree(vin);
         vin = nullptr; vin_cap = 0;
-        if (vstream) (void)hipStreamDestroy(vstream);
+        if (vstream && !ext_streams) (void)hipStreamDestroy(vstream);
         if (ev_v0) (void)hipEventDestroy(ev_v0);
         if (ev_v1) (void)hipEventDestroy(ev_v1);
         vstream = nullptr; ev_v0 = ev_v1 = nullptr;
@@ -126,7 +127,7 @@ struct TwoPhaseWs {
             if (splits_w[w]) (void)hipFree(splits_w[w]);
             rec_w[w] = perm_w[w] = splits_w[w] = nullptr; rec_w_cap[w] = perm_w_cap[w] = splits_w_cap[w] = 0;
         }
-        if (side) (void)hipStreamDestroy(side);
+        if (side && !ext_streams) (void)hipStreamDestroy(side);
         if (ev_fork) (void)hipEventDestroy(ev_fork);
         for (int w = 0; w < 4; w++) { if (ev_join[w]) (void)hipEventDestroy(ev_join[w]); ev_join[w] = nullptr; }
         if (ev_small) (void)hipEventDestroy(ev_small);
@@ -296,8 +297,8 @@ static inline int twophase_predict_a(TwoPhaseWs &ws, hipStream_t s, const Parsed
             if ((rc = tp_ensure(ws.rec_w[w], ws.rec_w_cap[w], n * 8, err))) return rc;
             if ((rc = tp_ensure(ws.splits_w[w], ws.splits_w_cap[w], (size_t)nb * (W3_SLICES + 1) * 4 + 64, err))) return rc;
         }
-        if (!ws.side) {
-            bool ok = hipStreamCreateWithFlags(&ws.side, hipStreamNonBlocking) == hipSuccess && hipEventCreateWithFlags(&ws.ev_fork, hipEventDisableTiming) == hipSuccess;
+        if (!ws.side || !ws.ev_fork) {
+            bool ok = (ws.side || hipStreamCreateWithFlags(&ws.side, hipStreamNonBlocking) == hipSuccess) && hipEventCreateWithFlags(&ws.ev_fork, hipEventDisableTiming) == hipSuccess;
             for (int w = 0; w < 4 && ok; w++) ok = hipEventCreateWithFlags(&ws.ev_join[w], hipEventDisableTiming) == hipSuccess;
             ok = ok && hipEventCreateWithFlags(&ws.ev_small, hipEventDisableTiming) == hipSuccess;
             if (!ok) { (void)hipGetLastError(); err = "side stream creation failed"; return W3_E_HIP; }
@@ -696,7 +697,8 @@ static inline int twophase_verify(TwoPhaseWs &ws, hipStream_t s, const ParsedSpe
     }
     if (!ws.vws) ws.vws = new TwoPhaseWs();
     TwoPhaseWs &v = *ws.vws;
-    v.variant = (ws.variant | W3_VAR_NO_LDS_ATOMICS | W3_VAR_PARTITION4) & ~(uint32_t)W3_VAR_INJECT_LDS_FAULT;
+    // (no side stream of its own: the sample is small, and every stream a context creates is one more claim on the hardware queues)
+    v.variant = (ws.variant | W3_VAR_NO_LDS_ATOMICS | W3_VAR_PARTITION4 | W3_VAR_NO_SIDE_STREAM) & ~(uint32_t)W3_VAR_INJECT_LDS_FAULT;
     v.lds_order = 0; v.verify = 0;
     v.stretch = ws.stretch; v.squash = ws.squash; v.st = ws.st; v.huff = ws.huff; v.slot_budget_mb = ws.slot_budget_mb;
     // only the leaves whose kernels use the property are re-predicted (not the slot-state leaves, not k_predict_wave's)
@@ -845,10 +847,10 @@ static inline int tp_code_stage(TwoPhaseWs &ws, hipStream_t s_pred, hipStream_t 
     bool verify_forked = false;
     const bool verify_on = ws.verify && ws.used_lds_atomics;
     const bool verify_in_place = verify_on && n_live == 1 && ps.n_apm > 0;
-    if (verify_on && !verify_in_place && !ws.vstream) {
+    if (verify_on && !verify_in_place && (!ws.vstream || !ws.ev_v0)) {
         // (lowest priority level: its own hardware queues, apart from the launch streams'; and the re-prediction is in nobody's way)
         int lo_p = 0, hi_p = 0;
-        bool ok = hipDeviceGetStreamPriorityRange(&lo_p, &hi_p) == hipSuccess && hipStreamCreateWithPriority(&ws.vstream, hipStreamNonBlocking, lo_p) == hipSuccess &&
+        bool ok = hipDeviceGetStreamPriorityRange(&lo_p, &hi_p) == hipSuccess && (ws.vstream || hipStreamCreateWithPriority(&ws.vstream, hipStreamNonBlocking, lo_p) == hipSuccess) &&
                   hipEventCreateWithFlags(&ws.ev_v0, hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&ws.ev_v1, hipEventDisableTiming) == hipSuccess;
         if (!ok) { (void)hipGetLastError(); err = "verification stream creation failed"; return W3_E_HIP; }
     }

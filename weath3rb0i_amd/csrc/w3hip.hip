@@ -80,6 +80,8 @@ struct w3_ctx {
     JobState js[W3_MAX_JOBS];
     hipStream_t s_pred = nullptr, s_code[W3_MAX_JOBS] = {};   // created by the first w3_encode_submit
     int next_job = 0, last_job = -1;
+    bool pooled_streams = false;
+    hipStream_t s_side = nullptr, s_verify[W3_MAX_JOBS] = {};   // the workspaces' side stream (one: predict phases never overlap) and re-prediction streams
 };
 
 // the members of job j under one name
@@ -152,6 +154,22 @@ extern "C" int w3_ctx_create(int device, w3_ctx **out) {
     return W3_OK;
 }
 
+// The pipeline's streams are kept for the life of the process and handed from context to context (per device and priority): HIP deals
+// hardware queues out when a stream is CREATED, by the queues' reference counts at that moment, and a context created after others
+// had come and gone got code streams that shared queues (bench.py's later lines ran at the two-in-flight rate with four in flight).
+struct StreamPool {
+    std::mutex mu;
+    std::vector<std::pair<long, hipStream_t>> idle;   // key = device * 4 + class (0 = predict, 1 = code, 2 = side, 3 = verification)
+    hipStream_t take(long key) {
+        std::lock_guard<std::mutex> g(mu);
+        for (size_t i = 0; i < idle.size(); i++)
+            if (idle[i].first == key) { hipStream_t s = idle[i].second; idle.erase(idle.begin() + (long)i); return s; }
+        return nullptr;
+    }
+    void give(long key, hipStream_t s) { std::lock_guard<std::mutex> g(mu); idle.emplace_back(key, s); }
+};
+static StreamPool &stream_pool() { static StreamPool *p = new StreamPool; return *p; }   // (never destroyed: streams outlive static teardown order)
+
 extern "C" void w3_ctx_destroy(w3_ctx *ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
@@ -175,8 +193,15 @@ extern "C" void w3_ctx_destroy(w3_ctx *ctx) {
         if (st.ev_apm) (void)hipEventDestroy(st.ev_apm);
         if (st.h_status) (void)hipHostFree(st.h_status);
     }
-    if (ctx->s_pred) (void)hipStreamDestroy(ctx->s_pred);
-    for (auto &sc : ctx->s_code) if (sc) (void)hipStreamDestroy(sc);
+    if (ctx->s_side) stream_pool().give(ctx->device * 4L + 2, ctx->s_side);
+    for (auto &sv : ctx->s_verify) if (sv) stream_pool().give(ctx->device * 4L + 3, sv);
+    if (ctx->pooled_streams) {   // (idle by now: the device was synchronised above)
+        if (ctx->s_pred) stream_pool().give(ctx->device * 4L, ctx->s_pred);
+        for (auto &sc : ctx->s_code) if (sc) stream_pool().give(ctx->device * 4L + 1, sc);
+    } else {
+        if (ctx->s_pred) (void)hipStreamDestroy(ctx->s_pred);
+        for (auto &sc : ctx->s_code) if (sc) (void)hipStreamDestroy(sc);
+    }
     for (auto &e : ctx->ev)
         if (e) (void)hipEventDestroy(e);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -651,6 +676,25 @@ static void sync_job_options(w3_ctx *ctx, JobRef &J) {
     if (ctx->tp.lds_order >= 0) J.tp.lds_order = ctx->tp.lds_order;   // (job 0 has run the self-test)
 }
 
+// The side stream of the predict phase and the job's re-prediction stream: the context's (taken from the process-wide pool), so that
+// a context does not create streams — and with them hardware-queue assignments — of its own for every workspace.
+static int attach_aux_streams(w3_ctx *ctx, JobRef &J, int j) {
+    if (!ctx->s_side) {
+        ctx->s_side = stream_pool().take(ctx->device * 4L + 2);
+        if (!ctx->s_side) HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->s_side, hipStreamNonBlocking));
+    }
+    if (!ctx->s_verify[j]) {
+        ctx->s_verify[j] = stream_pool().take(ctx->device * 4L + 3);
+        if (!ctx->s_verify[j]) {
+            int lo_p = 0, hi_p = 0;
+            HIPCHK(ctx, hipDeviceGetStreamPriorityRange(&lo_p, &hi_p));
+            HIPCHK(ctx, hipStreamCreateWithPriority(&ctx->s_verify[j], hipStreamNonBlocking, lo_p));
+        }
+    }
+    J.tp.side = ctx->s_side; J.tp.vstream = ctx->s_verify[j]; J.tp.ext_streams = true;
+    return W3_OK;
+}
+
 // d_out == nullptr: counting-sink mode (ACStats, helpers.rs:60-90) — the streams are coded into the stripes as usual, the
 // pack is skipped and only J.bits (per-block bit counts) is of interest; d_block_lens may then be a scratch buffer.
 // Synchronous: returns when the output is complete.  J = the job whose workspace is used (job 0 for every synchronous entry point;
@@ -687,6 +731,7 @@ static int encode_core(w3_ctx *ctx, JobRef J, const w3_model_spec *spec, const u
     if (ctx->opt_path == W3_PATH_TWOPHASE && !two) { ctx->err = "spec/block size not covered by the two-phase path"; return W3_E_UNSUPPORTED; }
     if (!two && &J.tp != &ctx->tp) { ctx->err = "internal: the lane-per-block path runs on job 0"; return W3_E_INVALID; }
     sync_job_options(ctx, J);
+    if ((rc = attach_aux_streams(ctx, J, &J.tp == &ctx->tp ? 0 : (int)(&J.st - ctx->js)))) return rc;
     J.tp.half_cu = (ctx->tp.variant & W3_VAR_HALF_CU) != 0;
 
     hipEvent_t *evp = ctx->opt_timing ? J.ev : nullptr;
@@ -810,11 +855,16 @@ static int ensure_pipeline(w3_ctx *ctx) {
         int lo_p = 0, hi_p = 0;
         HIPCHK(ctx, hipDeviceGetStreamPriorityRange(&lo_p, &hi_p));
         const bool pred_high = (ctx->tp.tune & 1u) != 0;   // W3_OPT_TUNE bit 0
+        const bool plain = !(ctx->tp.tune & (1u | 16u));   // (tuning variants create their own)
+        if (!ctx->s_pred && plain) ctx->s_pred = stream_pool().take(ctx->device * 4L);
         if (!ctx->s_pred) HIPCHK(ctx, hipStreamCreateWithPriority(&ctx->s_pred, hipStreamNonBlocking, pred_high ? hi_p : 0));
         // (created one after the other on one level: HIP deals that level's hardware queues out round-robin, so the W3_MAX_JOBS = 4 code
         // streams get a queue each and the free-running jobs' coders really run side by side)
-        for (auto &sc : ctx->s_code)
+        for (auto &sc : ctx->s_code) {
+            if (!sc && plain) sc = stream_pool().take(ctx->device * 4L + 1);
             if (!sc) HIPCHK(ctx, hipStreamCreateWithPriority(&sc, hipStreamNonBlocking, (pred_high || (ctx->tp.tune & 16u)) ? 0 : hi_p));
+        }
+        ctx->pooled_streams = plain;
     }
     for (int j = 0; j < W3_MAX_JOBS; j++) {
         JobState &st = ctx->js[j];
@@ -919,6 +969,7 @@ extern "C" int w3_encode_submit(w3_ctx *ctx, const w3_model_spec *spec, const ui
         ctx->tp.stretch = lut.stretch; ctx->tp.squash = lut.squash; ctx->tp.st = lut.st;
     }
     sync_job_options(ctx, J);
+    if ((rc = attach_aux_streams(ctx, J, j))) return rc;
     J.tp.half_cu = !(ctx->tp.variant & W3_VAR_FULL_CU);
     st.cap = default_stripe_cap(block_size);
     ENSURE(ctx, J.stripes, (size_t)nb * st.cap);
