@@ -106,4 +106,4 @@ def test_launcher_command_for_n_ranks():
     body = src[src.index("def main():"):]
     assert body.index("self_launch(") < body.index("import torch")
     a = bench.parse_args(["--gpus", "4"])
-    assert a.gpus == 4 and a.scaling == "both" and a.pipeline == 2
+    assert a.gpus == 4 and a.scaling == "both" and a.pipeline == 0   # (0 = as many encodes in flight as w3_encode_max_in_flight allows)
