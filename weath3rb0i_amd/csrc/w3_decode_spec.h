@@ -83,7 +83,21 @@ __global__ void __launch_bounds__(64) k_decode_spec(CmArgs a) {
                 if (!lp[l].frozen) {
                     ctx[l] = leaf_ctx(lp[l], hist_n, t_n, hs, g.huff);
                     uint32_t *tbl = reinterpret_cast<uint32_t *>(blk_tbl + lp[l].tbl_off);
-                    if (!lp[l].use_hash) { slot[l] = tbl + ctx[l]; val[l] = pl_ld32(slot[l]); }
+                    if (!lp[l].use_hash) {
+                        // NIBBLE-MAJOR direct table (this kernel's own layout; the table is scratch, zeroed per call): a raw-history
+                        // context of alignment 3 is a window of H = bits - 3 history bits plus the bit position.  For node (k, x) of
+                        // a nibble that starts with history h the window is [v : 3-k bits][g : H-3 bits][x : k bits], g = the low H-3
+                        // bits of h, v the 3-k bits above them — so the 32 Counters {(k, v, x)} of one (half, g) are everything ANY
+                        // nibble starting with those H-3 history bits can touch: ONE 128-byte line instead of 15 scattered words
+                        // (the PMC passes of the first version: 4.3 KB fetched per nibble and block, HBM-bound at 5 TB/s).
+                        uint32_t idx = ctx[l];
+                        if (lp[l].hist <= W3_HIST_RAW && lp[l].align == 3u && lp[l].bits >= 6u) {
+                            const uint32_t H = lp[l].bits - 3u;
+                            const uint32_t gq = (uint32_t)hist64 & ((1u << (H - 3u)) - 1u), v = (uint32_t)(hist64 >> (H - 3u)) & ((8u >> k) - 1u);
+                            idx = (((((t >> 2) & 1u) << (H - 3u)) | gq) << 5) | (k << 3) | (v << k) | x;
+                        }
+                        slot[l] = tbl + idx; val[l] = pl_ld32(slot[l]);
+                    }
                     else {
                         // exact map {ctx + 1, counts}: found, or absent (the empty slot ends the probe; only a path node claims one, below)
                         uint32_t h = (ctx[l] * 2654435761u) ^ (ctx[l] >> 15);
