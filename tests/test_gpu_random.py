@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 
 from tests.synth import lcg_text, markov_text, mixed_bytes
-from tests.test_gpu_parity import check_blocks, ctx  # noqa: F401  (fixture)
+from tests.test_gpu_parity import check_blocks, ctx, decode_both, pair  # noqa: F401  (fixture)
 
 pytestmark = pytest.mark.gpu
 
@@ -34,4 +34,24 @@ def test_random_shapes(ctx, oracle, case):  # noqa: F811
     if n // bs > 3000:                               # keep the oracle run short
         bs = max(bs, n // 3000 + 1)
     data = make_data(rng, case % 5, n)
-    check_blocks(ctx, oracle, name, data, bs, "twophase")
+    out, lens = check_blocks(ctx, oracle, name, data, bs, "twophase")
+    # and back: k_decode_spec (sixteen lanes per block) and the lane-per-block decoder must both return the input
+    assert decode_both(ctx, pair(oracle, name)[0](), out, lens, bs, len(data)).tobytes() == data
+
+
+CM_MODELS = ["slot1", "slot2", "slot_mix", "o012_apm", "apm_chain4", "full_cm_small_tables", "apm1_order0_r3", "slot7"]
+
+
+@pytest.mark.parametrize("case", range(16))
+def test_random_shapes_cm(ctx, oracle, case):  # noqa: F811
+    """The same sweep over the CM models: slot-state leaves on both forms (sorted replay and k_slot), APM chains, the two-phase encoder
+    against k_cm, both decoders (tests/test_gpu_cm.py::check does all of that per case)."""
+    from tests.test_gpu_cm import check
+    rng = np.random.default_rng(5000 + case)
+    name = CM_MODELS[case % len(CM_MODELS)]
+    n = int(rng.integers(8, 120_000))
+    bs = int(rng.choice([8, 17, 64, 100, 511, 512, 2049, 4096, 10_000, 65_536, 70_001]))
+    if n // bs > 1500:
+        bs = max(bs, n // 1500 + 1)
+    data = make_data(rng, case % 5, n)
+    check(ctx, oracle, name, data, bs)
