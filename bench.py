@@ -637,7 +637,10 @@ def main():
             "roofline": {"bound": "hbm", "kernel": dom["kernel"], "achieved": dom["achieved"], "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": dom["frac"], "traffic": dom["traffic"], "traffic_source": dom["traffic_source"],
                          "avg_launch_ms": dom["avg_launch_ms"], "algorithmic_bytes_per_launch": dom["algorithmic_bytes_per_launch"], "launches_per_step": 1,
-                         "chosen_by": "longest average launch among the step's kernels (hipEvents on each kernel's launch stream)"},
+                         "chosen_by": "longest average launch among the step's kernels (hipEvents on each kernel's launch stream)",
+                         "note": ("with several encodes in flight the coder's launch is stretched by the kernels beside it (one latency chain per lane: %s ms with nothing "
+                                  "beside it, floors.coder_floor_ms) — the kernels that own the chip are in roofline_kernels (k_apm0, k_rank_sorted) and whole_step is the step's "
+                                  "algorithmic bytes over its time" % (sync_line["kernel_ms_per_step"]["coder_ms"] if sync_line else "?")) if pipeline >= 2 and "coder" in dom["kernel"] else None},
             "roofline_kernels": table,
             "whole_step": {"algorithmic_bytes": int(sum(r["algorithmic_bytes_per_launch"] for r in table)),
                            "achieved_GBps": round(sum(r["algorithmic_bytes_per_launch"] for r in table) / (ms_per_step * 1e-3) / 1e9, 1),
