@@ -16,9 +16,9 @@
 //   3. k_slot_replay   one WAVEFRONT per (block, leaf); a lane replays the events of a range of Cells (the sort's last-pass
 //                      bins: contiguous in the sorted array) one by one: the open Cell lives in LDS (128 B per lane), starts empty
 //                      when the cell index changes and is simply dropped when its last event is through — nothing of it ever goes
-//                      to memory.  Tag match / eviction / four state steps as in k_slot (hashmap.rs:42-71, 80-128), the four
-//                      state reads of a nibble issued together (their addresses depend on the nibble's bits, not on the states
-//                      read).  The replay also CHECKS the sort it relies on (cells ascending inside a bin, events ascending
+//                      to memory.  Tag match / eviction / four state steps as in k_slot (hashmap.rs:42-71, 80-128) with the slots' tags and
+//                      first-bit states in registers, the four state reads of a nibble issued together (their addresses depend on the
+//                      nibble's bits, not on the states read); records arrive through an LDS transposition (coalesced loads).  The replay also CHECKS the sort it relies on (cells ascending inside a bin, events ascending
 //                      inside a cell): a violation — returning LDS adds not resolved in lane order — is counted in the call's
 //                      flag word 2, which makes the host code the call again on the ballot path, where k_slot runs.
 // HBM traffic per event: 8 B record written, 1 or 2 passes of (8 r + 8 w), 8 B read, 8 B of probabilities written (scattered
@@ -40,6 +40,10 @@ struct Slot2Args {
     uint32_t *fault;      // the call's flag word 2 (order violations seen by the replay), or null
     uint8_t *dummy;       // >= 1 KiB sink for predicated-off stores
     int n_leaves;
+    uint32_t *job_counter;               // k_slot_replay: next job (zeroed before the launch)
+    uint32_t dbg;                        // timing experiments only (results wrong): 1 = no probability store
+    uint32_t jobs_per_block;             // sum of leaf_w
+    uint32_t leaf_w[W3_MAX_SLOT_LEAVES]; // wavefronts per (block, leaf): 2^log_cells / 64, at least 1, at most 4
     SlotLeaf leaf[W3_MAX_SLOT_LEAVES];   // (tbl_off unused)
 };
 
@@ -164,27 +168,35 @@ __global__ void __launch_bounds__(64) k_slot_sort(Slot2Args a) {
 }
 
 // ---------------------------------------------------------------------------
-// One nibble on the Cell staged in LDS: slot lookup (or eviction), the four state steps with their reads issued together.
-__device__ __forceinline__ void slot_nibble2(lds_u16 *cb, const lds_u64 *st, uint32_t tag, uint32_t nib, uint32_t p[4]) {
-    // Cell::get_slot (hashmap.rs:42-63): compare the tags of slot 3, 2, 1, 0 in this order
-    const uint32_t t3 = cb[cx(63u)], t2 = cb[cx(47u)], t1 = cb[cx(31u)], t0 = cb[cx(15u)];
-    int id = tag == t3 ? 3 : tag == t2 ? 2 : tag == t1 ? 1 : tag == t0 ? 0 : -1;
+#define W3_S2_WAVES 8   // wavefronts per workgroup of k_slot_replay (they share the state table in LDS: 145 KiB per workgroup, one per CU)
+#define W3_S2_CHUNK 8u  // records per lane and staging round
+
+// One nibble on the Cell staged in LDS, tags and first-bit states of the four slots in REGISTERS (the Cell is private to the lane):
+// slot lookup (or eviction), the four state steps with their reads issued together.  A slot's sector in LDS is cleared when the
+// slot is first touched in this Cell (`valid`), not when the Cell is opened.
+struct OpenCell { uint32_t t0, t1, t2, t3, f0, f1, f2, f3, valid; };
+__device__ __forceinline__ void slot_nibble3(lds_u16 *cb, const lds_u64 *st, OpenCell &c, uint32_t tag, uint32_t nib, uint32_t p[4]) {
+    // Cell::get_slot (hashmap.rs:42-63): compare the tags of slot 3, 2, 1, 0 in this order (an empty Cell's tags are 0)
+    int id = tag == c.t3 ? 3 : tag == c.t2 ? 2 : tag == c.t1 ? 1 : tag == c.t0 ? 0 : -1;
     if (id < 0) {
         // miss (hashmap.rs:64-68 TODO; policy of w3_cm.h slot_select): victim = fewest observations in the slot's first-bit state,
         // candidates in the order 1, 0, 2, 3; tag stored, 15 states cleared
-        const uint32_t f1 = cb[cx(16u)], f0 = cb[cx(0u)], f2 = cb[cx(32u)], f3 = cb[cx(48u)];
-        uint32_t best = (uint32_t)(st[f1] >> 48); id = 1;
-        uint32_t c = (uint32_t)(st[f0] >> 48); if (c < best) { best = c; id = 0; }
-        c = (uint32_t)(st[f2] >> 48); if (c < best) { best = c; id = 2; }
-        c = (uint32_t)(st[f3] >> 48); if (c < best) { best = c; id = 3; }
-        W3_LDS_FENCE();
+        uint32_t best = (uint32_t)(st[c.f1] >> 48); id = 1;
+        uint32_t q = (uint32_t)(st[c.f0] >> 48); if (q < best) { best = q; id = 0; }
+        q = (uint32_t)(st[c.f2] >> 48); if (q < best) { best = q; id = 2; }
+        q = (uint32_t)(st[c.f3] >> 48); if (q < best) { best = q; id = 3; }
+        c.t0 = id == 0 ? tag : c.t0; c.t1 = id == 1 ? tag : c.t1; c.t2 = id == 2 ? tag : c.t2; c.t3 = id == 3 ? tag : c.t3;
+        c.valid &= ~(1u << id);
+    }
+    if (!((c.valid >> id) & 1u)) {   // first touch of this slot in this Cell (or just evicted): its 15 states start at 0
         typedef __attribute__((address_space(3))) u32x4 lds_u32x4;
         lds_u32x4 *sec = (lds_u32x4 *)(cb + cx(16u * (uint32_t)id));
         u32x4 z; z.x = 0u; z.y = 0u; z.z = 0u; z.w = 0u;
+        W3_LDS_FENCE();
         sec[0] = z;
-        z.w = tag << 16;
         sec[64] = z;            // next chunk row: 64 lanes x 16 bytes further
         W3_LDS_FENCE();
+        c.valid |= 1u << id;
     }
     // Slot::get_nib / set_nib (hashmap.rs:114-128): node k of the path = (1 << k) - 1 + (the nibble's top k bits); the four addresses
     // are known before any state is read, so the reads go out together, then the four table rows, then the four writes
@@ -197,100 +209,123 @@ __device__ __forceinline__ void slot_nibble2(lds_u16 *cb, const lds_u64 *st, uin
     uint64_t e[4];
 #pragma unroll
     for (int k = 0; k < 4; k++) e[k] = st[sv[k]];
+    uint32_t nf = 0u;
 #pragma unroll
     for (int k = 0; k < 4; k++) {
         const uint32_t bit = (nib >> (3 - k)) & 1u;
         p[k] = (uint32_t)e[k] & 0xFFFFu;
-        cb[x[k]] = (uint16_t)(bit ? ((uint32_t)(e[k] >> 32) & 0xFFFFu) : ((uint32_t)e[k] >> 16));
+        const uint32_t ns = bit ? ((uint32_t)(e[k] >> 32) & 0xFFFFu) : (((uint32_t)e[k] >> 16) & 0xFFFFu);
+        cb[x[k]] = (uint16_t)ns;
+        if (k == 0) nf = ns;   // the slot's first-bit state (node 0)
     }
     W3_LDS_FENCE();
+    c.f0 = id == 0 ? nf : c.f0; c.f1 = id == 1 ? nf : c.f1; c.f2 = id == 2 ? nf : c.f2; c.f3 = id == 3 ? nf : c.f3;
 }
 
-#define W3_S2_WAVES 4   // wavefronts per workgroup of k_slot_replay (they share the state table in LDS)
-#define W3_S2_BATCH 8u  // records per lane and memory wait
-
-// One WAVEFRONT per (block, leaf); lane l replays the events of the sort's last-pass bins l, l + 64, l + 128, l + 192 — cell
-// ranges whose events are contiguous in the sorted array (start = exclusive scan of the block's digit counts) — one after the
-// other, serially, with the open Cell in LDS.  All 64 lanes work on ONE block: the 8-byte probability stores land in the
-// block's own stream.
+// JOB = (block, leaf, w): wavefront w of the W_leaf (4; fewer for tables under 256 Cells) that share a (block, leaf); lane L = 64 w + lane replays the
+// events of the Cells [L << sh, (L + 1) << sh) — contiguous in the sorted array, found by binary search — serially, with the open Cell
+// in LDS.  Jobs are handed out in BLOCK-MAJOR order from one counter to a persistent grid (as k_rank_sorted does): with several wavefronts
+// per (block, leaf) fewer streams are being scattered into at a time, so the 8-byte probability stores — four of them make a 32-byte
+// sector, each from another Cell, i.e. another lane at another time — meet in the 256 MiB Infinity Cache instead of going to HBM as
+// partial writes (one wavefront per (block, leaf), 2,048 streams live: the stores were 16 of the replay's 30 ms at enwik8 size; with 16
+// wavefronts they cost 1 ms, but a job of 128 events per lane is too short for its own start-up: see twophase_predict_b for the numbers).
+// Shorter jobs also mean that a lane stuck with a hot Cell (few distinct contexts: one Cell takes most of a block's events) holds up one
+// wavefront's lanes for their share, not for a whole block's.  Records reach the lanes through an LDS transposition: a lane's records are consecutive in
+// memory, so 8 lanes fetch the next W3_S2_CHUNK records of ONE lane's range in one coalesced access and each lane then reads its own
+// records back from LDS (one load instruction per eight lanes' chunks instead of one fully divergent load per event).
 __global__ void __launch_bounds__(64 * W3_S2_WAVES) k_slot_replay(Slot2Args a, int two_passes) {
     __shared__ uint2 s_st[kStSize];
     __shared__ u32x4 s_cell[W3_S2_WAVES][8][64];   // [wave][chunk][lane]: the open Cell of every lane
-    __shared__ uint32_t s_cnt[W3_S2_WAVES][256], s_start[W3_S2_WAVES][256];
+    __shared__ uint32_t s_lo[W3_S2_WAVES][64], s_n[W3_S2_WAVES][64];
+    __shared__ uint64_t s_rec[W3_S2_WAVES][W3_S2_CHUNK * 65u];   // [round r][lane] (+1 per row: the staging writes would hit one bank)
     for (uint32_t i = threadIdx.x; i < (uint32_t)kStSize; i += 64u * W3_S2_WAVES) s_st[i] = a.st[i];
     __syncthreads();
     typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
     typedef __attribute__((address_space(1))) u32x2 g_uint2;
-    typedef __attribute__((address_space(3))) u32x4 lds_u32x4;
     const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
-    const SlotLeaf &lf = a.leaf[blockIdx.y];
-    const uint32_t b = blockIdx.x * W3_S2_WAVES + wv;
-    if (b >= a.nblocks) return;   // (no barrier below)
-    const uint64_t off = (uint64_t)b * a.block_size;
-    const uint64_t *keys = (two_passes ? a.keys_a : a.keys_b) + (uint64_t)blockIdx.y * 2u * a.n + 2u * off;
-    // the bins of the last pass that moved anything (a leaf of at most 2^8 Cells goes through the second pass unchanged: one bin)
-    const uint32_t *gh = a.hist + ((uint64_t)blockIdx.y * a.nblocks + b) * 512u + ((two_passes && lf.log_cells > 8u) ? 256u : 0u);
-    g_uint2 *Pout = (g_uint2 *)(lf.P + off);
     lds_u16 *cb = (lds_u16 *)&s_cell[wv][0][lane];
-    lds_u32x4 *cq = (lds_u32x4 *)&s_cell[wv][0][lane];
     const lds_u64 *st = (const lds_u64 *)&s_st[0];
-#pragma unroll
-    for (int k = 0; k < 4; k++) s_cnt[wv][k * 64 + lane] = gh[k * 64 + lane];
-    __asm__ volatile("" ::: "memory");
-    __builtin_amdgcn_wave_barrier();
-    wave_excl_scan_256(s_cnt[wv], s_start[wv], nullptr);
-    __asm__ volatile("" ::: "memory");
-    __builtin_amdgcn_wave_barrier();
-    uint32_t bs_[4], bc_[4], tot = 0u;
-#pragma unroll
-    for (int q = 0; q < 4; q++) { bs_[q] = s_start[wv][q * 64 + lane]; bc_[q] = s_cnt[wv][q * 64 + lane]; tot += bc_[q]; }
-    uint32_t maxtot = tot;
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) maxtot = max(maxtot, (uint32_t)__shfl_xor((int)maxtot, d, 64));
-    maxtot = __builtin_amdgcn_readfirstlane(maxtot);
-    // this lane's events as one sequence: bins q = 0..3 one after the other; event k of the lane sits at idx(k)
-    const uint32_t c0 = bc_[0], c1 = c0 + bc_[1], c2 = c1 + bc_[2];
-    auto idx = [&](uint32_t k) -> uint32_t {
-        const uint32_t kk = min(k, tot ? tot - 1u : 0u);   // (clamped: every load is unconditional and in range)
-        return kk < c0 ? bs_[0] + kk : kk < c1 ? bs_[1] + (kk - c0) : kk < c2 ? bs_[2] + (kk - c1) : bs_[3] + (kk - c2);
-    };
+    uint64_t *rec = s_rec[wv];
     g_uint2 *sink = (g_uint2 *)(a.dummy + 8u * lane);
-    uint32_t cur_cell = 0xFFFFFFFFu, prev_e = 0u, bad = 0u;
-    // Records travel in batches of W3_S2_BATCH per lane: the loads of batch k + 1 are issued before batch k is replayed and every
-    // store is unconditional (idle lanes write to the sink), so the loop waits for memory once per batch, not once per event (gfx9
-    // counts loads and stores in one counter: waiting for a record also waits for the scattered store issued just before it).
-    uint64_t kn[W3_S2_BATCH];
+    const uint32_t tl = lane >> 3, rl = lane & 7u;   // staging geometry: load instruction g fetches record rl of the chunks of owners 8 g + tl
+    uint32_t bad = 0u;
+    const uint32_t njobs = a.nblocks * a.jobs_per_block;
+    for (;;) {   // (no barrier below: the wavefronts of a workgroup take jobs independently)
+        uint32_t job = 0;
+        if (lane == 0) job = atomicAdd(a.job_counter, 1u);
+        job = __builtin_amdgcn_readfirstlane(job);
+        if (job >= njobs) break;
+        const uint32_t b = job / a.jobs_per_block;
+        uint32_t rj = job % a.jobs_per_block, lfi = 0u;
+        while (lfi + 1u < (uint32_t)a.n_leaves && rj >= a.leaf_w[lfi]) { rj -= a.leaf_w[lfi]; lfi++; }
+        const SlotLeaf &lf = a.leaf[lfi];
+        const uint32_t W = a.leaf_w[lfi], lc = lf.log_cells;
+        const uint64_t off = (uint64_t)b * a.block_size;
+        const uint32_t len = (uint32_t)((a.n - off) < a.block_size ? (a.n - off) : a.block_size);
+        const uint32_t nev = 2u * len;
+        const uint64_t *keys = (two_passes ? a.keys_a : a.keys_b) + (uint64_t)lfi * 2u * a.n + 2u * off;
+        g_uint2 *Pout = (g_uint2 *)(lf.P + off);
+        // this lane's range of Cells and of sorted records: lower bounds of its first Cell and of the next lane's
+        const uint32_t L = rj * 64u + lane, lanes_total = 64u * W;
+        const uint32_t ncell = 1u << lc;
+        const uint32_t c_lo = (uint32_t)(((uint64_t)L * ncell) / lanes_total), c_hi = (uint32_t)(((uint64_t)(L + 1u) * ncell) / lanes_total);
+        uint32_t lo0 = 0u, hi0 = nev, lo1 = 0u, hi1 = nev;   // first record with cell >= c_lo / >= c_hi
+        while (__any(lo0 < hi0 || lo1 < hi1)) {
+            const uint32_t m0 = (lo0 + hi0) >> 1, m1 = (lo1 + hi1) >> 1;
+            const uint32_t k0c = (uint32_t)(keys[min(m0, nev - 1u)] >> W3_S2_CELL_SH), k1c = (uint32_t)(keys[min(m1, nev - 1u)] >> W3_S2_CELL_SH);
+            if (lo0 < hi0) { if (k0c < c_lo) lo0 = m0 + 1u; else hi0 = m0; }
+            if (lo1 < hi1) { if (k1c < c_hi) lo1 = m1 + 1u; else hi1 = m1; }
+        }
+        const uint32_t bs = lo0, bc = c_hi > c_lo ? lo1 - lo0 : 0u;
+        __asm__ volatile("" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+        s_lo[wv][lane] = bs; s_n[wv][lane] = bc;
+        __asm__ volatile("" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+        uint32_t maxc = bc;
 #pragma unroll
-    for (uint32_t j = 0; j < W3_S2_BATCH; j++) kn[j] = keys[idx(j)];
-    for (uint32_t k0 = 0; k0 < maxtot; k0 += W3_S2_BATCH) {
-        uint64_t kc[W3_S2_BATCH];
+        for (int d = 32; d >= 1; d >>= 1) maxc = max(maxc, (uint32_t)__shfl_xor((int)maxc, d, 64));
+        maxc = __builtin_amdgcn_readfirstlane(maxc);
+        if (maxc == 0u) continue;
+        uint32_t os[8], oc[8];   // the owners' ranges for the staging loads
 #pragma unroll
-        for (uint32_t j = 0; j < W3_S2_BATCH; j++) kc[j] = kn[j];
+        for (uint32_t g = 0; g < 8u; g++) { os[g] = s_lo[wv][8u * g + tl]; oc[g] = s_n[wv][8u * g + tl]; }
+        OpenCell c; c.t0 = c.t1 = c.t2 = c.t3 = 0u; c.f0 = c.f1 = c.f2 = c.f3 = 0u; c.valid = 0u;
+        uint32_t cur_cell = 0xFFFFFFFFu, prev_e = 0u;
+        uint64_t kn[8];
 #pragma unroll
-        for (uint32_t j = 0; j < W3_S2_BATCH; j++) kn[j] = keys[idx(k0 + W3_S2_BATCH + j)];
+        for (uint32_t g = 0; g < 8u; g++) kn[g] = keys[oc[g] ? os[g] + min(rl, oc[g] - 1u) : 0u];
+        for (uint32_t k0 = 0; k0 < maxc; k0 += W3_S2_CHUNK) {
+            // stage the chunk: record r of lane t at rec[r * 65 + t]
+            __asm__ volatile("" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
 #pragma unroll
-        for (uint32_t j = 0; j < W3_S2_BATCH; j++) {
-            const bool act = k0 + j < tot;
-            const uint64_t key = kc[j];
-            const uint32_t cell = (uint32_t)(key >> W3_S2_CELL_SH), e = (uint32_t)key;
-            const uint32_t tag = (uint32_t)(key >> W3_S2_TAG_SH) & 0xFFFu, nib = (uint32_t)(key >> W3_S2_NIB_SH) & 15u;
-            uint32_t pq[4] = {0u, 0u, 0u, 0u};
-            if (act) {
-                if (cell != cur_cell) {   // the previous Cell's events are through: this one starts empty (a fresh HashMap is all zeros)
-                    // the sort this replay relies on: inside a lane's bins the cells ascend (bins l, l + 64, .. are ascending ranges)
-                    bad |= (cur_cell != 0xFFFFFFFFu && cell < cur_cell) ? 1u : 0u;
-                    u32x4 z; z.x = 0u; z.y = 0u; z.z = 0u; z.w = 0u;
+            for (uint32_t g = 0; g < 8u; g++) rec[rl * 65u + 8u * g + tl] = kn[g];
+            __asm__ volatile("" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
 #pragma unroll
-                    for (int qq = 0; qq < 8; qq++) cq[64 * qq] = z;
-                    W3_LDS_FENCE();
-                    cur_cell = cell;
-                } else bad |= e <= prev_e ? 1u : 0u;   // ... and inside a cell the events keep their time order (the partition is stable)
-                prev_e = e;
-                slot_nibble2(cb, st, tag, nib, pq);
+            for (uint32_t g = 0; g < 8u; g++) kn[g] = keys[oc[g] ? os[g] + min(k0 + W3_S2_CHUNK + rl, oc[g] - 1u) : 0u];   // the next chunk
+#pragma unroll
+            for (uint32_t j = 0; j < W3_S2_CHUNK; j++) {
+                const bool act = k0 + j < bc;
+                const uint64_t key = rec[j * 65u + lane];
+                const uint32_t cell = (uint32_t)(key >> W3_S2_CELL_SH), e = (uint32_t)key;
+                const uint32_t tag = (uint32_t)(key >> W3_S2_TAG_SH) & 0xFFFu, nib = (uint32_t)(key >> W3_S2_NIB_SH) & 15u;
+                uint32_t pq[4] = {0u, 0u, 0u, 0u};
+                if (act) {
+                    if (cell != cur_cell) {   // the previous Cell's events are through: this one starts empty (a fresh HashMap is all zeros)
+                        // the sort this replay relies on: the lane's cells ascend inside its range ...
+                        bad |= ((cur_cell != 0xFFFFFFFFu && cell < cur_cell) || cell < c_lo || cell >= c_hi) ? 1u : 0u;
+                        c.t0 = c.t1 = c.t2 = c.t3 = 0u; c.f0 = c.f1 = c.f2 = c.f3 = 0u; c.valid = 0u;
+                        cur_cell = cell;
+                    } else bad |= e <= prev_e ? 1u : 0u;   // ... and inside a cell the events keep their time order (the partition is stable)
+                    prev_e = e;
+                    slot_nibble3(cb, st, c, tag, nib, pq);
+                }
+                u32x2 v; v.x = pq[0] | (pq[1] << 16); v.y = pq[2] | (pq[3] << 16);
+                g_uint2 *dst = (act && !(a.dbg & 1u)) ? Pout + e : sink;
+                *dst = v;
             }
-            u32x2 v; v.x = pq[0] | (pq[1] << 16); v.y = pq[2] | (pq[3] << 16);
-            g_uint2 *dst = act ? Pout + e : sink;
-            *dst = v;
         }
     }
     if (bad && a.fault) atomicAdd(a.fault, 1u);

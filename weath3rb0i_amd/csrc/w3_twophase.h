@@ -594,7 +594,23 @@ static inline int twophase_predict_b(TwoPhaseWs &ws, hipStream_t s, const Parsed
             hipLaunchKernelGGL(w3::k_slot_events, gw, dim3(64), 0, s, s2);
             hipLaunchKernelGGL(w3::k_slot_sort<0>, gw, dim3(64), 0, s, s2);
             if (two_passes) hipLaunchKernelGGL(w3::k_slot_sort<1>, gw, dim3(64), 0, s, s2);   // (a leaf of at most 2^8 Cells passes through unchanged: one bin)
-            hipLaunchKernelGGL(w3::k_slot_replay, dim3((nb + W3_S2_WAVES - 1) / W3_S2_WAVES, sa.n_leaves), dim3(64 * W3_S2_WAVES), 0, s, s2, two_passes ? 1 : 0);
+            // replay: jobs (block, leaf, wavefront) from one counter, block-major, to a persistent grid (one 8-wave workgroup per CU)
+            s2.jobs_per_block = 0;
+            for (int l = 0; l < sa.n_leaves; l++) {
+                const uint32_t cells = 1u << sa.leaf[l].log_cells;
+                // wavefronts per (block, leaf): 4.  Measured at enwik8 size, four 2^14-cell leaves (tools/r3_sl2.sh; replay kernel, with / without
+                // its probability stores): 1 wavefront 30.1 / 13.7 ms (2,048 streams live: the 8-byte stores reach HBM as partial writes),
+                // 4 wavefronts 25.4 / 22.2, 16 wavefronts 42.2 / 41.0 (the stores merge in the Infinity Cache, but a job of 128 events per
+                // lane no longer covers its own start-up: job fetch, binary search, first chunk).  W3_OPT_TUNE bits 9 / 10: 16 / 1.
+                const uint32_t wcap = (ws.tune & 1024u) ? 1u : (ws.tune & 512u) ? 16u : 4u;
+                s2.leaf_w[l] = std::min<uint32_t>(wcap, std::max<uint32_t>(1u, cells / 64u));
+                s2.jobs_per_block += s2.leaf_w[l];
+            }
+            s2.dbg = (ws.tune >> 8) & 1u;   // (W3_OPT_TUNE bit 8: timing experiment, results wrong)
+            s2.job_counter = (uint32_t *)((uint8_t *)ws.slot_keys + 2 * key_bytes + hist_bytes);
+            (void)hipMemsetAsync(s2.job_counter, 0, 4, s);
+            const uint32_t njobs = nb * s2.jobs_per_block;
+            hipLaunchKernelGGL(w3::k_slot_replay, dim3(std::min<uint32_t>((njobs + W3_S2_WAVES - 1) / W3_S2_WAVES, 256u)), dim3(64 * W3_S2_WAVES), 0, s, s2, two_passes ? 1 : 0);
             if (ev) (void)hipEventRecord(ev[2 * W3_EV_SLOT + 1], s);
             if (tm) tm->n_slot_launches = 0;   // (no table batches)
             hipError_t e = hipGetLastError();
