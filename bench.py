@@ -675,9 +675,11 @@ def main():
         d_in_keep = None
         rg.release()
         oc = []
-        for mname, kind, size, obs in (("fullcm", "text", args.size, bs), ("fullcm", "mixed", 211_938_580, 262144)):
+        for mname, kind, size, obs, nsteps in (("fullcm", "text", args.size, bs, 3), ("fullcm", "mixed", 211_938_580, 262144, 3), ("fullcm", "text", 100_000_000, bs, 8)):
             try:
-                oc.append(short_run(w3, mname, kind, size, obs, args.seed, 3, env))
+                oc.append(short_run(w3, mname, kind, size, obs, args.seed, nsteps, env))
+                if size == 100_000_000:
+                    oc[-1]["what"] = "configs[2] at its literal enwik8 size"
             except Exception as e:   # an extra must not lose the main line
                 oc.append({"context_model": mname, "data": kind, "error": str(e)[:300]})
         res["other_configs"] = oc
