@@ -847,6 +847,26 @@ static bool slot_sorted_by_default(const ParsedSpec &ps, uint32_t nb, size_t blo
     return true;
 }
 
+// How submitted calls of this spec and size are kept in flight (w3_encode_submit and w3_encode_max_in_flight must agree).
+//   ordered pair   step k's coder beside step k+1's rank kernels, APM stage in between: large inputs of models with
+//                  wide (sorted) leaves AND an APM stage — the bench model: 14,1xx MiB/s against 13,570 free-running;
+//   free-running   every code stage on its own stream as soon as it is submitted: small and medium inputs of any model, and large inputs
+//                  of models WITHOUT rank kernels to put the coder beside (1e9 B: Order0 38,099 -> 52,642 MiB/s with three in flight,
+//                  main.rs's default model 15,578 -> 17,566; order012, wide leaves but no APM stage, 16,038 -> 16,313 with two).
+struct PipelinePlan { bool free_run; int depth; };
+static PipelinePlan pipeline_plan(const ParsedSpec &ps, uint32_t nb, uint32_t tune) {
+    int n_wide = 0;
+    for (int l = 0; l < ps.n_leaves; l++) { const int c = leaf_class(ps.leaf[l]); n_wide += c == LEAF_WIDE1 || c == LEAF_WIDE2 || c == LEAF_WAVE; }
+    PipelinePlan p;
+    p.free_run = (nb <= W3_FREE_RUN_BLOCKS || n_wide == 0 || ps.n_apm == 0 || (tune & 8192u)) && !(tune & 4096u);   // (W3_OPT_TUNE bit 12: ordered, 13: free-running, whatever the size)
+    if (ps.has_slot) p.depth = 2;                       // (event records: 32 bytes per input byte and leaf)
+    else if (!p.free_run) p.depth = 2;
+    else if (nb <= W3_FREE_RUN4_BLOCKS) p.depth = W3_MAX_JOBS;
+    else if (nb <= W3_FREE_RUN_BLOCKS) p.depth = 3;
+    else p.depth = n_wide == 0 ? 3 : 2;                 // large inputs: a workspace is 16 bytes per input byte and live leaf (+ 40 per wide leaf)
+    return p;
+}
+
 static int ensure_pipeline(w3_ctx *ctx) {
     // The two stages must not share a hardware queue (HIP maps streams onto GPU_MAX_HW_QUEUES = 4 queues per priority level by
     // default, round-robin: two streams of one level can land on the same queue and then run one after the other).  Streams of
@@ -913,9 +933,9 @@ extern "C" int w3_encode_submit(w3_ctx *ctx, const w3_model_spec *spec, const ui
     // Specs with slot-state leaves are pipelined when the leaves run as the sorted replay (w3_slot2.h: no hash maps sized from the memory
     // that happens to be free) — two jobs at most: a job's event records are 32 bytes per input byte and leaf.
     const bool slot_async = ps.has_slot && slot_sorted_by_default(ps, nb, block_size) && !(ctx->tp.variant & (W3_VAR_SLOT_TABLE | W3_VAR_NO_LDS_ATOMICS)) && ctx->tp.lds_order != 0;
-    // small inputs: free-running jobs, up to W3_MAX_JOBS of them, every code stage on its own stream; large ones: the ordered pair
-    const bool free_run = (nb <= W3_FREE_RUN_BLOCKS || (ctx->tp.tune & 8192u)) && !(ctx->tp.tune & 4096u);   // (W3_OPT_TUNE bit 12: the ordered pair whatever the size; 13: free-running jobs whatever the size)
-    const int depth = ps.has_slot ? 2 : free_run ? (nb <= W3_FREE_RUN4_BLOCKS ? W3_MAX_JOBS : 3) : 2;
+    const PipelinePlan plan = pipeline_plan(ps, nb, ctx->tp.tune);
+    const bool free_run = plan.free_run;
+    const int depth = plan.depth;
     int in_flight = 0;
     for (const auto &o : ctx->js) in_flight += o.state != 0;
     int j = ctx->next_job % depth;
@@ -1021,12 +1041,10 @@ extern "C" int w3_encode_submit(w3_ctx *ctx, const w3_model_spec *spec, const ui
 extern "C" int w3_encode_max_in_flight(const w3_model_spec *spec, size_t n, size_t block_size) {
     if (!block_size) return 0;
     const size_t nb = (n + block_size - 1) / block_size;
-    if (spec) {
-        ParsedSpec ps;
-        if (parse_spec(spec, ps)) return 0;
-        if (ps.has_slot) return 2;
-    }
-    return nb <= W3_FREE_RUN4_BLOCKS ? W3_MAX_JOBS : nb <= W3_FREE_RUN_BLOCKS ? 3 : 2;
+    ParsedSpec ps;   // (no spec: a model with wide leaves and an APM stage, the most conservative answer)
+    if (spec) { if (parse_spec(spec, ps)) return 0; }
+    else { ps.n_leaves = 1; ps.leaf[0] = w3_node{}; ps.leaf[0].kind = W3_NODE_ORDERN; ps.leaf[0].bits = 19; ps.leaf[0].align = 3; ps.n_apm = 1; }
+    return pipeline_plan(ps, (uint32_t)std::min<size_t>(nb, 0xFFFFFFFFu), 0u).depth;
 }
 
 extern "C" int w3_encode_wait(w3_ctx *ctx, int job) {
