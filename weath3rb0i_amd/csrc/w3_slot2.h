@@ -36,6 +36,8 @@ struct Slot2Args {
     uint32_t block_size, nblocks;
     uint64_t *keys_a, *keys_b;   // [n_leaves][2 n] each
     uint32_t *hist;       // [n_leaves][nblocks][512]: counts of the low 8 cell bits, of the bits above
+    uint32_t *pre2;       // [n_leaves][nblocks][1024]: exclusive prefix of the events per FINE bin (cell >> (log_cells - 10), or the cell itself
+                          // for tables under 2^10 Cells): where a lane's range of Cells starts in the sorted array (k_slot_replay)
     const uint2 *st;      // [kStSize] {prob | next0 << 16, next1 | conf << 16}
     uint32_t *fault;      // the call's flag word 2 (order violations seen by the replay), or null
     uint8_t *dummy;       // >= 1 KiB sink for predicated-off stores
@@ -43,7 +45,7 @@ struct Slot2Args {
     uint32_t *job_counter;               // k_slot_replay: next job (zeroed before the launch)
     uint32_t dbg;                        // timing experiments only (results wrong): 1 = no probability store
     uint32_t jobs_per_block;             // sum of leaf_w
-    uint32_t leaf_w[W3_MAX_SLOT_LEAVES]; // wavefronts per (block, leaf): 2^log_cells / 64, at least 1, at most 4
+    uint32_t leaf_w[W3_MAX_SLOT_LEAVES]; // wavefronts per (block, leaf): min(2^log_cells, 1024) / 64, at least 1, at most 4
     SlotLeaf leaf[W3_MAX_SLOT_LEAVES];   // (tbl_off unused)
 };
 
@@ -54,9 +56,11 @@ struct Slot2Args {
 // ---------------------------------------------------------------------------
 __global__ void __launch_bounds__(64) k_slot_events(Slot2Args a) {
     __shared__ uint32_t s_hist[512];
+    __shared__ uint32_t s_h2[1024];
     const uint32_t lane = threadIdx.x & 63u;
     const SlotLeaf &lf = a.leaf[blockIdx.y];
     const uint32_t order = lf.order, lshift = 64u - lf.log_cells;
+    const uint32_t sh2 = lf.log_cells > 10u ? lf.log_cells - 10u : 0u;
     uint64_t *keys = a.keys_a + (uint64_t)blockIdx.y * 2u * a.n;
     for (uint32_t b = blockIdx.x; b < a.nblocks; b += gridDim.x) {
         const uint64_t off = (uint64_t)b * a.block_size;
@@ -65,6 +69,8 @@ __global__ void __launch_bounds__(64) k_slot_events(Slot2Args a) {
         const bool first = off == 0;
 #pragma unroll
         for (int k = 0; k < 8; k++) s_hist[k * 64 + lane] = 0u;
+#pragma unroll
+        for (int k = 0; k < 16; k++) s_h2[k * 64 + lane] = 0u;
         __asm__ volatile("" ::: "memory");
         __builtin_amdgcn_wave_barrier();
         const uint32_t nev = 2u * len;
@@ -81,6 +87,7 @@ __global__ void __launch_bounds__(64) k_slot_events(Slot2Args a) {
                 keys[2u * off + e] = ((uint64_t)cell << W3_S2_CELL_SH) | ((uint64_t)((uint32_t)h & 0xFFFu) << W3_S2_TAG_SH) | ((uint64_t)nib << W3_S2_NIB_SH) | e;
                 __hip_atomic_fetch_add(&s_hist[cell & 255u], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 __hip_atomic_fetch_add(&s_hist[256u + (cell >> 8)], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __hip_atomic_fetch_add(&s_h2[cell >> sh2], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
         }
         __asm__ volatile("" ::: "memory");
@@ -88,6 +95,16 @@ __global__ void __launch_bounds__(64) k_slot_events(Slot2Args a) {
         uint32_t *gh = a.hist + ((uint64_t)blockIdx.y * a.nblocks + b) * 512u;
 #pragma unroll
         for (int k = 0; k < 8; k++) gh[k * 64 + lane] = s_hist[k * 64 + lane];
+        {   // exclusive prefix of the fine bins: lane l owns bins 16 l .. 16 l + 15
+            uint32_t cnt[16], sum = 0u;
+#pragma unroll
+            for (int k = 0; k < 16; k++) { cnt[k] = s_h2[16 * lane + k]; sum += cnt[k]; }
+            uint32_t tot;
+            uint32_t run = wave_excl_scan_u32(sum, &tot);
+            uint32_t *gp = a.pre2 + ((uint64_t)blockIdx.y * a.nblocks + b) * 1024u + 16u * lane;
+#pragma unroll
+            for (int k = 0; k < 16; k++) { gp[k] = run; run += cnt[k]; }
+        }
         __asm__ volatile("" ::: "memory");
         __builtin_amdgcn_wave_barrier();
     }
@@ -222,13 +239,13 @@ __device__ __forceinline__ void slot_nibble3(lds_u16 *cb, const lds_u64 *st, Ope
     c.f0 = id == 0 ? nf : c.f0; c.f1 = id == 1 ? nf : c.f1; c.f2 = id == 2 ? nf : c.f2; c.f3 = id == 3 ? nf : c.f3;
 }
 
-// JOB = (block, leaf, w): wavefront w of the W_leaf (4; fewer for tables under 256 Cells) that share a (block, leaf); lane L = 64 w + lane replays the
-// events of the Cells [L << sh, (L + 1) << sh) — contiguous in the sorted array, found by binary search — serially, with the open Cell
+// JOB = (block, leaf, w): wavefront w of the W_leaf (4; fewer for tables under 2^8 Cells) that share a (block, leaf); lane L = 64 w + lane replays
+// the events of its fine bin(s) of Cells — contiguous in the sorted array, the start read from k_slot_events' prefix table — serially, with the open Cell
 // in LDS.  Jobs are handed out in BLOCK-MAJOR order from one counter to a persistent grid (as k_rank_sorted does): with several wavefronts
 // per (block, leaf) fewer streams are being scattered into at a time, so the 8-byte probability stores — four of them make a 32-byte
 // sector, each from another Cell, i.e. another lane at another time — meet in the 256 MiB Infinity Cache instead of going to HBM as
 // partial writes (one wavefront per (block, leaf), 2,048 streams live: the stores were 16 of the replay's 30 ms at enwik8 size; with 16
-// wavefronts they cost 1 ms, but a job of 128 events per lane is too short for its own start-up: see twophase_predict_b for the numbers).
+// wavefronts they cost 1 ms, but a lane then owns 16 Cells and the wavefront waits for its busiest lane: see twophase_predict_b for the numbers).
 // Shorter jobs also mean that a lane stuck with a hot Cell (few distinct contexts: one Cell takes most of a block's events) holds up one
 // wavefront's lanes for their share, not for a whole block's.  Records reach the lanes through an LDS transposition: a lane's records are consecutive in
 // memory, so 8 lanes fetch the next W3_S2_CHUNK records of ONE lane's range in one coalesced access and each lane then reads its own
@@ -265,18 +282,14 @@ __global__ void __launch_bounds__(64 * W3_S2_WAVES) k_slot_replay(Slot2Args a, i
         const uint32_t nev = 2u * len;
         const uint64_t *keys = (two_passes ? a.keys_a : a.keys_b) + (uint64_t)lfi * 2u * a.n + 2u * off;
         g_uint2 *Pout = (g_uint2 *)(lf.P + off);
-        // this lane's range of Cells and of sorted records: lower bounds of its first Cell and of the next lane's
+        // this lane's range of fine bins (k_slot_events' prefix table), i.e. of Cells and of sorted records
         const uint32_t L = rj * 64u + lane, lanes_total = 64u * W;
-        const uint32_t ncell = 1u << lc;
-        const uint32_t c_lo = (uint32_t)(((uint64_t)L * ncell) / lanes_total), c_hi = (uint32_t)(((uint64_t)(L + 1u) * ncell) / lanes_total);
-        uint32_t lo0 = 0u, hi0 = nev, lo1 = 0u, hi1 = nev;   // first record with cell >= c_lo / >= c_hi
-        while (__any(lo0 < hi0 || lo1 < hi1)) {
-            const uint32_t m0 = (lo0 + hi0) >> 1, m1 = (lo1 + hi1) >> 1;
-            const uint32_t k0c = (uint32_t)(keys[min(m0, nev - 1u)] >> W3_S2_CELL_SH), k1c = (uint32_t)(keys[min(m1, nev - 1u)] >> W3_S2_CELL_SH);
-            if (lo0 < hi0) { if (k0c < c_lo) lo0 = m0 + 1u; else hi0 = m0; }
-            if (lo1 < hi1) { if (k1c < c_hi) lo1 = m1 + 1u; else hi1 = m1; }
-        }
-        const uint32_t bs = lo0, bc = c_hi > c_lo ? lo1 - lo0 : 0u;
+        const uint32_t sh2 = lc > 10u ? lc - 10u : 0u, nbins = 1u << (lc - sh2);
+        const uint32_t b_lo = (uint32_t)(((uint64_t)L * nbins) / lanes_total), b_hi = (uint32_t)(((uint64_t)(L + 1u) * nbins) / lanes_total);
+        const uint32_t c_lo = b_lo << sh2, c_hi = b_hi << sh2;
+        const uint32_t *pre = a.pre2 + ((uint64_t)lfi * a.nblocks + b) * 1024u;
+        const uint32_t p_lo = pre[min(b_lo, nbins - 1u)], p_hi = b_hi < nbins ? pre[b_hi] : nev;
+        const uint32_t bs = p_lo, bc = b_hi > b_lo ? p_hi - p_lo : 0u;
         __asm__ volatile("" ::: "memory");
         __builtin_amdgcn_wave_barrier();
         s_lo[wv][lane] = bs; s_n[wv][lane] = bc;

@@ -572,7 +572,7 @@ static inline int twophase_predict_b(TwoPhaseWs &ws, hipStream_t s, const Parsed
         slot_sorted = nb < W3_SLOT_SORTED_MAX_BLOCKS || (ws.variant & W3_VAR_SLOT_SORTED);
         bool two_passes = false;
         for (int l = 0; l < sa.n_leaves; l++) { slot_sorted &= sa.leaf[l].log_cells <= 16u; two_passes |= sa.leaf[l].log_cells > 8u; }
-        const size_t key_bytes = (size_t)sa.n_leaves * 2 * n * 8, hist_bytes = (size_t)sa.n_leaves * nb * 512 * 4;
+        const size_t key_bytes = (size_t)sa.n_leaves * 2 * n * 8, hist_bytes = (size_t)sa.n_leaves * nb * (512 + 1024) * 4;   // (digit counts + fine-bin prefixes)
         if (slot_sorted && ws.slot_keys_cap < 2 * key_bytes + hist_bytes + 64) {
             size_t free_b = 0, total_b = 0;
             if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); err = "hipMemGetInfo failed"; return W3_E_HIP; }
@@ -586,6 +586,7 @@ static inline int twophase_predict_b(TwoPhaseWs &ws, hipStream_t s, const Parsed
             s2.in = d_in; s2.n = n; s2.block_size = (uint32_t)block_size; s2.nblocks = nb;
             s2.keys_a = (uint64_t *)ws.slot_keys; s2.keys_b = (uint64_t *)((uint8_t *)ws.slot_keys + key_bytes);
             s2.hist = (uint32_t *)((uint8_t *)ws.slot_keys + 2 * key_bytes);
+            s2.pre2 = s2.hist + (size_t)sa.n_leaves * nb * 512;
             if ((rc = tp_ensure(ws.dummy, ws.dummy_cap, 2048, err))) return rc;
             s2.st = ws.st; s2.n_leaves = sa.n_leaves; s2.fault = ws.order_fault; s2.dummy = (uint8_t *)ws.dummy;
             for (int l = 0; l < sa.n_leaves; l++) s2.leaf[l] = sa.leaf[l];
@@ -598,12 +599,14 @@ static inline int twophase_predict_b(TwoPhaseWs &ws, hipStream_t s, const Parsed
             s2.jobs_per_block = 0;
             for (int l = 0; l < sa.n_leaves; l++) {
                 const uint32_t cells = 1u << sa.leaf[l].log_cells;
-                // wavefronts per (block, leaf): 4.  Measured at enwik8 size, four 2^14-cell leaves (tools/r3_sl2.sh; replay kernel, with / without
-                // its probability stores): 1 wavefront 30.1 / 13.7 ms (2,048 streams live: the 8-byte stores reach HBM as partial writes),
-                // 4 wavefronts 25.4 / 22.2, 16 wavefronts 42.2 / 41.0 (the stores merge in the Infinity Cache, but a job of 128 events per
-                // lane no longer covers its own start-up: job fetch, binary search, first chunk).  W3_OPT_TUNE bits 9 / 10: 16 / 1.
+                // wavefronts per (block, leaf): 4 (four fine bins per lane).  Measured at enwik8 size, four 2^14-cell leaves (tools/r3_sl2.sh; replay kernel,
+                // with / without its probability stores): 1 wavefront 36.3 / 13.7 ms (2,048 streams live: the 8-byte stores reach HBM as partial
+                // writes), 4 wavefronts 25.8 / 22.4, 16 wavefronts 41.8 / 41.2 — there the stores merge in the Infinity Cache and cost nothing, but a
+                // lane owns only 16 Cells and the wavefront runs as long as its busiest lane (hashed text contexts are very unevenly used: 6.6 us per
+                // event round against 2.2 with 256 Cells per lane); whether the ranges come from a binary search or from this prefix table made no
+                // difference.  W3_OPT_TUNE bits 9 / 10: 16 / 1.
                 const uint32_t wcap = (ws.tune & 1024u) ? 1u : (ws.tune & 512u) ? 16u : 4u;
-                s2.leaf_w[l] = std::min<uint32_t>(wcap, std::max<uint32_t>(1u, cells / 64u));
+                s2.leaf_w[l] = std::min<uint32_t>(wcap, std::max<uint32_t>(1u, std::min<uint32_t>(cells, 1024u) / 64u));
                 s2.jobs_per_block += s2.leaf_w[l];
             }
             s2.dbg = (ws.tune >> 8) & 1u;   // (W3_OPT_TUNE bit 8: timing experiment, results wrong)
