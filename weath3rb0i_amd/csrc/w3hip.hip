@@ -1649,6 +1649,7 @@ extern "C" int w3_predict_blocks(w3_ctx *ctx, const w3_model_spec *spec, const u
     ENSURE(ctx, ctx->io_in, n);
     HIPCHK(ctx, hipMemcpyAsync(ctx->io_in.p, in, n, hipMemcpyHostToDevice, s));
     const uint16_t *d_p = nullptr;
+    { JobRef J0 = jobref(ctx, 0); if ((rc = attach_aux_streams(ctx, J0, 0))) return rc; }
     rc = twophase_predict(ctx->tp, s, ps, (const uint8_t *)ctx->io_in.p, n, block_size, nb, ps.n_apm == 0, &d_p, nullptr, &ctx->timing, ctx->err);
     if (rc) return rc;
     if ((rc = twophase_apm(ctx->tp, s, ps, (const uint8_t *)ctx->io_in.p, n, block_size, nb, nullptr, &ctx->timing, ctx->err))) return rc;
