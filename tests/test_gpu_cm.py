@@ -97,6 +97,11 @@ def check(ctx, oracle, name, data, bs, decode=True):
             assert ctx.decode_blocks(dev(), out, lens, bs, len(data)).tobytes() == bytes(data), name + " (lane-per-block decoder)"
         finally:
             ctx.set_variant()
+        ctx.set_tune(16384)              # k_decode_spec with two bits per speculated group (the form of large batches)
+        try:
+            assert ctx.decode_blocks(dev(), out, lens, bs, len(data)).tobytes() == bytes(data), name + " (k_decode_spec, two-bit groups)"
+        finally:
+            ctx.set_tune(0)
     return out, lens
 
 

@@ -121,6 +121,12 @@ def decode_both(ctx, model, out, lens, bs, n):
     finally:
         ctx.set_variant()
     assert a == b, "k_decode_spec and the lane-per-block decoder disagree"
+    ctx.set_tune(16384)   # k_decode_spec with two bits per speculated group (four lanes per block: the form of large batches)
+    try:
+        c = ctx.decode_blocks(model, out, lens, bs, n).tobytes()
+    finally:
+        ctx.set_tune(0)
+    assert a == c, "k_decode_spec: the two-bit groups and the nibble groups disagree"
     return np.frombuffer(a, dtype=np.uint8)
 
 

@@ -35,8 +35,12 @@ __device__ __forceinline__ uint32_t pl_ld32(const uint32_t *p) { return __hip_at
 __device__ __forceinline__ void pl_st32(uint32_t *p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 __device__ __forceinline__ void pl_st16(uint16_t *p, uint16_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 
-template <int NL, int NA>
+// D = bits per speculated group: 4 (the nibble, 16 lanes per block: the shipped form) or 2 (half a nibble, 4 lanes per block, 16 blocks per
+// wavefront: 6 instead of 15 speculative look-ups per nibble and leaf, but four round trips per nibble instead of two — measured, no gain:
+// see decode_group_bits in w3hip.hip; a tested variant, W3_OPT_TUNE bit 14).
+template <int NL, int NA, int D>
 __global__ void __launch_bounds__(64) k_decode_spec(CmArgs a) {
+    constexpr uint32_t LPB = 1u << D, BPW = 64u / LPB;        // lanes per block, blocks per wavefront
     __shared__ int16_t s_str[NA > 0 ? 4096 : 1];
     if (NA > 0) for (uint32_t i = threadIdx.x; i < 4096u; i += 64u) s_str[i] = a.stretch[i];
     __shared__ LeafParam s_leaf[W3_MAX_LEAVES];
@@ -48,8 +52,8 @@ __global__ void __launch_bounds__(64) k_decode_spec(CmArgs a) {
     stage_leaves(s_leaf, a.g);   // (also the barrier for the tables above)
     const GenericArgs &g = a.g;
     const LeafParam *lp = s_leaf;
-    const uint32_t lane = threadIdx.x & 63u, r = lane & 15u, grp = lane >> 4;
-    const uint32_t bl = blockIdx.x * 4u + grp;               // block of this 16-lane row inside the batch
+    const uint32_t lane = threadIdx.x & 63u, r = lane & (LPB - 1u), grp = lane / LPB;
+    const uint32_t bl = blockIdx.x * BPW + grp;              // block of this row of LPB lanes inside the batch
     const bool live = bl < g.n_lanes;
     const uint32_t blc = live ? bl : g.n_lanes - 1u;
     const uint32_t b = g.first_block + blc;
@@ -57,21 +61,21 @@ __global__ void __launch_bounds__(64) k_decode_spec(CmArgs a) {
     uint32_t len = (uint32_t)((g.n - off) < g.block_size ? (g.n - off) : g.block_size);
     if (!live) len = 0u;
     uint8_t *blk_tbl = g.tables + (uint64_t)blc * g.lane_stride;
-    // this lane's node of the nibble tree
-    const uint32_t rr = r < 15u ? r : 14u;                   // (lane 15 shadows lane 14 and never updates anything)
+    // this lane's node of the group's tree
+    const uint32_t rr = r < LPB - 1u ? r : LPB - 2u;         // (the last lane of a row shadows its neighbour and never updates anything)
     const uint32_t k = 31u - (uint32_t)__builtin_clz(rr + 1u), x = rr + 1u - (1u << k);
-    const bool node = r < 15u;
-    const uint32_t row0 = lane & 48u;
-    bool fence_each = false;
+    const bool node = r < LPB - 1u;
+    const uint32_t row0 = lane & ~(LPB - 1u);
+    bool fence_each = false;   // (D = 2: consecutive groups differ in t mod 4, so even alignment 2 never reads what the group before stored)
 #pragma unroll
-    for (int l = 0; l < NL; l++) fence_each |= !lp[l].frozen && lp[l].align < 3;
+    for (int l = 0; l < NL; l++) fence_each |= D == 4 && !lp[l].frozen && lp[l].align < 3;
     Decoder dec;
     dec.init(g.cin + g.coffs[b], live ? g.clens[b] : 0u);
 
     uint64_t hist64 = 0; uint32_t t = 0, c0 = 1u, c1 = 0u;
     HuffState hs;
     for (uint32_t i = 0; i < len; i++) {
-        for (int half = 0; half < 2; half++) {
+        for (int gi = 0; gi < 8 / D; gi++) {
             // ---- the node's prediction: contexts, Counters, mix, APM chain ----
             const uint64_t hist_n = (hist64 << k) | x;
             const uint32_t t_n = t + k;
@@ -93,8 +97,11 @@ __global__ void __launch_bounds__(64) k_decode_spec(CmArgs a) {
                         uint32_t idx = ctx[l];
                         if (lp[l].hist <= W3_HIST_RAW && lp[l].align == 3u && lp[l].bits >= 6u) {
                             const uint32_t H = lp[l].bits - 3u;
-                            const uint32_t gq = (uint32_t)hist64 & ((1u << (H - 3u)) - 1u), v = (uint32_t)(hist64 >> (H - 3u)) & ((8u >> k) - 1u);
-                            idx = (((((t >> 2) & 1u) << (H - 3u)) | gq) << 5) | (k << 3) | (v << k) | x;
+                            // (a group may start inside the nibble, D = 2: tb bits of it are decoded already)
+                            const uint32_t tb = t & 3u, kn = tb + k, xn = (((uint32_t)hist64 & ((1u << tb) - 1u)) << k) | x;
+                            const uint64_t hn = hist64 >> tb;   // the history at the nibble's start
+                            const uint32_t gq = (uint32_t)hn & ((1u << (H - 3u)) - 1u), v = (uint32_t)(hn >> (H - 3u)) & ((8u >> kn) - 1u);
+                            idx = (((((t >> 2) & 1u) << (H - 3u)) | gq) << 5) | (kn << 3) | (v << kn) | xn;
                         }
                         slot[l] = tbl + idx; val[l] = pl_ld32(slot[l]);
                     }
@@ -139,7 +146,7 @@ __global__ void __launch_bounds__(64) k_decode_spec(CmArgs a) {
             uint32_t xk = 0u, mybit = 0u;
             bool on = false;
 #pragma unroll
-            for (uint32_t kk = 0; kk < 4u; kk++) {
+            for (uint32_t kk = 0; kk < (uint32_t)D; kk++) {
                 const uint32_t src = row0 | ((1u << kk) - 1u + xk);
                 const uint32_t psel = (uint32_t)__shfl((int)p, (int)src, 64);
                 const uint32_t bit = dec.decode(psel);
@@ -180,9 +187,9 @@ __global__ void __launch_bounds__(64) k_decode_spec(CmArgs a) {
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                 __builtin_amdgcn_s_waitcnt(0);
             }
-            hist64 = (hist64 << 4) | xk;
-            t += 4u;
-            c0 = (c0 << 4) | xk;
+            hist64 = (hist64 << D) | xk;
+            t += (uint32_t)D;
+            c0 = (c0 << D) | xk;
         }
         const uint32_t byte = c0 & 0xFFu;
         c1 = byte; c0 = 1u;
@@ -202,21 +209,32 @@ static inline bool decode_spec_covers(const CmArgs &ca) {
     return true;
 }
 
-template <int NL>
+template <int NL, int D>
 static inline void launch_decode_spec_na(const CmArgs &ca, uint32_t cnt, hipStream_t s) {
-    const dim3 grid((cnt + 3u) / 4u), blk(64);
+    constexpr uint32_t BPW = 64u >> D;
+    const dim3 grid((cnt + BPW - 1u) / BPW), blk(64);
     switch (ca.n_apm) {
-    case 0: hipLaunchKernelGGL((k_decode_spec<NL, 0>), grid, blk, 0, s, ca); break;
-    case 1: hipLaunchKernelGGL((k_decode_spec<NL, 1>), grid, blk, 0, s, ca); break;
-    default: hipLaunchKernelGGL((k_decode_spec<NL, 2>), grid, blk, 0, s, ca); break;
+    case 0: hipLaunchKernelGGL((k_decode_spec<NL, 0, D>), grid, blk, 0, s, ca); break;
+    case 1: hipLaunchKernelGGL((k_decode_spec<NL, 1, D>), grid, blk, 0, s, ca); break;
+    default: hipLaunchKernelGGL((k_decode_spec<NL, 2, D>), grid, blk, 0, s, ca); break;
     }
 }
-static inline void launch_decode_spec(const CmArgs &ca, uint32_t cnt, hipStream_t s) {
+// bits_per_group: 4 = the nibble (small batches: latency), 2 = half a nibble (large batches: HBM traffic)
+static inline void launch_decode_spec(const CmArgs &ca, uint32_t cnt, hipStream_t s, int bits_per_group) {
+    if (bits_per_group == 2) {
+        switch (ca.g.n_leaves) {
+        case 1: launch_decode_spec_na<1, 2>(ca, cnt, s); break;
+        case 2: launch_decode_spec_na<2, 2>(ca, cnt, s); break;
+        case 3: launch_decode_spec_na<3, 2>(ca, cnt, s); break;
+        default: launch_decode_spec_na<4, 2>(ca, cnt, s); break;
+        }
+        return;
+    }
     switch (ca.g.n_leaves) {
-    case 1: launch_decode_spec_na<1>(ca, cnt, s); break;
-    case 2: launch_decode_spec_na<2>(ca, cnt, s); break;
-    case 3: launch_decode_spec_na<3>(ca, cnt, s); break;
-    default: launch_decode_spec_na<4>(ca, cnt, s); break;
+    case 1: launch_decode_spec_na<1, 4>(ca, cnt, s); break;
+    case 2: launch_decode_spec_na<2, 4>(ca, cnt, s); break;
+    case 3: launch_decode_spec_na<3, 4>(ca, cnt, s); break;
+    default: launch_decode_spec_na<4, 4>(ca, cnt, s); break;
     }
 }
 

@@ -430,6 +430,15 @@ static int prepare_achash_luts(w3_ctx *ctx, hipStream_t s, GenericArgs &ga) {
     return W3_OK;
 }
 
+// k_decode_spec's group: the whole nibble.  Half a nibble (W3_OPT_TUNE bit 14: four lanes per block, 6 instead of 15 speculative look-ups per
+// nibble and leaf) was measured for the large batches, which are bound by those look-ups' HBM traffic — order012apm 736 -> 758 MiB/s at 1e9 B,
+// but order012 856 -> 778, Order0 3,906 -> 3,366, main.rs default 1,585 -> 1,417, and 189 -> 104 MiB/s at 1e8 B: four round trips per nibble
+// instead of two, and a quarter of the wavefronts to hide them (profiles/r3_decode_spec/).  Kept as a tested variant.
+static int decode_group_bits(const w3_ctx *ctx, uint32_t blocks_in_batch) {
+    (void)blocks_in_batch;
+    return (ctx->tp.tune & 16384u) ? 2 : 4;
+}
+
 static int generic_encode(w3_ctx *ctx, hipStream_t s, const ParsedSpec &ps, const uint8_t *d_in, size_t n, size_t block_size,
                           uint32_t nb, uint32_t stripe_cap, uint32_t *d_lens) {
     GenericArgs ga;
@@ -488,7 +497,7 @@ static int generic_decode(w3_ctx *ctx, hipStream_t s, const ParsedSpec &ps, cons
             memset(&ca, 0, sizeof ca);
             ca.g = ga;
             if (decode_spec_covers(ca) && !(ctx->tp.variant & W3_VAR_DECODE_LANE)) {
-                launch_decode_spec(ca, cnt, s);
+                launch_decode_spec(ca, cnt, s, decode_group_bits(ctx, cnt));
                 HIPCHK(ctx, hipGetLastError());
                 continue;
             }
@@ -566,7 +575,7 @@ static int cm_run(w3_ctx *ctx, hipStream_t s, CmArgs &ca, uint64_t lane_stride, 
         bool has_slot = false;
         for (int l = 0; l < ca.g.n_leaves; l++) has_slot |= ca.g.leaf[l].kind == 1;
         const dim3 grid((cnt + 63) / 64), blk(64);
-        if (DECODE && decode_spec_covers(ca) && !(ctx->tp.variant & W3_VAR_DECODE_LANE)) launch_decode_spec(ca, cnt, s);   // (w3_decode_spec.h)
+        if (DECODE && decode_spec_covers(ca) && !(ctx->tp.variant & W3_VAR_DECODE_LANE)) launch_decode_spec(ca, cnt, s, decode_group_bits(ctx, cnt));   // (w3_decode_spec.h)
         else if (!has_slot && ca.g.n_leaves <= 4) {   // Counter leaves + APM chain: all Counter loads of a step in flight together
             switch (ca.g.n_leaves) {
             case 1: hipLaunchKernelGGL((k_cm_nl<DECODE, 1>), grid, blk, 0, s, ca); break;
