@@ -24,6 +24,9 @@
 namespace w3 {
 
 #define W3_X5_CH 2                    // input bytes per hand-off chunk
+#ifndef W3_X5_NB1
+#define W3_X5_NB1 8u                  // chunk buffers the M-wave of a one-stream coder keeps in flight
+#endif
 #define W3_X5_RING 6                  // ring depth in input bytes = one revolution of the asm loops (3 chunks)
 
 // operands of ring byte K -> v[B .. B+30]; %[opl] = this lane's operand address (constant: the ring never moves)
@@ -252,7 +255,7 @@ __global__ void __launch_bounds__(L > 1 ? 256 : 192) k_coder_x5(Coder3Args a) {
             }
             lds_store_u32(m_prod, min(i + CH, maxlen));   // after the operands: the LDS executes one wave's operations in order
         };
-        constexpr uint32_t NB = L == 1 ? 8u : L == 2 ? 6u : 4u;   // chunk buffers in flight per wave
+        constexpr uint32_t NB = L == 1 ? W3_X5_NB1 : L == 2 ? 6u : 4u;   // chunk buffers in flight per wave
         constexpr uint32_t ST = NM * CH;                          // bytes between two chunks of one M-wave
         const uint32_t i0 = wave * CH;
         Buf bf[NB];
