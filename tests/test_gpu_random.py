@@ -9,6 +9,10 @@ from tests.test_gpu_parity import check_blocks, ctx, decode_both, pair  # noqa: 
 
 pytestmark = pytest.mark.gpu
 
+import os
+
+SOAK = int(os.environ.get("W3_RANDOM_SOAK", "1"))   # W3_RANDOM_SOAK=8: eight times as many cases (a one-off soak, not the driver's run)
+
 MODELS = ["order0", "order1", "order2", "best012", "best_ac_wide", "main_default", "ordern_5_3", "best_right"]
 
 
@@ -25,7 +29,7 @@ def make_data(rng, kind, n):
     return rng.integers(0, 256, n, dtype=np.uint8).tobytes()   # incompressible: every group tiny
 
 
-@pytest.mark.parametrize("case", range(36))
+@pytest.mark.parametrize("case", range(36 * SOAK))
 def test_random_shapes(ctx, oracle, case):  # noqa: F811
     rng = np.random.default_rng(1000 + case)
     name = MODELS[case % len(MODELS)]
@@ -42,7 +46,7 @@ def test_random_shapes(ctx, oracle, case):  # noqa: F811
 CM_MODELS = ["slot1", "slot2", "slot_mix", "o012_apm", "apm_chain4", "full_cm_small_tables", "apm1_order0_r3", "slot7"]
 
 
-@pytest.mark.parametrize("case", range(16))
+@pytest.mark.parametrize("case", range(16 * SOAK))
 def test_random_shapes_cm(ctx, oracle, case):  # noqa: F811
     """The same sweep over the CM models: slot-state leaves on both forms (sorted replay and k_slot), APM chains, the two-phase encoder
     against k_cm, both decoders (tests/test_gpu_cm.py::check does all of that per case)."""
