@@ -38,11 +38,22 @@ __device__ __forceinline__ void pl_st16(uint16_t *p, uint16_t v) { __hip_atomic_
 // D = bits per speculated group: 4 (the nibble, 16 lanes per block: the shipped form) or 2 (half a nibble, 4 lanes per block, 16 blocks per
 // wavefront: 6 instead of 15 speculative look-ups per nibble and leaf, but four round trips per nibble instead of two — measured, no gain:
 // see decode_group_bits in w3hip.hip; a tested variant, W3_OPT_TUNE bit 14).
-template <int NL, int NA, int D>
+// HS = the spec has slot-state leaves (build-defined CM leaf over hashmap.rs / state_table: DESIGN.md 2.4): such a leaf is nibble-major by nature
+// — one Cell per nibble (hashslots.md:3-4), the 15 states of the nibble's tree in one slot — so lane 0 of the row does the Cell's tag match /
+// eviction (slot_select of w3_cm.h on the byte-exact 96-byte Cell, hashmap.rs:42-71) when the nibble starts, every node lane reads its 12-bit
+// state (hashmap.rs:86-97) and looks its probability up in the state table (staged in LDS), and lane 0 walks the four path states on
+// (hashmap.rs:99-112: the packed states share bytes, so one lane writes them one after the other).  The Cell is staged in LDS for the
+// nibble (six 16-byte loads by six lanes, w3_cm.h's cmc_* helpers on the copy, six stores back).  D = 4 only.
+template <int NL, int NA, int D, bool HS = false>
 __global__ void __launch_bounds__(64) k_decode_spec(CmArgs a) {
     constexpr uint32_t LPB = 1u << D, BPW = 64u / LPB;        // lanes per block, blocks per wavefront
+    static_assert(!HS || D == 4, "slot-state leaves: one Cell per nibble");
     __shared__ int16_t s_str[NA > 0 ? 4096 : 1];
     if (NA > 0) for (uint32_t i = threadIdx.x; i < 4096u; i += 64u) s_str[i] = a.stretch[i];
+    __shared__ uint2 s_st[HS ? kStSize : 1];
+    if (HS) for (uint32_t i = threadIdx.x; i < (uint32_t)kStSize; i += 64u) s_st[i] = a.st[i];
+    // the nibble's Cell of every (row, slot leaf), staged in w3_cm.h's layout: "lane" v = 8 * row + leaf of [chunk][64] x 16 B
+    __shared__ cm_u32x4 s_cell[HS ? 6 : 1][HS ? 64 : 1];
     __shared__ LeafParam s_leaf[W3_MAX_LEAVES];
     __shared__ ApmParam s_apm[W3_MAX_APM];
     if (threadIdx.x == 0) {
@@ -68,7 +79,8 @@ __global__ void __launch_bounds__(64) k_decode_spec(CmArgs a) {
     const uint32_t row0 = lane & ~(LPB - 1u);
     bool fence_each = false;   // (D = 2: consecutive groups differ in t mod 4, so even alignment 2 never reads what the group before stored)
 #pragma unroll
-    for (int l = 0; l < NL; l++) fence_each |= D == 4 && !lp[l].frozen && lp[l].align < 3;
+    for (int l = 0; l < NL; l++) fence_each |= D == 4 && lp[l].kind == 0 && !lp[l].frozen && lp[l].align < 3;
+    if (HS) fence_each = true;   // (two nibbles in a row may hash to one Cell: what the first stored must have landed)
     Decoder dec;
     dec.init(g.cin + g.coffs[b], live ? g.clens[b] : 0u);
 
@@ -81,10 +93,41 @@ __global__ void __launch_bounds__(64) k_decode_spec(CmArgs a) {
             const uint32_t t_n = t + k;
             uint32_t *slot[NL]; uint32_t val[NL], ctx[NL];
             uint32_t p = 32768u, best = 0u;
+            uint8_t *cellp[HS ? NL : 1]; uint32_t sid[HS ? NL : 1];
+            if (HS) {
+                // the nibble's Cell of every slot-state leaf: lanes 0..5 of the row fetch its six 16-byte chunks into LDS, lane 0 selects the slot
+                // there (and evicts on a miss: cmc_select of w3_cm.h, hashmap.rs:42-71), the row learns the slot's id
+                const uint32_t tb8 = t & 7u;
+                const uint64_t hb = hist64 >> tb8;   // the completed bytes
+                uint32_t tagv[NL];
+#pragma unroll
+                for (int l = 0; l < NL; l++) {
+                    cellp[l] = nullptr; sid[l] = 0u; tagv[l] = 0u;
+                    if (lp[l].kind == 1) {
+                        const uint64_t h = slot_hash(lp[l].order, hb, tb8 != 0u, (uint32_t)hist64 & 15u);
+                        cellp[l] = blk_tbl + lp[l].tbl_off + (h >> (64u - lp[l].log_cells)) * 96ull;
+                        tagv[l] = (uint32_t)h & 0xFFFu;
+                        if (r < 6u) s_cell[r][grp * 8u + (uint32_t)l] = *reinterpret_cast<const cm_u32x4 *>(cellp[l] + 16u * r);
+                    }
+                }
+                __asm__ volatile("" ::: "memory");
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int l = 0; l < NL; l++)
+                    if (lp[l].kind == 1 && r == 0u) sid[l] = cmc_select((cm_lds_u32 *)&s_cell[0][grp * 8u + (uint32_t)l], tagv[l], s_st);
+                __asm__ volatile("" ::: "memory");
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int l = 0; l < NL; l++)
+                    if (lp[l].kind == 1) sid[l] = (uint32_t)__shfl((int)sid[l], (int)row0, 64);
+            }
 #pragma unroll
             for (int l = 0; l < NL; l++) {
                 slot[l] = nullptr; val[l] = 0u; ctx[l] = 0u;
-                if (!lp[l].frozen) {
+                if (HS && lp[l].kind == 1) {
+                    CmCellRef cr; uint32_t cv;   // this node's 12-bit state from the staged Cell (Slot::get_nib path, hashmap.rs:114-121)
+                    val[l] = cmc_state((cm_lds_u32 *)&s_cell[0][grp * 8u + (uint32_t)l], slot_idx(sid[l], k, x), cr, cv);
+                } else if (lp[l].kind == 0 && !lp[l].frozen) {
                     ctx[l] = leaf_ctx(lp[l], hist_n, t_n, hs, g.huff);
                     uint32_t *tbl = reinterpret_cast<uint32_t *>(blk_tbl + lp[l].tbl_off);
                     if (!lp[l].use_hash) {
@@ -119,11 +162,14 @@ __global__ void __launch_bounds__(64) k_decode_spec(CmArgs a) {
                     }
                 }
             }
+            bool first_leaf = true;
 #pragma unroll
             for (int l = 0; l < NL; l++) {
-                const uint32_t pl = lp[l].frozen ? 32768u : counter_p_packed(val[l]);
+                if (lp[l].kind > 1) continue;   // (NL is an upper bound: unused entries)
+                const uint32_t pl = (HS && lp[l].kind == 1) ? (s_st[val[l]].x & 0xFFFFu)      // StateTable::p, state_table/mod.rs:47-49
+                                                            : lp[l].frozen ? 32768u : counter_p_packed(val[l]);
                 const uint32_t d = opinion_dist(pl);
-                if (l == 0 || d > best) { p = pl; best = d; }
+                if (first_leaf || d > best) { p = pl; best = d; first_leaf = false; }
             }
             const uint32_t c0_n = (c0 << k) | x;
             uint16_t *aslot[NA > 0 ? NA : 1]; int tv[NA > 0 ? NA : 1];
@@ -154,10 +200,36 @@ __global__ void __launch_bounds__(64) k_decode_spec(CmArgs a) {
                 xk = (xk << 1) | bit;
             }
             // ---- the path's nodes adapt (Counter::update, counter.rs:20-26; the APM entry nearer to the looked-up position) ----
+            if (HS) {
+                // slot-state leaves: lane 0 of the row walks the four path states on in the staged Cell (the packed states share bytes: one lane,
+                // one after the other), then lanes 0..5 write the Cell back
+                __asm__ volatile("" ::: "memory");
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int l = 0; l < NL; l++) {
+                    if (lp[l].kind != 1 || r != 0u) continue;
+                    cm_lds_u32 *cbv = (cm_lds_u32 *)&s_cell[0][grp * 8u + (uint32_t)l];
+#pragma unroll
+                    for (uint32_t kk = 0; kk < 4u; kk++) {
+                        const uint32_t pre = xk >> (4u - kk);                                   // the nibble's first kk bits
+                        const uint32_t bitk = (xk >> (3u - kk)) & 1u;
+                        CmCellRef cr; uint32_t cv;
+                        const uint32_t idx = slot_idx(sid[l], kk, pre);
+                        const uint32_t stv = cmc_state(cbv, idx, cr, cv);
+                        cmc_set_state(cbv, idx, cr, cv, bitk ? (s_st[stv].y & 0xFFFFu) : (s_st[stv].x >> 16));
+                        __asm__ volatile("" ::: "memory");
+                    }
+                }
+                __asm__ volatile("" ::: "memory");
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int l = 0; l < NL; l++)
+                    if (lp[l].kind == 1 && r < 6u) *reinterpret_cast<cm_u32x4 *>(cellp[l] + 16u * r) = s_cell[r][grp * 8u + (uint32_t)l];
+            }
             if (on) {
 #pragma unroll
                 for (int l = 0; l < NL; l++) {
-                    if (lp[l].frozen) continue;
+                    if (lp[l].kind != 0 || lp[l].frozen) continue;
                     const uint32_t nv = counter_update_packed(val[l], mybit);
                     if (slot[l]) { if (lp[l].use_hash) ds_st32(slot[l], nv); else pl_st32(slot[l], nv); }
                     else {   // claim a slot of the exact map: another path node of this nibble may be after the same empty one
@@ -199,14 +271,30 @@ __global__ void __launch_bounds__(64) k_decode_spec(CmArgs a) {
 }
 
 // what k_decode_spec covers (see the header comment)
+static inline bool decode_spec_has_slot(const CmArgs &ca) {
+    for (int l = 0; l < ca.g.n_leaves; l++)
+        if (ca.g.leaf[l].kind == 1) return true;
+    return false;
+}
 static inline bool decode_spec_covers(const CmArgs &ca) {
-    if (ca.g.n_leaves < 1 || ca.g.n_leaves > 4 || ca.n_apm > 2) return false;
+    if (ca.g.n_leaves < 1 || ca.g.n_leaves > 8 || ca.n_apm > 2) return false;
     for (int l = 0; l < ca.g.n_leaves; l++) {
         const LeafParam &lp = ca.g.leaf[l];
-        if (lp.kind != 0) return false;
-        if (!lp.frozen && lp.align < 2) return false;
+        if (lp.kind == 0 && !lp.frozen && lp.align < 2) return false;
     }
     return true;
+}
+
+// up to eight leaves (the full CM has seven) and slot-state leaves: one instantiation with NL = 8, unused entries marked kind 2
+template <bool HS>
+static inline void launch_decode_spec_8(CmArgs ca, uint32_t cnt, hipStream_t s) {
+    for (int l = ca.g.n_leaves; l < 8; l++) { ca.g.leaf[l] = LeafParam{}; ca.g.leaf[l].kind = 2; ca.g.leaf[l].frozen = 1; }
+    const dim3 grid((cnt + 3u) / 4u), blk(64);
+    switch (ca.n_apm) {
+    case 0: hipLaunchKernelGGL((k_decode_spec<8, 0, 4, HS>), grid, blk, 0, s, ca); break;
+    case 1: hipLaunchKernelGGL((k_decode_spec<8, 1, 4, HS>), grid, blk, 0, s, ca); break;
+    default: hipLaunchKernelGGL((k_decode_spec<8, 2, 4, HS>), grid, blk, 0, s, ca); break;
+    }
 }
 
 template <int NL, int D>
@@ -221,6 +309,8 @@ static inline void launch_decode_spec_na(const CmArgs &ca, uint32_t cnt, hipStre
 }
 // bits_per_group: 4 = the nibble (small batches: latency), 2 = half a nibble (large batches: HBM traffic)
 static inline void launch_decode_spec(const CmArgs &ca, uint32_t cnt, hipStream_t s, int bits_per_group) {
+    if (decode_spec_has_slot(ca)) { launch_decode_spec_8<true>(ca, cnt, s); return; }
+    if (ca.g.n_leaves > 4) { launch_decode_spec_8<false>(ca, cnt, s); return; }
     if (bits_per_group == 2) {
         switch (ca.g.n_leaves) {
         case 1: launch_decode_spec_na<1, 2>(ca, cnt, s); break;
