@@ -15,9 +15,9 @@
 //   compare-and-swap (two path nodes may meet one empty slot).
 // A wavefront holds four blocks: 3,815 wavefronts at enwik9 size instead of 239, and the chip hides the round trips it still has.
 // Model tables: the lane-per-block decoder's layout (layout_generic / layout_cm), one region per block.
-// Covered: 1..4 Counter-table leaves of any history kind with alignment_bits >= 2 (FrozenModel leaves too), 0..2 APM stages.  Everything
-// else (alignment 0 / 1: the nibble's own updates feed its later contexts; slot-state leaves; longer chains) stays on the lane-per-block
-// kernels, which also remain the cross-check (W3_OPT_VARIANT bit 1024).
+// Covered: up to 8 leaves — Counter-table leaves of any history kind with alignment_bits >= 2 (FrozenModel leaves too), slot-state leaves (HS
+// below) — and 0..2 APM stages.  Everything else (alignment 0 / 1: the nibble's own updates feed its later contexts; longer chains) stays on
+// the lane-per-block kernels, which also remain the cross-check (W3_OPT_VARIANT bit 1024).
 #pragma once
 #include "w3_cm.h"
 
@@ -54,6 +54,7 @@ __global__ void __launch_bounds__(64) k_decode_spec(CmArgs a) {
     if (HS) for (uint32_t i = threadIdx.x; i < (uint32_t)kStSize; i += 64u) s_st[i] = a.st[i];
     // the nibble's Cell of every (row, slot leaf), staged in w3_cm.h's layout: "lane" v = 8 * row + leaf of [chunk][64] x 16 B
     __shared__ cm_u32x4 s_cell[HS ? 6 : 1][HS ? 64 : 1];
+    __shared__ uint32_t s_sid[HS ? 64 : 1];   // the selected slot of every staged Cell
     __shared__ LeafParam s_leaf[W3_MAX_LEAVES];
     __shared__ ApmParam s_apm[W3_MAX_APM];
     if (threadIdx.x == 0) {
@@ -81,6 +82,7 @@ __global__ void __launch_bounds__(64) k_decode_spec(CmArgs a) {
 #pragma unroll
     for (int l = 0; l < NL; l++) fence_each |= D == 4 && lp[l].kind == 0 && !lp[l].frozen && lp[l].align < 3;
     if (HS) fence_each = true;   // (two nibbles in a row may hash to one Cell: what the first stored must have landed)
+    const bool leader = HS && r < (uint32_t)NL && lp[r < (uint32_t)NL ? r : 0u].kind == 1;
     Decoder dec;
     dec.init(g.cin + g.coffs[b], live ? g.clens[b] : 0u);
 
@@ -99,27 +101,28 @@ __global__ void __launch_bounds__(64) k_decode_spec(CmArgs a) {
                 // there (and evicts on a miss: cmc_select of w3_cm.h, hashmap.rs:42-71), the row learns the slot's id
                 const uint32_t tb8 = t & 7u;
                 const uint64_t hb = hist64 >> tb8;   // the completed bytes
-                uint32_t tagv[NL];
 #pragma unroll
                 for (int l = 0; l < NL; l++) {
-                    cellp[l] = nullptr; sid[l] = 0u; tagv[l] = 0u;
+                    cellp[l] = nullptr; sid[l] = 0u;
                     if (lp[l].kind == 1) {
                         const uint64_t h = slot_hash(lp[l].order, hb, tb8 != 0u, (uint32_t)hist64 & 15u);
                         cellp[l] = blk_tbl + lp[l].tbl_off + (h >> (64u - lp[l].log_cells)) * 96ull;
-                        tagv[l] = (uint32_t)h & 0xFFFu;
                         if (r < 6u) s_cell[r][grp * 8u + (uint32_t)l] = *reinterpret_cast<const cm_u32x4 *>(cellp[l] + 16u * r);
                     }
                 }
                 __asm__ volatile("" ::: "memory");
                 __builtin_amdgcn_wave_barrier();
-#pragma unroll
-                for (int l = 0; l < NL; l++)
-                    if (lp[l].kind == 1 && r == 0u) sid[l] = cmc_select((cm_lds_u32 *)&s_cell[0][grp * 8u + (uint32_t)l], tagv[l], s_st);
+                // lane r of the row is the LEADER of leaf r: the slot leaves' selects run side by side (one code path, several lanes), not one
+                // after the other on lane 0
+                if (leader) {
+                    const uint64_t h = slot_hash(lp[r].order, hb, tb8 != 0u, (uint32_t)hist64 & 15u);
+                    s_sid[grp * 8u + r] = cmc_select((cm_lds_u32 *)&s_cell[0][grp * 8u + r], (uint32_t)h & 0xFFFu, s_st);
+                }
                 __asm__ volatile("" ::: "memory");
                 __builtin_amdgcn_wave_barrier();
 #pragma unroll
                 for (int l = 0; l < NL; l++)
-                    if (lp[l].kind == 1) sid[l] = (uint32_t)__shfl((int)sid[l], (int)row0, 64);
+                    if (lp[l].kind == 1) sid[l] = s_sid[grp * 8u + (uint32_t)l];
             }
 #pragma unroll
             for (int l = 0; l < NL; l++) {
@@ -201,20 +204,19 @@ __global__ void __launch_bounds__(64) k_decode_spec(CmArgs a) {
             }
             // ---- the path's nodes adapt (Counter::update, counter.rs:20-26; the APM entry nearer to the looked-up position) ----
             if (HS) {
-                // slot-state leaves: lane 0 of the row walks the four path states on in the staged Cell (the packed states share bytes: one lane,
-                // one after the other), then lanes 0..5 write the Cell back
+                // slot-state leaves: each leaf's leader lane walks the four path states on in the staged Cell (the packed states share bytes: one
+                // lane per Cell, one state after the other), then lanes 0..5 write the Cell back
                 __asm__ volatile("" ::: "memory");
                 __builtin_amdgcn_wave_barrier();
-#pragma unroll
-                for (int l = 0; l < NL; l++) {
-                    if (lp[l].kind != 1 || r != 0u) continue;
-                    cm_lds_u32 *cbv = (cm_lds_u32 *)&s_cell[0][grp * 8u + (uint32_t)l];
+                if (leader) {   // (every slot leaf's leader at once)
+                    cm_lds_u32 *cbv = (cm_lds_u32 *)&s_cell[0][grp * 8u + r];
+                    const uint32_t my_sid = s_sid[grp * 8u + r];
 #pragma unroll
                     for (uint32_t kk = 0; kk < 4u; kk++) {
                         const uint32_t pre = xk >> (4u - kk);                                   // the nibble's first kk bits
                         const uint32_t bitk = (xk >> (3u - kk)) & 1u;
                         CmCellRef cr; uint32_t cv;
-                        const uint32_t idx = slot_idx(sid[l], kk, pre);
+                        const uint32_t idx = slot_idx(my_sid, kk, pre);
                         const uint32_t stv = cmc_state(cbv, idx, cr, cv);
                         cmc_set_state(cbv, idx, cr, cv, bitk ? (s_st[stv].y & 0xFFFFu) : (s_st[stv].x >> 16));
                         __asm__ volatile("" ::: "memory");
