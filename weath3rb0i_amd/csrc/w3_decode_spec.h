@@ -35,6 +35,39 @@ __device__ __forceinline__ uint32_t pl_ld32(const uint32_t *p) { return __hip_at
 __device__ __forceinline__ void pl_st32(uint32_t *p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 __device__ __forceinline__ void pl_st16(uint16_t *p, uint16_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 
+// The Counter look-up of one leaf of k_decode_spec's node (its own macro: the kernel issues these before it stages the slot leaves' Cells).
+// Direct tables are NIBBLE-MAJOR (this kernel's own layout; the table is scratch, zeroed per call): a raw-history context of alignment 3 is a
+// window of H = bits - 3 history bits plus the bit position.  For node (k, x) of a nibble that starts with history h the window is
+// [v : 3-k bits][g : H-3 bits][x : k bits], g = the low H-3 bits of h, v the 3-k bits above them — so the 32 Counters {(k, v, x)} of one
+// (half, g) are everything ANY nibble starting with those H-3 history bits can touch: ONE 128-byte line instead of 15 scattered words (the PMC
+// passes of the first version: 4.3 KB fetched per nibble and block, HBM-bound at 5 TB/s).  A group may start inside the nibble (D = 2: tb bits
+// of it are decoded already).  Exact maps {ctx + 1, counts}: found, or absent (the empty slot ends the probe; only a path node claims one).
+#define W3_DS_COUNTER_LOOKUP \
+                    ctx[l] = leaf_ctx(lp[l], hist_n, t_n, hs, g.huff); \
+                    uint32_t *tbl = reinterpret_cast<uint32_t *>(blk_tbl + lp[l].tbl_off); \
+                    if (!lp[l].use_hash) { \
+                        uint32_t idx = ctx[l]; \
+                        if (lp[l].hist <= W3_HIST_RAW && lp[l].align == 3u && lp[l].bits >= 6u) { \
+                            const uint32_t H = lp[l].bits - 3u; \
+                            const uint32_t tb = t & 3u, kn = tb + k, xn = (((uint32_t)hist64 & ((1u << tb) - 1u)) << k) | x; \
+                            const uint64_t hn = hist64 >> tb; \
+                            const uint32_t gq = (uint32_t)hn & ((1u << (H - 3u)) - 1u), v = (uint32_t)(hn >> (H - 3u)) & ((8u >> kn) - 1u); \
+                            idx = (((((t >> 2) & 1u) << (H - 3u)) | gq) << 5) | (kn << 3) | (v << kn) | xn; \
+                        } \
+                        slot[l] = tbl + idx; val[l] = pl_ld32(slot[l]); \
+                    } \
+                    else { \
+                        uint32_t h = (ctx[l] * 2654435761u) ^ (ctx[l] >> 15); \
+                        for (;;) { \
+                            h &= lp[l].hash_mask; \
+                            const uint64_t kv = ds_ld64(reinterpret_cast<const uint64_t *>(tbl + 2u * h)); \
+                            const uint32_t key = (uint32_t)kv; \
+                            if (key == ctx[l] + 1u) { slot[l] = tbl + 2u * h + 1u; val[l] = (uint32_t)(kv >> 32); break; } \
+                            if (key == 0u) break; \
+                            h++; \
+                        } \
+                    }
+
 // D = bits per speculated group: 4 (the nibble, 16 lanes per block: the shipped form) or 2 (half a nibble, 4 lanes per block, 16 blocks per
 // wavefront: 6 instead of 15 speculative look-ups per nibble and leaf, but four round trips per nibble instead of two — measured, no gain:
 // see decode_group_bits in w3hip.hip; a tested variant, W3_OPT_TUNE bit 14).
@@ -96,6 +129,7 @@ __global__ void __launch_bounds__(64) k_decode_spec(CmArgs a) {
             uint32_t *slot[NL]; uint32_t val[NL], ctx[NL];
             uint32_t p = 32768u, best = 0u;
             uint8_t *cellp[HS ? NL : 1]; uint32_t sid[HS ? NL : 1];
+            cm_u32x4 cq[HS ? NL : 1];
             if (HS) {
                 // the nibble's Cell of every slot-state leaf: lanes 0..5 of the row fetch its six 16-byte chunks into LDS, lane 0 selects the slot
                 // there (and evicts on a miss: cmc_select of w3_cm.h, hashmap.rs:42-71), the row learns the slot's id
@@ -107,9 +141,24 @@ __global__ void __launch_bounds__(64) k_decode_spec(CmArgs a) {
                     if (lp[l].kind == 1) {
                         const uint64_t h = slot_hash(lp[l].order, hb, tb8 != 0u, (uint32_t)hist64 & 15u);
                         cellp[l] = blk_tbl + lp[l].tbl_off + (h >> (64u - lp[l].log_cells)) * 96ull;
-                        if (r < 6u) s_cell[r][grp * 8u + (uint32_t)l] = *reinterpret_cast<const cm_u32x4 *>(cellp[l] + 16u * r);
+                        if (r < 6u) cq[l] = *reinterpret_cast<const cm_u32x4 *>(cellp[l] + 16u * r);   // (in flight beside the Counter look-ups below)
                     }
                 }
+            }
+            // ---- Counter-table leaves: contexts, look-ups ----
+#pragma unroll
+            for (int l = 0; l < NL; l++) {
+                slot[l] = nullptr; val[l] = 0u; ctx[l] = 0u;
+                if (lp[l].kind == 0 && !lp[l].frozen) {
+                    W3_DS_COUNTER_LOOKUP
+                }
+            }
+            if (HS) {
+                const uint32_t tb8 = t & 7u;
+                const uint64_t hb = hist64 >> tb8;
+#pragma unroll
+                for (int l = 0; l < NL; l++)
+                    if (lp[l].kind == 1 && r < 6u) s_cell[r][grp * 8u + (uint32_t)l] = cq[l];
                 __asm__ volatile("" ::: "memory");
                 __builtin_amdgcn_wave_barrier();
                 // lane r of the row is the LEADER of leaf r: the slot leaves' selects run side by side (one code path, several lanes), not one
@@ -124,46 +173,13 @@ __global__ void __launch_bounds__(64) k_decode_spec(CmArgs a) {
                 for (int l = 0; l < NL; l++)
                     if (lp[l].kind == 1) sid[l] = s_sid[grp * 8u + (uint32_t)l];
             }
+            if (HS) {
 #pragma unroll
-            for (int l = 0; l < NL; l++) {
-                slot[l] = nullptr; val[l] = 0u; ctx[l] = 0u;
-                if (HS && lp[l].kind == 1) {
-                    CmCellRef cr; uint32_t cv;   // this node's 12-bit state from the staged Cell (Slot::get_nib path, hashmap.rs:114-121)
-                    val[l] = cmc_state((cm_lds_u32 *)&s_cell[0][grp * 8u + (uint32_t)l], slot_idx(sid[l], k, x), cr, cv);
-                } else if (lp[l].kind == 0 && !lp[l].frozen) {
-                    ctx[l] = leaf_ctx(lp[l], hist_n, t_n, hs, g.huff);
-                    uint32_t *tbl = reinterpret_cast<uint32_t *>(blk_tbl + lp[l].tbl_off);
-                    if (!lp[l].use_hash) {
-                        // NIBBLE-MAJOR direct table (this kernel's own layout; the table is scratch, zeroed per call): a raw-history
-                        // context of alignment 3 is a window of H = bits - 3 history bits plus the bit position.  For node (k, x) of
-                        // a nibble that starts with history h the window is [v : 3-k bits][g : H-3 bits][x : k bits], g = the low H-3
-                        // bits of h, v the 3-k bits above them — so the 32 Counters {(k, v, x)} of one (half, g) are everything ANY
-                        // nibble starting with those H-3 history bits can touch: ONE 128-byte line instead of 15 scattered words
-                        // (the PMC passes of the first version: 4.3 KB fetched per nibble and block, HBM-bound at 5 TB/s).
-                        uint32_t idx = ctx[l];
-                        if (lp[l].hist <= W3_HIST_RAW && lp[l].align == 3u && lp[l].bits >= 6u) {
-                            const uint32_t H = lp[l].bits - 3u;
-                            // (a group may start inside the nibble, D = 2: tb bits of it are decoded already)
-                            const uint32_t tb = t & 3u, kn = tb + k, xn = (((uint32_t)hist64 & ((1u << tb) - 1u)) << k) | x;
-                            const uint64_t hn = hist64 >> tb;   // the history at the nibble's start
-                            const uint32_t gq = (uint32_t)hn & ((1u << (H - 3u)) - 1u), v = (uint32_t)(hn >> (H - 3u)) & ((8u >> kn) - 1u);
-                            idx = (((((t >> 2) & 1u) << (H - 3u)) | gq) << 5) | (kn << 3) | (v << kn) | xn;
-                        }
-                        slot[l] = tbl + idx; val[l] = pl_ld32(slot[l]);
+                for (int l = 0; l < NL; l++)
+                    if (lp[l].kind == 1) {
+                        CmCellRef cr; uint32_t cv;   // this node's 12-bit state from the staged Cell (Slot::get_nib path, hashmap.rs:114-121)
+                        val[l] = cmc_state((cm_lds_u32 *)&s_cell[0][grp * 8u + (uint32_t)l], slot_idx(sid[l], k, x), cr, cv);
                     }
-                    else {
-                        // exact map {ctx + 1, counts}: found, or absent (the empty slot ends the probe; only a path node claims one, below)
-                        uint32_t h = (ctx[l] * 2654435761u) ^ (ctx[l] >> 15);
-                        for (;;) {
-                            h &= lp[l].hash_mask;
-                            const uint64_t kv = ds_ld64(reinterpret_cast<const uint64_t *>(tbl + 2u * h));
-                            const uint32_t key = (uint32_t)kv;
-                            if (key == ctx[l] + 1u) { slot[l] = tbl + 2u * h + 1u; val[l] = (uint32_t)(kv >> 32); break; }
-                            if (key == 0u) break;
-                            h++;
-                        }
-                    }
-                }
             }
             bool first_leaf = true;
 #pragma unroll
