@@ -849,11 +849,17 @@ extern "C" int w3_encode_blocks_device(w3_ctx *ctx, const w3_model_spec *spec, c
 // or coder kernel — in the half-CU shapes (w3_predict.h, w3_coder5.h) that let the two share every CU.
 // ---------------------------------------------------------------------------
 // twophase_predict_b's choice for the slot-state leaves, as far as the spec and the shape decide it (w3_twophase.h)
-static bool slot_sorted_by_default(const ParsedSpec &ps, uint32_t nb, size_t block_size) {
+static bool slot_sorted_by_default(const ParsedSpec &ps, uint32_t nb, size_t block_size, size_t n) {
     if (nb >= W3_SLOT_SORTED_MAX_BLOCKS || block_size > (1ull << 31)) return false;
-    for (int l = 0; l < ps.n_leaves; l++)
-        if (ps.leaf[l].kind == W3_NODE_SLOT_STATE && ps.leaf[l].log_cells > 16) return false;
-    return true;
+    size_t n_slot = 0;
+    for (int l = 0; l < ps.n_leaves; l++) {
+        if (ps.leaf[l].kind != W3_NODE_SLOT_STATE) continue;
+        if (ps.leaf[l].log_cells > 16) return false;
+        n_slot++;
+    }
+    // (two jobs in flight hold two sets of event records, 32 bytes per input byte and leaf: beyond 48 GB a set the call stays synchronous —
+    // twophase_predict_b then still picks the replay if the records fit beside everything else, or k_slot)
+    return 32ull * n_slot * n <= (48ull << 30);
 }
 
 // How submitted calls of this spec and size are kept in flight (w3_encode_submit and w3_encode_max_in_flight must agree).
@@ -941,7 +947,7 @@ extern "C" int w3_encode_submit(w3_ctx *ctx, const w3_model_spec *spec, const ui
     const uint32_t nb = (uint32_t)((n + block_size - 1) / block_size);
     // Specs with slot-state leaves are pipelined when the leaves run as the sorted replay (w3_slot2.h: no hash maps sized from the memory
     // that happens to be free) — two jobs at most: a job's event records are 32 bytes per input byte and leaf.
-    const bool slot_async = ps.has_slot && slot_sorted_by_default(ps, nb, block_size) && !(ctx->tp.variant & (W3_VAR_SLOT_TABLE | W3_VAR_NO_LDS_ATOMICS)) && ctx->tp.lds_order != 0;
+    const bool slot_async = ps.has_slot && slot_sorted_by_default(ps, nb, block_size, n) && !(ctx->tp.variant & (W3_VAR_SLOT_TABLE | W3_VAR_NO_LDS_ATOMICS)) && ctx->tp.lds_order != 0;
     const PipelinePlan plan = pipeline_plan(ps, nb, ctx->tp.tune);
     const bool free_run = plan.free_run;
     const int depth = plan.depth;
