@@ -609,7 +609,9 @@ static inline int twophase_predict_b(TwoPhaseWs &ws, hipStream_t s, const Parsed
                 s2.leaf_w[l] = std::min<uint32_t>(wcap, std::max<uint32_t>(1u, std::min<uint32_t>(cells, 1024u) / 64u));
                 s2.jobs_per_block += s2.leaf_w[l];
             }
-            s2.dbg = (ws.tune >> 8) & 1u;   // (W3_OPT_TUNE bit 8: timing experiment, results wrong)
+#ifdef W3_TUNING
+            s2.dbg = (ws.tune >> 8) & 1u;   // (-DW3_TUNING builds only — W3_OPT_TUNE bit 8: timing experiment, results WRONG)
+#endif
             s2.job_counter = (uint32_t *)((uint8_t *)ws.slot_keys + 2 * key_bytes + hist_bytes);
             (void)hipMemsetAsync(s2.job_counter, 0, 4, s);
             const uint32_t njobs = nb * s2.jobs_per_block;
