@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define W3_ABI_VERSION 7
+#define W3_ABI_VERSION 8
 
 /* ---- error codes --------------------------------------------------------- */
 enum {
@@ -149,7 +149,9 @@ enum {
                            sample / nblocks per call.  Full coverage = decode the output (w3_decode_blocks_device shares no kernel
                            with the predict phase; bench.py does that for every block of its last step).  0 = off */
     W3_OPT_TUNE = 11,   /* scheduling experiments of the submit / wait pipeline (bit mask; output is identical whatever is set) */
-    W3_OPT_FAULT_BLOCK = 10 /* test hook, with W3_OPT_VARIANT bit 32: the one block the injected fault hits (-1 = every block, default) */
+    W3_OPT_FAULT_BLOCK = 10, /* test hook, with W3_OPT_VARIANT bit 32: the one block the injected fault hits (-1 = every block, default) */
+    W3_OPT_HOST_CHUNK_BLOCKS = 12 /* w3_encode_blocks: blocks per pipelined piece of a host-buffer call (0 = default: equal pieces of at most
+                           4,096 blocks; tests use small values to get ragged pieces) */
 };
 enum { W3_PATH_AUTO = 0, W3_PATH_GENERIC = 1, W3_PATH_TWOPHASE = 2 };
 int         w3_ctx_set_option(w3_ctx *ctx, int opt, int64_t value);
@@ -163,7 +165,11 @@ size_t      w3_max_compressed_size(size_t n, size_t block_size);
  * what the reference writes after its 12-byte header for a file holding only
  * that block.  Streams are byte-aligned (ACWriter::flush, io.rs:91-100) and
  * concatenated in block order; block_lens[ceil(n/block_size)] gets the sizes.
- * *out_len is set even on W3_E_NOSPACE.                                       */
+ * *out_len is set even on W3_E_NOSPACE.
+ * w3_encode_blocks is PIPELINED inside the call (ABI v8): inputs of more than 4,096 blocks are cut into equal pieces of whole
+ * blocks, each a w3_encode_host_submit call (below) — piece k+1's input crosses PCIe while piece k is encoded and piece k-1's
+ * streams travel back; the output is byte-identical to the one-piece call's.  `in` / `out` may be pageable or pinned
+ * (hipHostMalloc / hipHostRegister) memory; pinned buffers make the copies asynchronous.                                    */
 int w3_encode_blocks(w3_ctx *ctx, const w3_model_spec *spec,
                      const uint8_t *in, size_t n, size_t block_size,
                      uint8_t *out, size_t out_cap, size_t *out_len, uint32_t *block_lens);
@@ -218,6 +224,28 @@ int w3_encode_submit(w3_ctx *ctx, const w3_model_spec *spec,
 int w3_encode_wait(w3_ctx *ctx, int job);
 int w3_encode_max_in_flight(const w3_model_spec *spec /* NULL: a Counter-leaf model */, size_t n, size_t block_size);
 
+/* ---- the host-buffer encode, asynchronous: calls in flight (ABI v8) -------------------------------------------
+ * compress() of the reference reads a file and writes a file (main.rs:89-113): a host sees PCIe in, encode, PCIe out.  One
+ * synchronous call cannot hide its own first copy in, its last coder chain (8 x block_size dependent steps per lane) and its
+ * last copy out; a host with several inputs (files of a directory, main.rs:41-50; pieces of a long stream) keeps CALLS in flight:
+ *   w3_encode_host_submit   arguments as w3_encode_blocks; enqueues the H2D of `in` on the context's copy-in stream and — as soon
+ *                     as a device job slot is free — the encode behind it (w3_encode_submit); returns at once when `in` is pinned
+ *                     memory (pageable: when HIP has staged the input).  `in`, `out`, `block_lens` must stay valid and untouched
+ *                     until the job has been waited for.  *hjob receives a handle (0 .. 4).  W3_E_INVALID when
+ *                     w3_encode_host_max_in_flight(spec, n, block_size) calls are in flight already.
+ *   w3_encode_host_max_in_flight  = w3_encode_max_in_flight + 1: the extra call is the one whose input travels while every
+ *                     device job slot is busy.
+ *   w3_encode_host_wait     blocks until the job's streams and length table are in the caller's buffers; returns what
+ *                     w3_encode_blocks would have returned (W3_E_NOSPACE with *out_len = the size needed included).  The jobs are
+ *                     encoded in submission order; waiting for a later one first completes the earlier ones on the device (their
+ *                     outputs stay on the device until they are waited for themselves).
+ * Not to be mixed with w3_encode_submit jobs on the same context.  Every synchronous entry point returns W3_E_INVALID while a
+ * host-buffer job is in flight.  Output byte-identical to w3_encode_blocks.                                                  */
+int w3_encode_host_submit(w3_ctx *ctx, const w3_model_spec *spec, const uint8_t *in, size_t n, size_t block_size,
+                          uint8_t *out, size_t out_cap, uint32_t *block_lens, int *hjob);
+int w3_encode_host_wait(w3_ctx *ctx, int hjob, size_t *out_len);
+int w3_encode_host_max_in_flight(const w3_model_spec *spec /* NULL: a Counter-leaf model */, size_t n, size_t block_size);
+
 /* ---- sharding over several GPUs from ONE process (C, C++ or Rust hosts) ---------------------------
  * Blocks are independent (fresh model + coder each), so they shard with no data-path collective: context r codes the
  * contiguous block range w3_shard_range gives it (block b -> rank floor(b * world / nblocks): rank order = stream
@@ -244,6 +272,11 @@ int w3_encode_blocks_sharded(w3_ctx *const *ctxs, int n_ctx, const w3_model_spec
  * does not link it, and W3_E_HIP with w3_last_error(ctxs[0]) = "RCCL not available ..." is returned when it is missing.
  * Output identical to w3_encode_blocks_device on one context over the concatenated shards.                               */
 enum { W3_GATHER_AUTO = 0, W3_GATHER_RCCL = 1, W3_GATHER_PEER_COPY = 2 };
+/* w3_rccl_library: the library to dlopen INSTEAD of the usual sonames ("librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1");
+ * only before the first gather or status call of the process (W3_E_INVALID afterwards).  w3_rccl_status resolves RCCL now and
+ * reports: W3_OK, or W3_E_HIP with the loader's message in msg ("RCCL not available: ...").  Neither needs a device.          */
+int w3_rccl_library(const char *path);
+int w3_rccl_status(char *msg, size_t cap);
 int w3_encode_blocks_sharded_device(w3_ctx *const *ctxs, int n_ctx, const w3_model_spec *spec,
                                     const uint8_t *const *d_in, const size_t *n, size_t block_size, int root,
                                     uint8_t *d_out, size_t out_cap, uint32_t *d_block_lens,
@@ -298,7 +331,9 @@ int w3_stationary_table(const uint8_t *buf, size_t n, uint16_t table[8]);
  * (entropy_coding/package_merge.rs:1-84) -> canonical codes (:87-117), bit-reversed; the same for the 255 partial-byte
  * symbols.  The reference sorts with sort_unstable_by (:9, :92): among EQUAL counts / lengths its order is an
  * implementation detail of Rust's unstable sort; this implementation takes them in ascending symbol order (the order the
- * reference's own tests show for small inputs).  Model construction, not the hot path.
+ * reference's own tests show for small inputs).  REFERENCE-IDENTICAL TABLES for a histogram with tied counts or lengths
+ * therefore come from the crate itself: a Rust host passes HuffHistory's own tables through w3_model_spec.huff (from_tables in
+ * INTEGRATION.md); Rust's unstable sort is not re-derived here.  Model construction, not the hot path.
  * Returns W3_E_INVALID for the reference's panics (no symbols, max length > 32 or too small for the alphabet).      */
 int w3_huff_tables(const uint8_t *buf, size_t n, uint8_t huff_size, uint8_t rem_huff_size, w3_huff_table *out);
 
@@ -336,7 +371,8 @@ typedef struct w3_timing {
     float    slot_ms;      /* slot-state leaves: table zero-fill + k_slot launches (also inside predict_ms) */
     uint32_t n_slot_launches; /* k_slot launches (block batches sized to the device memory budget) */
     float    achash_ms;    /* ACHistory key kernels (k_achash_lut + k_achash; also inside predict_ms) */
-    uint32_t n_parts;      /* always 1 (ABI v5: block ranges of W3_OPT_PARTS) */
+    uint32_t n_parts;      /* pieces the call was cut into: 1 for every device-resident call, >= 1 for w3_encode_blocks (ABI v8: the
+                              times and byte counts of this struct are then sums over the pieces) */
     uint32_t n_lds_faults; /* wavefronts of the sampled verification whose streams differed (W3_OPT_VERIFY); > 0: the call was
                               re-encoded with ballot rounds */
     /* launch durations of the predict phase's kernels (they may overlap in time: side stream, or another job's kernels) */

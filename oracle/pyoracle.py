@@ -271,6 +271,39 @@ class ACHistory:
 lib.w3o_history_hash.restype = C.c_uint32
 
 
+class ACHistoryCached:
+    """history/ac_history_cached.rs:9-76 restated with its memo (w3o_achc_*).  counts() -> (level-0 hits, level-1 hits, full runs,
+    memo entries)."""
+
+    def __init__(self, max_bits, model, cache_size):
+        self.h = lib.w3o_achc_new(C.c_uint8(max_bits), C.byref(model.m), C.c_uint8(cache_size))
+
+    def update(self, bit):
+        lib.w3o_achc_update(self.h, C.c_uint8(bit))
+
+    def hash(self):
+        return lib.w3o_achc_hash(self.h)
+
+    def counts(self):
+        out = (C.c_uint64 * 4)()
+        lib.w3o_achc_counts(self.h, out)
+        return tuple(int(v) for v in out)
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib.w3o_achc_free(self.h)
+            self.h = None
+
+
+lib.w3o_achc_new.restype = C.c_void_p
+lib.w3o_achc_new.argtypes = [C.c_uint8, C.c_void_p, C.c_uint8]
+lib.w3o_achc_free.argtypes = [C.c_void_p]
+lib.w3o_achc_update.argtypes = [C.c_void_p, C.c_uint8]
+lib.w3o_achc_hash.restype = C.c_uint32
+lib.w3o_achc_hash.argtypes = [C.c_void_p]
+lib.w3o_achc_counts.argtypes = [C.c_void_p, C.c_void_p]
+
+
 # ---- length-limited Huffman (entropy_coding/package_merge.rs) and HuffHistory (history/huff_history.rs) -------------
 PM_ERRORS = {-1: "No symbols provided", -2: "Max length is too big", -3: "Max length is too small"}
 

@@ -417,6 +417,103 @@ uint32_t w3o_history_hash(w3o_history *h) {
 }
 
 /* ================================================================== */
+/* ACHistoryCached  history/ac_history_cached.rs:9-76                  */
+/* The reference's memoised form of ACHistory, restated WITH its memo  */
+/* (the product treats it as an alias of ACHistory: this is what the   */
+/* equality test compares).  Rust's std HashMap<(u64, u8, u8), (EntropyWriter, ArithmeticCoder)> */
+/* is an open-addressing table here; insert overwrites like :68, :71.  */
+/* Integer behaviour is the RELEASE profile's (Cargo.toml:20-24: no    */
+/* overflow checks): cache_size / 2 == 0 makes `c2 - 1` wrap to 255,   */
+/* which no i in 0..64 equals (:67) — a debug build would panic there. */
+/* ================================================================== */
+
+typedef struct achc_entry {
+    uint64_t bits; uint8_t alignment, level, used;        /* key (:15) */
+    uint32_t state; uint8_t max_bits, idx; uint16_t rev_bits;   /* EntropyWriter (:79-85) */
+    uint32_t x1, x2;                                       /* ArithmeticCoder (arithmetic_coder.rs:13-18; x is the decoder's) */
+} achc_entry;
+
+struct w3o_achc {
+    uint64_t pos, bits;          /* :10-11 */
+    uint8_t max_bits;            /* :12 */
+    w3o_stationary model;        /* :13 */
+    uint8_t cache_size;          /* :14 */
+    achc_entry *tab; size_t cap, len;   /* :15 */
+    uint64_t hits[2], misses;    /* (instrumentation for the tests: level-0 / level-1 hits, full runs) */
+};
+
+static size_t achc_slot(const w3o_achc *h, uint64_t bits, uint8_t alignment, uint8_t level) {
+    uint64_t k = bits * 0x9E3779B97F4A7C15ull + ((uint64_t)alignment << 8 | level) * 0xC2B2AE3D27D4EB4Full;
+    k ^= k >> 29;
+    size_t i = (size_t)k & (h->cap - 1);
+    while (h->tab[i].used && !(h->tab[i].bits == bits && h->tab[i].alignment == alignment && h->tab[i].level == level))
+        i = (i + 1) & (h->cap - 1);
+    return i;
+}
+
+static void achc_insert(w3o_achc *h, uint64_t bits, uint8_t alignment, uint8_t level, const w3o_sink *w, const w3o_ac *ac) {
+    if ((h->len + 1) * 2 > h->cap) {   /* grow */
+        achc_entry *old = h->tab; const size_t ocap = h->cap;
+        h->cap = ocap ? ocap * 2 : 1024;
+        h->tab = (achc_entry *)calloc(h->cap, sizeof(achc_entry));
+        for (size_t i = 0; i < ocap; i++)
+            if (old[i].used) h->tab[achc_slot(h, old[i].bits, old[i].alignment, old[i].level)] = old[i];
+        free(old);
+    }
+    achc_entry *e = &h->tab[achc_slot(h, bits, alignment, level)];
+    if (!e->used) h->len++;
+    e->used = 1; e->bits = bits; e->alignment = alignment; e->level = level;
+    e->state = w->state; e->max_bits = w->max_bits; e->idx = w->eidx; e->rev_bits = w->erev;
+    e->x1 = ac->x1; e->x2 = ac->x2;
+}
+
+w3o_achc *w3o_achc_new(uint8_t max_bits, const w3o_stationary *m, uint8_t cache_size) {   /* :19-28 */
+    w3o_achc *h = (w3o_achc *)calloc(1, sizeof *h);
+    h->max_bits = max_bits; h->model = *m; h->cache_size = cache_size;
+    return h;
+}
+void w3o_achc_free(w3o_achc *h) { if (h) { free(h->tab); free(h); } }
+void w3o_achc_update(w3o_achc *h, uint8_t bit) {   /* :32-35 */
+    h->bits = (h->bits << 1) | bit;
+    h->pos += 1;
+}
+void w3o_achc_counts(const w3o_achc *h, uint64_t out[4]) { out[0] = h->hits[0]; out[1] = h->hits[1]; out[2] = h->misses; out[3] = h->len; }
+
+uint32_t w3o_achc_hash(w3o_achc *h) {   /* :37-76 */
+    uint8_t alignment = (uint8_t)(h->pos & 7);                                        /* :38 */
+    const uint8_t c1 = h->cache_size, c2 = (uint8_t)(h->cache_size / 2);              /* :40 */
+    const uint64_t m1 = (c1 >= 64 ? 0 : (1ull << c1)) - 1, m2 = (1ull << c2) - 1;     /* :41 (1u64 << 64 would panic: cache sizes stay below) */
+    const uint64_t k1 = h->bits & m1, k2 = h->bits & m2;                              /* :42-45: keys (bits & m, alignment, level) */
+    uint8_t start;
+    w3o_sink writer; w3o_ac ac;
+    const achc_entry *e = h->cap ? &h->tab[achc_slot(h, k1, alignment, 0)] : NULL;    /* :46 cache.get(&k1) */
+    int level = 0;
+    if (!e || !e->used) { e = h->cap ? &h->tab[achc_slot(h, k2, alignment, 1)] : NULL; level = 1; }   /* :48 cache.get(&k2) */
+    if (e && e->used) {   /* :47 / :49: clones of the memoised writer and coder */
+        start = level == 0 ? c1 : c2;
+        w3o_sink_init_entropy(&writer, e->max_bits);
+        writer.state = e->state; writer.eidx = e->idx; writer.erev = e->rev_bits;
+        ac.x1 = e->x1; ac.x2 = e->x2; ac.x = 0;
+        h->hits[level]++;
+    } else {              /* :50-54 */
+        start = 0;
+        w3o_sink_init_entropy(&writer, h->max_bits);
+        w3o_ac_new_coder(&ac);
+        h->misses++;
+    }
+    alignment = (uint8_t)(((uint8_t)(alignment + 32) - start) & 7);                   /* :58 (u8 arithmetic) */
+    stationary_align(&h->model, alignment);                                           /* :59 */
+    for (uint8_t i = start; i < 64; i++) {                                            /* :60 */
+        const uint8_t bit = (uint8_t)((h->bits >> i) & 1);                            /* :61 */
+        if (w3o_ac_encode(&ac, bit, stationary_predict(&h->model), &writer)) break;   /* :62-65 */
+        if (i == (uint8_t)(c2 - 1)) achc_insert(h, k2, (uint8_t)(h->pos & 7), 1, &writer, &ac);   /* :66-68 */
+        if (i == (uint8_t)(c1 - 1)) achc_insert(h, k1, (uint8_t)(h->pos & 7), 0, &writer, &ac);   /* :69-71 */
+    }
+    const unsigned sh = 32u - writer.eidx;                                            /* :75; idx == 0: see w3o_history_hash */
+    return sh >= 32 ? writer.state : (writer.state >> sh);
+}
+
+/* ================================================================== */
 /* Models                                                              */
 /* ================================================================== */
 

@@ -113,6 +113,17 @@ void     w3o_history_huff(w3o_history *h, const w3o_huff_tables *t);
 void     w3o_history_update(w3o_history *h, uint8_t bit);
 uint32_t w3o_history_hash(w3o_history *h);
 
+/* ACHistoryCached  history/ac_history_cached.rs:9-76: the memoised ACHistory, restated with its two-level memo keyed by
+ * (bits & mask, alignment, level).  The product has no node for it (its hash() equals ACHistory's: weath3rb0i_amd/models.py);
+ * this literal form exists so that the equality is a TEST RESULT (tests/test_oracle_kats.py), not an argument.
+ * counts: [level-0 hits, level-1 hits, full runs, memo entries]. */
+typedef struct w3o_achc w3o_achc;
+w3o_achc *w3o_achc_new(uint8_t max_bits, const w3o_stationary *m, uint8_t cache_size);   /* :19-28 */
+void      w3o_achc_free(w3o_achc *h);
+void      w3o_achc_update(w3o_achc *h, uint8_t bit);   /* :32-35 */
+uint32_t  w3o_achc_hash(w3o_achc *h);                  /* :37-76 */
+void      w3o_achc_counts(const w3o_achc *h, uint64_t out[4]);
+
 /* Models: trait Model (models/mod.rs:12-15) as an opaque tree */
 typedef struct w3o_model w3o_model;
 w3o_model *w3o_order0(void);                                   /* models/order0.rs */

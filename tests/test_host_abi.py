@@ -29,7 +29,7 @@ def test_exports_match_header(lib):
         assert hasattr(lib, name), "libw3hip.so does not export %s" % name
     assert declared == set(L.EXPORTS)
     m = re.search(r"#define W3_ABI_VERSION (\d+)", open(os.path.join(ROOT, "include", "w3hip.h")).read())
-    assert lib.w3_abi_version() == int(m.group(1)) == 7
+    assert lib.w3_abi_version() == int(m.group(1)) == 8
 
 
 def test_integration_doc_binds_every_export():
@@ -180,3 +180,28 @@ def test_shard_range_matches_the_python_sharding(lib):
                 assert lib.w3_shard_range(nb, world, rank, C.byref(lo), C.byref(hi)) == 0
                 assert (lo.value, hi.value) == shard.block_range(rank, world, nb)
     assert lib.w3_shard_range(10, 0, 0, C.byref(C.c_size_t()), C.byref(C.c_size_t())) == L.W3_E_INVALID
+
+
+def test_missing_rccl_is_an_error_code_not_a_crash(lib):
+    """include/w3hip.h: without RCCL the device-resident gather returns W3_E_HIP "RCCL not available ..." (w3_rccl.h resolves the
+    library at first use).  The loader's not-found path, taken in a fresh process (the library is resolved once per process) by naming
+    a file that does not exist; needs no device."""
+    import subprocess
+    import sys
+    code = r'''
+import ctypes as C, sys
+sys.path.insert(0, %r)
+from weath3rb0i_amd import _lib as L
+lib = L.load()
+assert lib.w3_rccl_library(b"/nonexistent/librccl-not-here.so.1") == 0
+buf = C.create_string_buffer(512)
+rc = lib.w3_rccl_status(buf, 512)
+assert rc == L.W3_E_HIP, rc
+assert buf.value.startswith(b"RCCL not available: "), buf.value
+assert b"librccl-not-here" in buf.value, buf.value
+assert lib.w3_rccl_library(b"librccl.so.1") == L.W3_E_INVALID    # resolved once per process
+assert lib.w3_rccl_status(buf, 512) == L.W3_E_HIP                 # and the verdict stays
+print("ok")
+''' % ROOT
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0 and p.stdout.strip().endswith("ok"), (p.returncode, p.stdout[-500:], p.stderr[-1500:])

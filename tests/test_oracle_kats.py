@@ -367,3 +367,45 @@ def test_huff_history_hash_and_model(oracle):
         s = oracle.encode_stream(mk(), data)
         assert oracle.decode_stream(mk(), s, len(data)) == data
         assert s != oracle.encode_stream(oracle.OrderNEntropy(bits, 3, oracle.RawHistory()), data)
+
+
+@pytest.mark.parametrize("table", ["book1", "enwik7", "edge"])
+def test_ac_history_cached_equals_ac_history(oracle, table):
+    """history/ac_history_cached.rs:37-76 restated WITH its two-level memo (oracle: w3o_achc_*): hash() equals ACHistory's
+    (ac_history.rs:28-46) after every update, for cache sizes 0..24 (and a few beyond), several max_bits, the reference's two baked
+    tables and one with extreme probabilities (prob 0 / 65535: up to 32 bits per coded history bit), over text-like and random
+    histories — every alignment occurs as pos runs.  The memo really is exercised (hits at both levels).  This is what makes the
+    product's `ACHistoryCached = ACHistory` alias (weath3rb0i_amd/models.py) a test result."""
+    from tests.synth import markov_text
+    tables = {"book1": [1, 50188, 62497, 15819, 22545, 31499, 22988, 29616], "enwik7": [752, 50314, 58928, 21421, 24680, 30788, 24297, 32530],
+              "edge": [0, 65535, 1, 32768, 0, 65535, 12345, 1]}
+    rng = np.random.default_rng(1234)
+    text = markov_text(700, seed=17)
+    rnd = bytes(rng.integers(0, 256, 300, dtype=np.uint8))
+    runs = text + bytes(40) + b"\xff" * 40 + rnd
+    bits = [(b >> s) & 1 for b in runs for s in range(7, -1, -1)]
+    sizes = list(range(0, 25)) + [31, 40, 63]
+    level_hits = [0, 0]
+    for cache_size in sizes:
+        for max_bits in ((0, 8, 23, 32) if cache_size % 6 == 0 else (8, 17)):
+            sm = lambda: oracle.StationaryModel.from_table(tables[table])
+            plain = oracle.ACHistory(max_bits, sm())
+            cached = oracle.ACHistoryCached(max_bits, sm(), cache_size)
+            assert cached.hash() == plain.hash()                      # pos == 0, empty history
+            n = len(bits) if cache_size in (0, 1, 7, 16, 24) else 2400
+            for t, bit in enumerate(bits[:n]):
+                plain.update(bit)
+                cached.update(bit)
+                a, b = cached.hash(), plain.hash()
+                assert a == b, (table, cache_size, max_bits, t, a, b)
+                if t % 97 == 0:                                         # hash() is repeatable (&mut self only moves the model's alignment)
+                    assert cached.hash() == b
+            h0, h1, full, entries = cached.counts()
+            if cache_size >= 2:
+                level_hits[0] += h0
+                level_hits[1] += h1
+                # (the extreme table fills max_bits within a step or two: the loop breaks before i reaches c - 1 and nothing is memoised, :63-65)
+                assert entries > 0 or table == "edge" or max_bits == 0
+            else:   # c2 == 0: `c2 - 1` wraps (release profile), the level-1 key is never inserted; cache_size 0 inserts nothing at all
+                assert h1 == 0 and (cache_size == 1 or (h0 == 0 and entries == 0))
+    assert table == "edge" or (level_hits[0] > 1000 and level_hits[1] > 100), level_hits

@@ -13,7 +13,7 @@ W3_MAX_APM = 4
 W3_HIST_NONE, W3_HIST_RAW, W3_HIST_AC, W3_HIST_HUFF = 0, 1, 2, 3
 W3_MAX_HUFF = 4
 W3_OK, W3_E_INVALID, W3_E_NOSPACE, W3_E_HIP, W3_E_UNSUPPORTED, W3_E_NOMEM, W3_E_FORMAT = 0, -1, -2, -3, -4, -5, -6
-W3_OPT_PATH, W3_OPT_TIMING, W3_OPT_CODER, W3_OPT_ACC_LIMIT, W3_OPT_DEBUG_STAMPS, W3_OPT_VARIANT, W3_OPT_SLOT_BUDGET_MB, W3_OPT_VERIFY, W3_OPT_FAULT_BLOCK, W3_OPT_TUNE = 1, 2, 3, 4, 5, 7, 8, 9, 10, 11
+W3_OPT_PATH, W3_OPT_TIMING, W3_OPT_CODER, W3_OPT_ACC_LIMIT, W3_OPT_DEBUG_STAMPS, W3_OPT_VARIANT, W3_OPT_SLOT_BUDGET_MB, W3_OPT_VERIFY, W3_OPT_FAULT_BLOCK, W3_OPT_TUNE, W3_OPT_HOST_CHUNK_BLOCKS = 1, 2, 3, 4, 5, 7, 8, 9, 10, 11, 12
 W3_VAR_NO_LDS_ATOMICS, W3_VAR_PARTITION4, W3_VAR_NO_CHAINED_PARTITION, W3_VAR_CM_UNSTAGED, W3_VAR_NO_SIDE_STREAM, W3_VAR_INJECT_LDS_FAULT = 1, 2, 4, 8, 16, 32
 W3_VAR_HALF_CU, W3_VAR_FULL_CU = 64, 128
 W3_VAR_SLOT_TABLE, W3_VAR_SLOT_SORTED, W3_VAR_DECODE_LANE = 256, 512, 1024
@@ -49,6 +49,7 @@ EXPORTS = [
     "w3_decode_blocks_device", "w3_encode_submit", "w3_encode_wait", "w3_encode_max_in_flight", "w3_compress_stream", "w3_decompress_stream", "w3_predict_blocks", "w3_stationary_table",
     "w3_get_timing", "w3_selftest_counter_p", "w3_debug_get_stamps", "w3_state_table", "w3_stretch_squash", "w3_huff_tables",
     "w3_shard_range", "w3_encode_blocks_sharded", "w3_encode_blocks_sharded_device", "w3_encode_stats", "w3_encode_stats_device", "w3_sweep_ordern", "w3_sweep_ordern_device", "w3_export_counters",
+    "w3_encode_host_submit", "w3_encode_host_wait", "w3_encode_host_max_in_flight", "w3_rccl_library", "w3_rccl_status",
 ]
 
 _lib = None
@@ -110,5 +111,11 @@ def load():
     lib.w3_sweep_ordern.argtypes = [vp, vp, sz, sz, vp, vp, sz, vp]
     lib.w3_sweep_ordern_device.argtypes = [vp, vp, sz, sz, vp, vp, sz, vp]
     lib.w3_export_counters.argtypes = [vp, C.POINTER(ModelSpec), vp, sz, vp]
+    lib.w3_encode_host_submit.argtypes = [vp, C.POINTER(ModelSpec), vp, sz, sz, vp, sz, vp, C.POINTER(C.c_int)]
+    lib.w3_encode_host_wait.argtypes = [vp, C.c_int, C.POINTER(sz)]
+    lib.w3_encode_host_max_in_flight.argtypes = [C.POINTER(ModelSpec), sz, sz]
+    lib.w3_encode_host_max_in_flight.restype = C.c_int
+    lib.w3_rccl_library.argtypes = [C.c_char_p]
+    lib.w3_rccl_status.argtypes = [C.c_char_p, sz]
     _lib = lib
     return lib

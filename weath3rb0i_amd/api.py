@@ -19,6 +19,15 @@ def _u8(data):
     return np.frombuffer(bytes(data), dtype=np.uint8)
 
 
+def _host_ptr(buf):
+    """(address, bytes) of a host buffer: a numpy array, or anything with data_ptr() / numel() / element_size() (a torch CPU tensor —
+    pinned ones make the copies asynchronous)."""
+    if isinstance(buf, np.ndarray):
+        assert buf.flags["C_CONTIGUOUS"]
+        return buf.ctypes.data, buf.nbytes
+    return buf.data_ptr(), buf.numel() * buf.element_size()
+
+
 class Context:
     def __init__(self, device=0):
         self.lib = L.load()
@@ -77,6 +86,10 @@ class Context:
     def set_slot_budget_mb(self, mb=0):
         self._chk(self.lib.w3_ctx_set_option(self.h, L.W3_OPT_SLOT_BUDGET_MB, int(mb)))
 
+    def set_host_chunk_blocks(self, blocks=0):
+        """W3_OPT_HOST_CHUNK_BLOCKS: blocks per pipelined piece of a host-buffer call (0 = default)."""
+        self._chk(self.lib.w3_ctx_set_option(self.h, L.W3_OPT_HOST_CHUNK_BLOCKS, int(blocks)))
+
     def set_timing(self, on=True):
         self._chk(self.lib.w3_ctx_set_option(self.h, L.W3_OPT_TIMING, int(on)))
 
@@ -105,6 +118,28 @@ class Context:
                 continue
             self._chk(rc)
             return out[: olen.value], lens[:nb]
+
+    def encode_host_submit(self, model, data, block_size, out, lens):
+        """w3_encode_host_submit: `data`, `out` (uint8) and `lens` (uint32[nb]) are host buffers — numpy arrays or torch CPU tensors,
+        pinned or not — that must stay alive and untouched until encode_host_wait(job).  -> job handle"""
+        spec = model.spec() if isinstance(model, Model) else model
+        ip, n = _host_ptr(data)
+        op, cap = _host_ptr(out)
+        lp, _ = _host_ptr(lens)
+        job = C.c_int(-1)
+        self._chk(self.lib.w3_encode_host_submit(self.h, C.byref(spec), C.c_void_p(ip), n, block_size, C.c_void_p(op), cap, C.c_void_p(lp), C.byref(job)))
+        return job.value
+
+    def encode_host_wait(self, job):
+        """w3_encode_host_wait -> compressed bytes now in the job's `out` (raises what w3_encode_blocks would have raised)."""
+        olen = C.c_size_t()
+        rc = self.lib.w3_encode_host_wait(self.h, int(job), C.byref(olen))
+        self._chk(rc)
+        return olen.value
+
+    def host_max_in_flight(self, n, block_size, model=None):
+        spec = None if model is None else (model.spec() if isinstance(model, Model) else model)
+        return int(self.lib.w3_encode_host_max_in_flight(C.byref(spec) if spec is not None else None, int(n), int(block_size)))
 
     def decode_blocks(self, model, comp, block_lens, block_size, orig_len):
         spec = model.spec() if isinstance(model, Model) else model
@@ -201,8 +236,9 @@ class Context:
         self._chk(rc)
 
     def encode_submit(self, model, d_in, block_size, d_out, d_lens, d_total, stream=None):
-        """w3_encode_submit: enqueue the encode and return a job handle at once (at most two jobs in flight; the next call's predict
-        phase runs beside this call's APM and coder kernels).  Keep every tensor alive and untouched until encode_wait(job)."""
+        """w3_encode_submit: enqueue the encode and return a job handle at once (at most max_in_flight(n, block_size, model) jobs in
+        flight: four up to 4,096 blocks, three up to 12,288, two beyond; the next call's predict phase runs beside this call's APM and
+        coder kernels).  Keep every tensor alive and untouched until encode_wait(job)."""
         spec = model.spec() if isinstance(model, Model) else model
         st = C.c_void_p(stream) if stream else None
         job = C.c_int(-1)

@@ -27,20 +27,30 @@ struct Api {
     std::string error;
 };
 
+static inline std::string &library_override() { static std::string s; return s; }
+static inline bool &resolved() { static bool r = false; return r; }
+
 static inline Api *api() {
     static Api a;
     static std::once_flag once;
     std::call_once(once, [] {
-        const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
-        for (const char *nm : names) {
-            a.handle = dlopen(nm, RTLD_NOW | RTLD_NOLOAD | RTLD_GLOBAL);   // a copy the process has loaded already (torch's) first
-            if (a.handle) break;
+        resolved() = true;
+        // w3_rccl_library(path): the one library to try instead of the usual sonames (a host whose RCCL lives elsewhere; the tests
+        // name a file that does not exist to take the "not available" path on a machine that has RCCL)
+        const char *over = library_override().empty() ? nullptr : library_override().c_str();
+        const char *usual[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+        const char *one[] = {over};
+        const char *const *names = over && *over ? one : usual;
+        const int n_names = over && *over ? 1 : 3;
+        for (int i = 0; i < n_names && !a.handle; i++)
+            a.handle = dlopen(names[i], RTLD_NOW | RTLD_NOLOAD | RTLD_GLOBAL);   // a copy the process has loaded already (torch's) first
+        for (int i = 0; i < n_names && !a.handle; i++)
+            a.handle = dlopen(names[i], RTLD_NOW | RTLD_GLOBAL);
+        if (!a.handle) {
+            const char *e = dlerror();   // (once: the call clears the error it returns)
+            a.error = std::string("RCCL not available: ") + (e ? e : "dlopen failed");
+            return;
         }
-        for (const char *nm : names) {
-            if (a.handle) break;
-            a.handle = dlopen(nm, RTLD_NOW | RTLD_GLOBAL);
-        }
-        if (!a.handle) { a.error = std::string("RCCL not available: ") + (dlerror() ? dlerror() : "dlopen failed"); return; }
 #define W3_RCCL_SYM(field, name)                                                                          \
         do {                                                                                               \
             *(void **)(&a.field) = dlsym(a.handle, name);                                                  \

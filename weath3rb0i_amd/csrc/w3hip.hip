@@ -51,6 +51,8 @@ struct JobState {
     const uint8_t *d_in = nullptr; size_t n = 0, block_size = 0; uint8_t *d_out = nullptr; size_t out_cap = 0;
     uint32_t *d_block_lens = nullptr; uint64_t *d_total = nullptr;
     w3_timing tm{};
+    w3_timing tm_ev{}; bool tm_snap = false;   // the event times, collected early (a synchronous fallback is about to reuse job 0's events)
+    int sync_rc = W3_OK;           // state 2: what the synchronous run inside w3_encode_submit returned
     bool has_apm = false, has_slot = false, timed = false;
     hipStream_t sc = nullptr;      // the stream this job's code stage runs on (free-running jobs: one each; ordered jobs share s_code[0])
 };
@@ -63,6 +65,24 @@ struct JobState {
 #define W3_MAX_JOBS 4
 #define W3_FREE_RUN_BLOCKS 12288u
 #define W3_FREE_RUN4_BLOCKS 4096u
+
+// One host-buffer encode in flight (w3_encode_host_submit / w3_encode_host_wait): its own device input / output buffers, so that call
+// k+1's input can travel over PCIe while call k is being encoded and call k-1's streams travel back.  One more than the device jobs:
+// the extra one is the call whose input is on its way while every device job slot is busy.
+#define W3_MAX_HOST_JOBS (W3_MAX_JOBS + 1)
+struct HostJob {
+    int state = 0;                 // 0 idle, 1 input enqueued (H2D), encode not submitted yet (no device job slot free), 2 encode submitted (djob),
+                                   // 3 through on the device (rc / total known), output not fetched yet
+    int djob = -1, rc = W3_OK;
+    uint64_t seq = 0, total = 0;
+    DevBuf d_in, d_out, d_lens, d_total;
+    hipEvent_t ev_d2h = nullptr;
+    w3_model_spec spec{};
+    w3_huff_table huff_copy[W3_MAX_HUFF];
+    size_t n = 0, block_size = 0, nb = 0, dcap = 0;
+    uint8_t *out = nullptr; size_t out_cap = 0; uint32_t *block_lens = nullptr;
+    w3_timing tm{};
+};
 
 struct w3_ctx {
     int device = 0;
@@ -82,6 +102,11 @@ struct w3_ctx {
     int next_job = 0, last_job = -1;
     bool pooled_streams = false;
     hipStream_t s_side = nullptr, s_verify[W3_MAX_JOBS] = {};   // the workspaces' side stream (one: predict phases never overlap) and re-prediction streams
+    // host-buffer calls in flight (w3_encode_host_submit / w3_encode_host_wait; w3_encode_blocks cuts its input into such calls)
+    HostJob hj[W3_MAX_HOST_JOBS];
+    hipStream_t s_h2d = nullptr, s_d2h = nullptr;   // copy streams: nothing but transfers is ever enqueued on them
+    uint64_t hseq = 0;
+    uint32_t host_chunk_blocks = 0;                 // W3_OPT_HOST_CHUNK_BLOCKS (0 = auto)
 };
 
 // the members of job j under one name
@@ -118,6 +143,16 @@ static int ensure(w3_ctx *ctx, DevBuf &b, size_t bytes) {
     return W3_OK;
 }
 #define ENSURE(ctx, buf, bytes) do { int r_ = ensure(ctx, buf, bytes); if (r_) return r_; } while (0)
+
+// Every entry point but w3_encode_submit / w3_encode_wait (and their host-buffer forms) works on job 0's workspace and the context's
+// options: none of them may run while a submitted call is in flight (include/w3hip.h).
+static int jobs_idle(w3_ctx *ctx) {
+    for (const auto &st : ctx->js)
+        if (st.state == 1) { ctx->err = "asynchronous jobs are in flight on this context: w3_encode_wait them first"; return W3_E_INVALID; }
+    for (const auto &h : ctx->hj)
+        if (h.state != 0) { ctx->err = "host-buffer jobs are in flight on this context: w3_encode_host_wait them first"; return W3_E_INVALID; }
+    return W3_OK;
+}
 
 extern "C" int w3_abi_version(void) { return W3_ABI_VERSION; }
 
@@ -202,6 +237,14 @@ extern "C" void w3_ctx_destroy(w3_ctx *ctx) {
         if (ctx->s_pred) (void)hipStreamDestroy(ctx->s_pred);
         for (auto &sc : ctx->s_code) if (sc) (void)hipStreamDestroy(sc);
     }
+    for (auto &h : ctx->hj) {
+        DevBuf *bufs2[] = {&h.d_in, &h.d_out, &h.d_lens, &h.d_total};
+        for (DevBuf *b : bufs2)
+            if (b->p) (void)hipFree(b->p);
+        if (h.ev_d2h) (void)hipEventDestroy(h.ev_d2h);
+    }
+    if (ctx->s_h2d) (void)hipStreamDestroy(ctx->s_h2d);
+    if (ctx->s_d2h) (void)hipStreamDestroy(ctx->s_d2h);
     for (auto &e : ctx->ev)
         if (e) (void)hipEventDestroy(e);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -210,6 +253,10 @@ extern "C" void w3_ctx_destroy(w3_ctx *ctx) {
 
 extern "C" int w3_ctx_set_option(w3_ctx *ctx, int opt, int64_t value) {
     if (!ctx) return W3_E_INVALID;
+    // A job in flight has taken its paths, variants and coder from the options: changing them between its predict and code stages would
+    // mix two settings in one call.  Two options are exempt: W3_OPT_TIMING (read when a call is submitted) and W3_OPT_TUNE (scheduling
+    // only: the output is identical whatever is set).
+    if (opt != W3_OPT_TIMING && opt != W3_OPT_TUNE) { const int rc_ = jobs_idle(ctx); if (rc_) return rc_; }
     switch (opt) {
     case W3_OPT_PATH:
         if (value < W3_PATH_AUTO || value > W3_PATH_TWOPHASE) return W3_E_INVALID;
@@ -231,6 +278,7 @@ extern "C" int w3_ctx_set_option(w3_ctx *ctx, int opt, int64_t value) {
         if ((value & W3_VAR_INJECT_LDS_FAULT) && !ctx->tp.verify) { ctx->err = "W3_OPT_VARIANT bit 32 (fault injection) needs W3_OPT_VERIFY on"; return W3_E_INVALID; }
         ctx->tp.variant = (uint32_t)value;
         ctx->tp.lds_order = -1;   // re-run the lane-order self-test under the new setting
+        for (auto &x : ctx->jx) x.tp.lds_order = -1;   // (the other job slots follow job 0: sync_job_options)
         return W3_OK;
     case W3_OPT_VERIFY:
         if (!value && (ctx->tp.variant & W3_VAR_INJECT_LDS_FAULT)) { ctx->err = "W3_OPT_VERIFY cannot be switched off while the fault-injection variant is set"; return W3_E_INVALID; }
@@ -247,6 +295,10 @@ extern "C" int w3_ctx_set_option(w3_ctx *ctx, int opt, int64_t value) {
     case W3_OPT_FAULT_BLOCK:
         if (value < -1 || value > 0x7FFFFFFF) return W3_E_INVALID;
         ctx->tp.fault_block = value < 0 ? 0xFFFFFFFFu : (uint32_t)value;
+        return W3_OK;
+    case W3_OPT_HOST_CHUNK_BLOCKS:
+        if (value < 0 || value > 0x7FFFFFFF) return W3_E_INVALID;
+        ctx->host_chunk_blocks = (uint32_t)value;
         return W3_OK;
     default: return W3_E_INVALID;
     }
@@ -402,6 +454,14 @@ static int table_budget(w3_ctx *ctx, uint64_t lane_stride, uint32_t want_lanes, 
     if (lanes == 0) {
         ctx->err = "model tables of one wavefront (" + std::to_string(lane_stride * 64) + " B) exceed the device budget";
         return W3_E_NOMEM;
+    }
+    // One hipMalloc of that size can still fail (fragmentation, another process or rank on the same GPU, a caching allocator that
+    // holds what hipMemGetInfo calls free): take half the lanes then — the callers run batches — rather than fail the call.
+    for (;;) {
+        const int rc = ensure(ctx, ctx->tables, (size_t)lanes * lane_stride);
+        if (rc == W3_OK) break;
+        if (rc != W3_E_NOMEM || lanes <= 64) return rc;
+        lanes = std::max<uint64_t>(64, lanes / 2 / 64 * 64);
     }
     lanes_out = (uint32_t)lanes;
     return W3_OK;
@@ -682,7 +742,10 @@ static void sync_job_options(w3_ctx *ctx, JobRef &J) {
     J.tp.coder_mode = ctx->tp.coder_mode; J.tp.acc_limit = ctx->tp.acc_limit; J.tp.debug_stamps = 0;
     J.tp.variant = ctx->tp.variant; J.tp.slot_budget_mb = ctx->tp.slot_budget_mb; J.tp.verify = ctx->tp.verify;
     J.tp.stretch = ctx->tp.stretch; J.tp.squash = ctx->tp.squash; J.tp.st = ctx->tp.st; J.tp.fault_block = ctx->tp.fault_block; J.tp.tune = ctx->tp.tune;
-    if (ctx->tp.lds_order >= 0) J.tp.lds_order = ctx->tp.lds_order;   // (job 0 has run the self-test)
+    // the lane-order self-test runs once, on job 0's workspace; the other slots take its verdict (and lose a stale one when
+    // W3_OPT_VARIANT has reset job 0's)
+    if (ctx->tp.lds_order < 0) (void)twophase_lds_order_ok(ctx->tp, ctx->stream);
+    J.tp.lds_order = ctx->tp.lds_order;
 }
 
 // The side stream of the predict phase and the job's re-prediction stream: the context's (taken from the process-wide pool), so that
@@ -827,12 +890,6 @@ static int encode_core(w3_ctx *ctx, JobRef J, const w3_model_spec *spec, const u
     return W3_OK;
 }
 
-static int jobs_idle(w3_ctx *ctx) {
-    for (const auto &st : ctx->js)
-        if (st.state == 1) { ctx->err = "asynchronous jobs are in flight on this context: w3_encode_wait them first"; return W3_E_INVALID; }
-    return W3_OK;
-}
-
 extern "C" int w3_encode_blocks_device(w3_ctx *ctx, const w3_model_spec *spec, const uint8_t *d_in, size_t n, size_t block_size,
                                        uint8_t *d_out, size_t out_cap, uint32_t *d_block_lens, uint64_t *d_total, void *stream) {
     if (!ctx) return W3_E_INVALID;
@@ -880,6 +937,16 @@ static PipelinePlan pipeline_plan(const ParsedSpec &ps, uint32_t nb, uint32_t tu
     else if (nb <= W3_FREE_RUN_BLOCKS) p.depth = 3;
     else p.depth = n_wide == 0 ? 3 : 2;                 // large inputs: a workspace is 16 bytes per input byte and live leaf (+ 40 per wide leaf)
     return p;
+}
+
+// Does w3_encode_submit only enqueue this call (true), or run it to completion inside the call (false: specs outside the predict kernels,
+// and specs whose slot-state leaves walk hash maps in HBM)?
+static bool submit_pipelines(const w3_ctx *ctx, const ParsedSpec &ps, uint32_t nb, size_t block_size, size_t n) {
+    const bool two = nb > 0 && twophase_supported(ps, block_size, n) && ctx->opt_path != W3_PATH_GENERIC;
+    // Specs with slot-state leaves are pipelined when the leaves run as the sorted replay (w3_slot2.h: no hash maps sized from the memory
+    // that happens to be free) — two jobs at most: a job's event records are 32 bytes per input byte and leaf.
+    const bool slot_async = ps.has_slot && slot_sorted_by_default(ps, nb, block_size, n) && !(ctx->tp.variant & (W3_VAR_SLOT_TABLE | W3_VAR_NO_LDS_ATOMICS)) && ctx->tp.lds_order != 0;
+    return two && !(ps.has_slot && !slot_async);
 }
 
 static int ensure_pipeline(w3_ctx *ctx) {
@@ -945,9 +1012,6 @@ extern "C" int w3_encode_submit(w3_ctx *ctx, const w3_model_spec *spec, const ui
     ParsedSpec ps;
     if ((rc = parse_spec(spec, ps))) { ctx->err = "malformed model spec"; return rc; }
     const uint32_t nb = (uint32_t)((n + block_size - 1) / block_size);
-    // Specs with slot-state leaves are pipelined when the leaves run as the sorted replay (w3_slot2.h: no hash maps sized from the memory
-    // that happens to be free) — two jobs at most: a job's event records are 32 bytes per input byte and leaf.
-    const bool slot_async = ps.has_slot && slot_sorted_by_default(ps, nb, block_size, n) && !(ctx->tp.variant & (W3_VAR_SLOT_TABLE | W3_VAR_NO_LDS_ATOMICS)) && ctx->tp.lds_order != 0;
     const PipelinePlan plan = pipeline_plan(ps, nb, ctx->tp.tune);
     const bool free_run = plan.free_run;
     const int depth = plan.depth;
@@ -963,18 +1027,26 @@ extern "C" int w3_encode_submit(w3_ctx *ctx, const w3_model_spec *spec, const ui
         return W3_E_INVALID;
     }
     HIPCHK(ctx, hipSetDevice(ctx->device));
-    const bool two = nb > 0 && twophase_supported(ps, block_size, n) && ctx->opt_path != W3_PATH_GENERIC;
-    if (!two || (ps.has_slot && !slot_async)) {
+    if (!submit_pipelines(ctx, ps, nb, block_size, n)) {
         // Not pipelined: the lane-per-block kernels (any spec the predict kernels do not cover) and specs whose slot-state leaves walk
         // hash maps in HBM (k_slot: sized from the memory that is free at the time) run to completion here, on job 0's workspace.
         for (int k = 0; k < W3_MAX_JOBS; k++) {   // let the other jobs' kernels finish first; their status is in pinned memory already
             if (ctx->js[k].state != 1) continue;
             if (ctx->js[k].code_pending) { JobRef O = jobref(ctx, k); if ((rc = enqueue_code(ctx, O, nullptr, nullptr))) return rc; }
             HIPCHK(ctx, hipEventSynchronize(ctx->js[k].ev_done));
+            if (k == 0 && ctx->js[0].timed && !ctx->js[0].tm_snap) {   // job 0's events are about to be recorded again
+                JobRef O = jobref(ctx, 0);
+                memset(&O.st.tm_ev, 0, sizeof O.st.tm_ev);
+                collect_timing(O.ev, O.tp, O.st.has_apm, O.st.has_slot, true, O.st.tm_ev);
+                O.st.tm_snap = true;
+            }
         }
-        rc = encode_core(ctx, jobref(ctx, 0), spec, d_in, n, block_size, d_out, out_cap, d_block_lens, d_total, stream);
-        if (rc) return rc;
+        // Completed by w3_encode_wait like any other job: THAT call returns what the synchronous call returned (W3_E_NOSPACE with
+        // d_total = the need included), so a caller that follows the submit / wait contract sees one behaviour for every spec.
+        const w3_timing keep = ctx->timing;
+        ctx->js[j].sync_rc = encode_core(ctx, jobref(ctx, 0), spec, d_in, n, block_size, d_out, out_cap, d_block_lens, d_total, stream);
         ctx->js[j].state = 2; ctx->js[j].tm = ctx->timing;
+        ctx->timing = keep;
         *job = j; ctx->next_job = j + 1; ctx->last_job = j;
         return W3_OK;
     }
@@ -986,7 +1058,7 @@ extern "C" int w3_encode_submit(w3_ctx *ctx, const w3_model_spec *spec, const ui
     if (ps.n_huff) { memcpy(st.huff_copy, ps.huff, sizeof(w3_huff_table) * ps.n_huff); st.spec.huff = st.huff_copy; ps.huff = st.huff_copy; }
     st.ps = ps;
     st.d_in = d_in; st.n = n; st.block_size = block_size; st.d_out = d_out; st.out_cap = out_cap; st.d_block_lens = d_block_lens; st.d_total = d_total;
-    st.has_apm = ps.n_apm > 0; st.has_slot = ps.has_slot; st.timed = ctx->opt_timing != 0;
+    st.has_apm = ps.n_apm > 0; st.has_slot = ps.has_slot; st.timed = ctx->opt_timing != 0; st.tm_snap = false;
     st.nb = nb;
     st.sc = free_run ? ctx->s_code[j] : ctx->s_code[0];
     memset(&st.tm, 0, sizeof st.tm);
@@ -1068,7 +1140,7 @@ extern "C" int w3_encode_wait(w3_ctx *ctx, int job) {
     JobState &st = J.st;
     if (st.state == 0) { ctx->err = "no such job in flight"; return W3_E_INVALID; }
     HIPCHK(ctx, hipSetDevice(ctx->device));
-    if (st.state == 2) { st.state = 0; ctx->timing = st.tm; return W3_OK; }
+    if (st.state == 2) { st.state = 0; ctx->timing = st.tm; return st.sync_rc; }
     if (st.code_pending) {   // no later submit has placed this job's code stage: it goes out now
         const int rc = enqueue_code(ctx, J, nullptr, nullptr);
         if (rc) { (void)hipDeviceSynchronize(); st.state = 0; st.code_pending = false; return rc; }
@@ -1098,9 +1170,182 @@ extern "C" int w3_encode_wait(w3_ctx *ctx, int job) {
     ctx->timing.coder_bytes = st.tm.coder_bytes + total; ctx->timing.predict_bytes = st.tm.predict_bytes;
     ctx->timing.n_coder_launches = st.tm.n_coder_launches; ctx->timing.n_slot_launches = st.tm.n_slot_launches;
     ctx->timing.n_parts = 1;
-    if (st.timed) collect_timing(J.ev, J.tp, st.has_apm, st.has_slot, true, ctx->timing);
+    if (st.timed && st.tm_snap) {
+        const w3_timing &e = st.tm_ev;
+        ctx->timing.predict_ms = e.predict_ms; ctx->timing.coder_ms = e.coder_ms; ctx->timing.apm_ms = e.apm_ms; ctx->timing.slot_ms = e.slot_ms;
+        ctx->timing.achash_ms = e.achash_ms; ctx->timing.n_wide = e.n_wide; ctx->timing.small_ms = e.small_ms; ctx->timing.pack_ms = e.pack_ms; ctx->timing.total_ms = e.total_ms;
+        memcpy(ctx->timing.part_ms, e.part_ms, sizeof e.part_ms); memcpy(ctx->timing.rank_ms, e.rank_ms, sizeof e.rank_ms);
+    } else if (st.timed) collect_timing(J.ev, J.tp, st.has_apm, st.has_slot, true, ctx->timing);
     if (total > st.out_cap) { ctx->err = "out_cap too small"; return W3_E_NOSPACE; }
     return W3_OK;
+}
+
+// ---------------------------------------------------------------------------
+// Host buffers, asynchronous (ABI v8): compress() of main.rs:89-113 reads a file and writes a file, so what a host sees is
+// PCIe in, encode, PCIe out.  A call here is those three as a pipeline ACROSS calls: the input of call k+1 travels while call k
+// is encoded (w3_encode_submit: up to four encodes in flight) and the streams of call k-1 travel back.  Copies run on two
+// streams of their own (one per direction: the link is full duplex); from pinned host memory they are asynchronous, from
+// pageable memory HIP stages them and the enqueueing call blocks — the encodes already submitted keep the GPU busy meanwhile.
+// ---------------------------------------------------------------------------
+static int host_streams(w3_ctx *ctx) {
+    if (!ctx->s_h2d) HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->s_h2d, hipStreamNonBlocking));
+    if (!ctx->s_d2h) HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->s_d2h, hipStreamNonBlocking));
+    for (auto &h : ctx->hj)
+        if (!h.ev_d2h) HIPCHK(ctx, hipEventCreateWithFlags(&h.ev_d2h, hipEventDisableTiming));
+    return W3_OK;
+}
+
+static int host_depth(const w3_model_spec *spec, size_t n, size_t block_size) {
+    return std::min(W3_MAX_HOST_JOBS, w3_encode_max_in_flight(spec, n, block_size) + 1);
+}
+
+// Submit the encodes of host jobs whose input is on its way, oldest first, while device job slots are free.
+static void host_start_pending(w3_ctx *ctx) {
+    for (;;) {
+        HostJob *h = nullptr;
+        for (auto &x : ctx->hj)
+            if (x.state == 1 && (!h || x.seq < h->seq)) h = &x;
+        if (!h) return;
+        int in_flight = 0;
+        for (const auto &o : ctx->js) in_flight += o.state != 0;
+        if (in_flight >= w3_encode_max_in_flight(&h->spec, h->n, h->block_size)) return;
+        // (the job starts behind everything enqueued on the H2D stream so far: its own input was the last of it)
+        h->rc = w3_encode_submit(ctx, &h->spec, (const uint8_t *)h->d_in.p, h->n, h->block_size, (uint8_t *)h->d_out.p, h->dcap,
+                                 (uint32_t *)h->d_lens.p, (uint64_t *)h->d_total.p, ctx->s_h2d, &h->djob);
+        h->state = h->rc ? 3 : 2;   // (a refused submit is reported by the wait)
+    }
+}
+
+// state 2 -> 3: wait for the job's encode; rc and the compressed size are known afterwards
+static void host_finish_device(w3_ctx *ctx, HostJob &h) {
+    h.rc = w3_encode_wait(ctx, h.djob);
+    h.tm = ctx->timing;
+    h.total = 0;
+    h.state = 3;
+    auto read_total = [&]() -> int {
+        HIPCHK(ctx, hipMemcpyAsync(&h.total, h.d_total.p, 8, hipMemcpyDeviceToHost, ctx->s_d2h));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->s_d2h));
+        return W3_OK;
+    };
+    if (h.rc == W3_OK || h.rc == W3_E_NOSPACE) { const int r = read_total(); if (r) h.rc = r; }
+    if (h.rc == W3_E_NOSPACE && h.total > h.dcap) {
+        // The device buffer is sized for the realistic bound (2 n + 64 per block: the stripes' own); a call beyond it (adversarial
+        // input: up to 16 n) is encoded again, alone, with the room it asked for.
+        auto redo = [&]() -> int {
+            HIPCHK(ctx, hipDeviceSynchronize());   // (the other jobs' kernels: their outputs are complete afterwards, their status words in pinned memory)
+            ENSURE(ctx, h.d_out, (size_t)h.total);
+            h.dcap = (size_t)h.total;
+            ParsedSpec ps;
+            int rc = parse_spec(&h.spec, ps);
+            if (rc) return rc;
+            const int slot = submit_pipelines(ctx, ps, (uint32_t)h.nb, h.block_size, h.n) ? h.djob : 0;
+            rc = encode_core(ctx, jobref(ctx, slot), &h.spec, (const uint8_t *)h.d_in.p, h.n, h.block_size, (uint8_t *)h.d_out.p, h.dcap,
+                             (uint32_t *)h.d_lens.p, (uint64_t *)h.d_total.p, ctx->stream);
+            if (rc) return rc;
+            return read_total();
+        };
+        h.rc = redo();
+    }
+}
+
+static int host_submit_core(w3_ctx *ctx, const w3_model_spec *spec, const ParsedSpec &ps, const uint8_t *in, size_t n, size_t block_size,
+                            uint8_t *out, size_t out_cap, uint32_t *block_lens, int *hjob) {
+    int rc = host_streams(ctx);
+    if (rc) return rc;
+    const size_t nb = (n + block_size - 1) / block_size;
+    int busy = 0, slot = -1;
+    for (int k = 0; k < W3_MAX_HOST_JOBS; k++) {
+        if (ctx->hj[k].state != 0) busy++;
+        else if (slot < 0) slot = k;
+    }
+    const int depth = host_depth(spec, n, block_size);
+    if (busy >= depth || slot < 0) {
+        ctx->err = std::to_string(busy) + " host-buffer jobs are in flight already (at most " + std::to_string(depth) + " for an input of this size): w3_encode_host_wait the oldest one first";
+        return W3_E_INVALID;
+    }
+    HostJob &h = ctx->hj[slot];
+    h.spec = *spec;   // (the spec and its HuffHistory tables are the caller's memory)
+    if (ps.n_huff) { memcpy(h.huff_copy, ps.huff, sizeof(w3_huff_table) * ps.n_huff); h.spec.huff = h.huff_copy; }
+    h.n = n; h.block_size = block_size; h.nb = nb; h.out = out; h.out_cap = out_cap; h.block_lens = block_lens;
+    h.djob = -1; h.rc = W3_OK; h.total = 0;
+    memset(&h.tm, 0, sizeof h.tm);
+    // the device output buffer: the realistic bound, never more than the hard one (a call beyond it is redone: host_finish_device)
+    h.dcap = std::min<size_t>(w3_max_compressed_size(n, block_size), 2 * n + 64 * nb + 64);
+    ENSURE(ctx, h.d_in, std::max<size_t>(n, 16));
+    ENSURE(ctx, h.d_out, std::max<size_t>(h.dcap, 16));
+    ENSURE(ctx, h.d_lens, std::max<size_t>(nb * 4, 16));
+    ENSURE(ctx, h.d_total, 8);
+    HIPCHK(ctx, hipMemcpyAsync(h.d_in.p, in, n, hipMemcpyHostToDevice, ctx->s_h2d));
+    h.seq = ++ctx->hseq;
+    h.state = 1;
+    host_start_pending(ctx);
+    *hjob = slot;
+    return W3_OK;
+}
+
+// out / out_cap: where the streams go (w3_encode_blocks binds a chunk's destination only now: it is the sum of the earlier chunks'
+// sizes).  *out_len is set even on W3_E_NOSPACE; the length table is copied in either case.
+static int host_wait_core(w3_ctx *ctx, int hjob, uint8_t *out, size_t out_cap, size_t *out_len) {
+    HostJob &h = ctx->hj[hjob];
+    // jobs are encoded in the order they were submitted: whatever is older goes through the device first
+    while (h.state == 1 || h.state == 2) {
+        HostJob *o = nullptr;
+        for (auto &x : ctx->hj)
+            if (x.state == 2 && (!o || x.seq < o->seq)) o = &x;
+        if (o) host_finish_device(ctx, *o);
+        const int before = h.state;
+        host_start_pending(ctx);   // FIRST: the next call's kernels reach the GPU before this call's streams start travelling back
+        if (!o && h.state == before) { h.state = 0; ctx->err = "host-buffer job could not be submitted (internal error)"; return W3_E_HIP; }
+    }
+    int rc = h.rc;
+    *out_len = (size_t)h.total;
+    if (rc == W3_OK || rc == W3_E_NOSPACE) {
+        auto fetch = [&]() -> int {
+            if (h.nb && h.block_lens) HIPCHK(ctx, hipMemcpyAsync(h.block_lens, h.d_lens.p, h.nb * 4, hipMemcpyDeviceToHost, ctx->s_d2h));
+            const bool fits = rc == W3_OK && h.total <= out_cap && (out || !h.total);
+            if (fits && h.total) HIPCHK(ctx, hipMemcpyAsync(out, h.d_out.p, (size_t)h.total, hipMemcpyDeviceToHost, ctx->s_d2h));
+            HIPCHK(ctx, hipEventRecord(h.ev_d2h, ctx->s_d2h));
+            HIPCHK(ctx, hipEventSynchronize(h.ev_d2h));
+            if (!fits) { if (rc == W3_OK) ctx->err = "out_cap too small"; return W3_E_NOSPACE; }
+            return W3_OK;
+        };
+        rc = fetch();
+    }
+    ctx->timing = h.tm;
+    h.state = 0;
+    return rc;
+}
+
+extern "C" int w3_encode_host_max_in_flight(const w3_model_spec *spec, size_t n, size_t block_size) {
+    if (!block_size || (spec && w3_spec_validate(spec))) return 0;
+    return host_depth(spec, n, block_size);
+}
+
+extern "C" int w3_encode_host_submit(w3_ctx *ctx, const w3_model_spec *spec, const uint8_t *in, size_t n, size_t block_size,
+                                     uint8_t *out, size_t out_cap, uint32_t *block_lens, int *hjob) {
+    if (!ctx || !hjob) return W3_E_INVALID;
+    *hjob = -1;
+    int rc = check_args(ctx, n, block_size);
+    if (rc) return rc;
+    ParsedSpec ps;
+    if ((rc = parse_spec(spec, ps))) { ctx->err = "malformed model spec"; return rc; }
+    if (n == 0 || !in || !block_lens) { ctx->err = "w3_encode_host_submit needs input and a length table"; return W3_E_INVALID; }
+    for (const auto &st : ctx->js)   // (the two levels are not mixed: the host jobs count the device job slots as theirs)
+        if (st.state != 0) {
+            bool ours = false;
+            for (const auto &h : ctx->hj) ours |= h.state == 2 && &ctx->js[h.djob] == &st;
+            if (!ours) { ctx->err = "w3_encode_submit jobs are in flight on this context: w3_encode_wait them first"; return W3_E_INVALID; }
+        }
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    return host_submit_core(ctx, spec, ps, in, n, block_size, out, out_cap, block_lens, hjob);
+}
+
+extern "C" int w3_encode_host_wait(w3_ctx *ctx, int hjob, size_t *out_len) {
+    if (!ctx || !out_len || hjob < 0 || hjob >= W3_MAX_HOST_JOBS) return W3_E_INVALID;
+    *out_len = 0;
+    if (ctx->hj[hjob].state == 0) { ctx->err = "no such host-buffer job in flight"; return W3_E_INVALID; }
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    return host_wait_core(ctx, hjob, ctx->hj[hjob].out, ctx->hj[hjob].out_cap, out_len);
 }
 
 // ---------------------------------------------------------------------------
@@ -1114,8 +1359,8 @@ extern "C" int w3_encode_stats_device(w3_ctx *ctx, const w3_model_spec *spec, co
     if (nb == 0) return w3_spec_validate(spec);
     if (!d_in || !d_block_bits) return W3_E_INVALID;
     HIPCHK(ctx, hipSetDevice(ctx->device));
-    ENSURE(ctx, ctx->lens, nb * 4);
     if ((rc = jobs_idle(ctx))) return rc;
+    ENSURE(ctx, ctx->lens, nb * 4);
     rc = encode_core(ctx, jobref(ctx, 0), spec, d_in, n, block_size, nullptr, 0, (uint32_t *)ctx->lens.p, nullptr, stream);
     if (rc) return rc;
     hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
@@ -1131,10 +1376,10 @@ extern "C" int w3_encode_stats(w3_ctx *ctx, const w3_model_spec *spec, const uin
     if (nb == 0) return w3_spec_validate(spec);
     if (!in || !block_bits) return W3_E_INVALID;
     HIPCHK(ctx, hipSetDevice(ctx->device));
+    if ((rc = jobs_idle(ctx))) return rc;
     ENSURE(ctx, ctx->io_in, n);
     ENSURE(ctx, ctx->lens, nb * 4);
     HIPCHK(ctx, hipMemcpyAsync(ctx->io_in.p, in, n, hipMemcpyHostToDevice, ctx->stream));
-    if ((rc = jobs_idle(ctx))) return rc;
     rc = encode_core(ctx, jobref(ctx, 0), spec, (const uint8_t *)ctx->io_in.p, n, block_size, nullptr, 0, (uint32_t *)ctx->lens.p, nullptr, ctx->stream);
     if (rc) return rc;
     HIPCHK(ctx, hipMemcpy(block_bits, ctx->bits.p, nb * 4, hipMemcpyDeviceToHost));
@@ -1145,6 +1390,7 @@ extern "C" int w3_decode_blocks_device(w3_ctx *ctx, const w3_model_spec *spec, c
                                        size_t nblocks, size_t block_size, uint64_t orig_len, uint8_t *d_out, void *stream) {
     int rc = check_args(ctx, (size_t)orig_len, block_size);
     if (rc) return rc;
+    if ((rc = jobs_idle(ctx))) return rc;   // (job 0's HuffHistory tables, length scan and model tables)
     ParsedSpec ps;
     if ((rc = parse_spec(spec, ps))) { ctx->err = "malformed model spec"; return rc; }
     const uint64_t nb = (orig_len + block_size - 1) / block_size;
@@ -1173,6 +1419,23 @@ extern "C" int w3_decode_blocks_device(w3_ctx *ctx, const w3_model_spec *spec, c
 // ---------------------------------------------------------------------------
 // host-buffer entry points
 // ---------------------------------------------------------------------------
+// How a host-buffer call is cut into pipelined pieces (whole blocks each).  The pieces are calls of w3_encode_host_submit, so piece
+// k+1's input travels while piece k is encoded and piece k-1's streams travel back; what a single call cannot hide is its first
+// piece's H2D and its last piece's coder chain (8 x block_size dependent steps per lane whatever the block count) and D2H.
+//   - calls that w3_encode_submit would run synchronously (lane-per-block specs, slot leaves on hash maps in HBM): one piece — they
+//     take hundreds of milliseconds per GB, PCIe is a few percent of that;
+//   - up to W3_FREE_RUN4_BLOCKS blocks: one piece (four coders of such pieces overlap, but one call has only one);
+//   - beyond: pieces of at most W3_FREE_RUN4_BLOCKS blocks, equal in size — the four-in-flight regime of DESIGN.md 2.8
+//     (measured at 1e9 B from pinned memory, tools/host_api_rate.py: DESIGN.md section 5).
+// W3_OPT_HOST_CHUNK_BLOCKS overrides the piece size (tests: ragged pieces; measurements).
+static size_t host_chunk_blocks(const w3_ctx *ctx, const ParsedSpec &ps, size_t nb, size_t block_size, size_t n) {
+    if (!submit_pipelines(ctx, ps, (uint32_t)nb, block_size, n)) return nb;
+    if (ctx->host_chunk_blocks) return std::min<size_t>(nb, ctx->host_chunk_blocks);
+    if (nb <= W3_FREE_RUN4_BLOCKS) return nb;
+    const size_t pieces = (nb + W3_FREE_RUN4_BLOCKS - 1) / W3_FREE_RUN4_BLOCKS;
+    return (nb + pieces - 1) / pieces;
+}
+
 extern "C" int w3_encode_blocks(w3_ctx *ctx, const w3_model_spec *spec, const uint8_t *in, size_t n, size_t block_size, uint8_t *out,
                                 size_t out_cap, size_t *out_len, uint32_t *block_lens) {
     int rc = check_args(ctx, n, block_size);
@@ -1181,24 +1444,52 @@ extern "C" int w3_encode_blocks(w3_ctx *ctx, const w3_model_spec *spec, const ui
     const size_t nb = (n + block_size - 1) / block_size;
     if (nb == 0) return w3_spec_validate(spec);
     if (!in || !block_lens || !out_len) return W3_E_INVALID;
+    if ((rc = jobs_idle(ctx))) return rc;
+    ParsedSpec ps;
+    if ((rc = parse_spec(spec, ps))) { ctx->err = "malformed model spec"; return rc; }
     HIPCHK(ctx, hipSetDevice(ctx->device));
-    hipStream_t s = ctx->stream;
-    // device output capacity: what the caller can take, but never more than the hard bound
-    size_t dcap = std::min(out_cap, w3_max_compressed_size(n, block_size));
-    ENSURE(ctx, ctx->io_in, n);
-    ENSURE(ctx, ctx->io_out, std::max<size_t>(dcap, 16));
-    ENSURE(ctx, ctx->lens, nb * 4);
-    ENSURE(ctx, ctx->total, 8);
-    HIPCHK(ctx, hipMemcpyAsync(ctx->io_in.p, in, n, hipMemcpyHostToDevice, s));
-    rc = w3_encode_blocks_device(ctx, spec, (const uint8_t *)ctx->io_in.p, n, block_size, (uint8_t *)ctx->io_out.p, dcap,
-                                 (uint32_t *)ctx->lens.p, (uint64_t *)ctx->total.p, s);
-    if (rc && rc != W3_E_NOSPACE) return rc;
-    uint64_t total = 0;
-    HIPCHK(ctx, hipMemcpy(&total, ctx->total.p, 8, hipMemcpyDeviceToHost));
-    *out_len = (size_t)total;
-    HIPCHK(ctx, hipMemcpy(block_lens, ctx->lens.p, nb * 4, hipMemcpyDeviceToHost));
-    if (rc == W3_E_NOSPACE || total > out_cap || !out) return W3_E_NOSPACE;
-    HIPCHK(ctx, hipMemcpy(out, ctx->io_out.p, (size_t)total, hipMemcpyDeviceToHost));
+    const size_t cb = host_chunk_blocks(ctx, ps, nb, block_size, n);
+    // The pieces in flight, oldest first.  A piece's streams go to `out` at the sum of the earlier pieces' sizes, known when it is
+    // waited for; once the caller's buffer is full the later pieces are still encoded (*out_len must hold the size needed) but
+    // only their length tables are fetched.
+    int q[W3_MAX_HOST_JOBS], qn = 0;
+    size_t off = 0;
+    int first_err = W3_OK;
+    w3_timing sum;
+    memset(&sum, 0, sizeof sum);
+    auto wait_oldest = [&]() {
+        const int hjob = q[0];
+        for (int k = 1; k < qn; k++) q[k - 1] = q[k];
+        qn--;
+        size_t len = 0;
+        const bool room = first_err == W3_OK && out && off <= out_cap;
+        const int r = host_wait_core(ctx, hjob, room ? out + off : nullptr, room ? out_cap - off : 0, &len);
+        off += len;
+        if (r != W3_OK && first_err == W3_OK) first_err = r;
+        const w3_timing &t = ctx->timing;
+        sum.predict_ms += t.predict_ms; sum.coder_ms += t.coder_ms; sum.pack_ms += t.pack_ms; sum.generic_ms += t.generic_ms; sum.total_ms += t.total_ms;
+        sum.apm_ms += t.apm_ms; sum.slot_ms += t.slot_ms; sum.achash_ms += t.achash_ms; sum.small_ms += t.small_ms;
+        for (int w = 0; w < 4; w++) { sum.part_ms[w] += t.part_ms[w]; sum.rank_ms[w] += t.rank_ms[w]; }
+        sum.path = t.path; sum.n_wide = t.n_wide; sum.n_parts += 1;
+        sum.n_coder_launches += t.n_coder_launches; sum.coder_bytes += t.coder_bytes; sum.predict_bytes += t.predict_bytes;
+        sum.n_recoded_blocks += t.n_recoded_blocks; sum.n_slot_launches += t.n_slot_launches; sum.n_lds_faults += t.n_lds_faults;
+    };
+    for (size_t b0 = 0; b0 < nb; b0 += cb) {
+        const size_t lo = b0 * block_size, hi = std::min(n, (b0 + cb) * block_size);
+        // (an error that is not "out of room" ends the call: nothing more is submitted, what is in flight is drained below)
+        if (first_err != W3_OK && first_err != W3_E_NOSPACE) break;
+        while (qn >= host_depth(spec, hi - lo, block_size)) wait_oldest();
+        if (first_err != W3_OK && first_err != W3_E_NOSPACE) break;
+        int hjob = -1;
+        rc = host_submit_core(ctx, spec, ps, in + lo, hi - lo, block_size, nullptr, 0, block_lens + b0, &hjob);
+        if (rc) { if (first_err == W3_OK) first_err = rc; break; }
+        q[qn++] = hjob;
+    }
+    while (qn) wait_oldest();
+    ctx->timing = sum;
+    if (first_err != W3_OK && first_err != W3_E_NOSPACE) return first_err;
+    *out_len = off;
+    if (first_err == W3_E_NOSPACE || off > out_cap || !out) { ctx->err = "out_cap too small"; return W3_E_NOSPACE; }
     return W3_OK;
 }
 
@@ -1206,6 +1497,7 @@ extern "C" int w3_decode_blocks(w3_ctx *ctx, const w3_model_spec *spec, const ui
                                 size_t block_size, uint64_t orig_len, uint8_t *out) {
     int rc = check_args(ctx, (size_t)orig_len, block_size);
     if (rc) return rc;
+    if ((rc = jobs_idle(ctx))) return rc;
     if (nblocks == 0 && orig_len == 0) return w3_spec_validate(spec);
     if (!in || !block_lens || !out) return W3_E_INVALID;
     HIPCHK(ctx, hipSetDevice(ctx->device));
@@ -1307,6 +1599,20 @@ static ShardComms *shard_comms(const std::vector<int> &devs, std::string &err) {
     return c;
 }
 
+extern "C" int w3_rccl_library(const char *path) {
+    std::lock_guard<std::mutex> lk(g_comm_mu);
+    if (w3rccl::resolved()) return W3_E_INVALID;   // (the library is resolved once per process, at the first gather or status call)
+    w3rccl::library_override() = path ? path : "";
+    return W3_OK;
+}
+
+extern "C" int w3_rccl_status(char *msg, size_t cap) {
+    w3rccl::Api *r;
+    { std::lock_guard<std::mutex> lk(g_comm_mu); r = w3rccl::api(); }
+    if (msg && cap) { snprintf(msg, cap, "%s", r->error.empty() ? "RCCL resolved" : r->error.c_str()); }
+    return r->error.empty() ? W3_OK : W3_E_HIP;
+}
+
 extern "C" int w3_encode_blocks_sharded_device(w3_ctx *const *ctxs, int n_ctx, const w3_model_spec *spec, const uint8_t *const *d_in, const size_t *n,
                                                size_t block_size, int root, uint8_t *d_out, size_t out_cap, uint32_t *d_block_lens,
                                                uint64_t *totals, int transport) {
@@ -1375,20 +1681,26 @@ extern "C" int w3_encode_blocks_sharded_device(w3_ctx *const *ctxs, int n_ctx, c
 
     w3_ctx *rt = ctxs[root];
     HIPCHK(rt, hipSetDevice(rt->device));
-    // 2. the sizes: with RCCL an all-gather of every rank's total (the exchange step's first half, exercised even with one rank)
+    // 2. the sizes: with RCCL an all-gather of every rank's total (the exchange step's first half, exercised even with one rank).
+    // Nothing between ncclGroupStart and ncclGroupEnd may leave this function: an open group would swallow every later RCCL call of
+    // this thread.  So whatever can fail for other reasons (allocations, memsets) is done first, and inside a group only RCCL's own
+    // return codes are collected.
     if (use_rccl) {
         w3rccl::Api *rc_api = w3rccl::api();
-        std::vector<DevBuf *> gathered(n_ctx);
-        int gs = rc_api->GroupStart();
-        for (int r = 0; r < n_ctx && gs == w3rccl::kSuccess; r++) {
+        for (int r = 0; r < n_ctx; r++) {
             w3_ctx *c = ctxs[r];
             HIPCHK(c, hipSetDevice(c->device));
             ENSURE(c, c->total, 8);                          // (holds this rank's total already when the shard was not empty)
             if (!nbs[r]) HIPCHK(c, hipMemsetAsync(c->total.p, 0, 8, c->stream));
             ENSURE(c, c->misc, 8 * (size_t)n_ctx);
-            gs = rc_api->AllGather(c->total.p, c->misc.p, 1, w3rccl::kUint64, cm->comms[r], c->stream);
         }
-        const int ge = rc_api->GroupEnd();
+        int gs = rc_api->GroupStart();
+        const bool opened = gs == w3rccl::kSuccess;
+        for (int r = 0; r < n_ctx && gs == w3rccl::kSuccess; r++) {
+            (void)hipSetDevice(ctxs[r]->device);   // (a communicator knows its device; set for RCCL versions that look at the current one)
+            gs = rc_api->AllGather(ctxs[r]->total.p, ctxs[r]->misc.p, 1, w3rccl::kUint64, cm->comms[r], ctxs[r]->stream);
+        }
+        const int ge = opened ? rc_api->GroupEnd() : w3rccl::kSuccess;
         if (gs != w3rccl::kSuccess || ge != w3rccl::kSuccess) { ctxs[0]->err = std::string("ncclAllGather: ") + rc_api->GetErrorString(gs != w3rccl::kSuccess ? gs : ge); return W3_E_HIP; }
         std::vector<uint64_t> seen(n_ctx);
         HIPCHK(rt, hipSetDevice(rt->device));
@@ -1404,24 +1716,30 @@ extern "C" int w3_encode_blocks_sharded_device(w3_ctx *const *ctxs, int n_ctx, c
     // 3. the streams and length tables to the root, at the exclusive scan of the totals / block counts
     if (use_rccl) {
         w3rccl::Api *rc_api = w3rccl::api();
+        HIPCHK(rt, hipSetDevice(rt->device));
+        {   // the root's own shard: a device copy, outside the group
+            uint64_t so = 0; size_t lo = 0;
+            for (int r = 0; r < root; r++) { so += totals[r]; lo += nbs[r]; }
+            if (totals[root]) HIPCHK(rt, hipMemcpyAsync(d_out + so, rt->io_out.p, (size_t)totals[root], hipMemcpyDeviceToDevice, rt->stream));
+            if (nbs[root]) HIPCHK(rt, hipMemcpyAsync(d_block_lens + lo, rt->lens.p, nbs[root] * 4, hipMemcpyDeviceToDevice, rt->stream));
+        }
         int gs = rc_api->GroupStart();
+        const bool opened = gs == w3rccl::kSuccess;
         uint64_t so = 0; size_t lo = 0;
-        for (int r = 0; r < n_ctx && gs == w3rccl::kSuccess; r++) {
+        for (int r = 0; r < n_ctx; r++) {
             w3_ctx *c = ctxs[r];
-            if (r == root) {
-                HIPCHK(rt, hipSetDevice(rt->device));
-                if (totals[r]) HIPCHK(rt, hipMemcpyAsync(d_out + so, c->io_out.p, (size_t)totals[r], hipMemcpyDeviceToDevice, rt->stream));
-                if (nbs[r]) HIPCHK(rt, hipMemcpyAsync(d_block_lens + lo, c->lens.p, nbs[r] * 4, hipMemcpyDeviceToDevice, rt->stream));
-            } else if (nbs[r]) {
+            if (r != root && nbs[r] && gs == w3rccl::kSuccess) {
+                (void)hipSetDevice(c->device);
                 // seven peers each have their own xGMI link to the root: the transfers of one group run concurrently
                 gs = rc_api->Send(c->io_out.p, (size_t)totals[r], w3rccl::kUint8, root, cm->comms[r], c->stream);
-                if (gs == w3rccl::kSuccess) gs = rc_api->Recv(d_out + so, (size_t)totals[r], w3rccl::kUint8, r, cm->comms[root], rt->stream);
                 if (gs == w3rccl::kSuccess) gs = rc_api->Send(c->lens.p, nbs[r] * 4, w3rccl::kUint8, root, cm->comms[r], c->stream);
+                (void)hipSetDevice(rt->device);
+                if (gs == w3rccl::kSuccess) gs = rc_api->Recv(d_out + so, (size_t)totals[r], w3rccl::kUint8, r, cm->comms[root], rt->stream);
                 if (gs == w3rccl::kSuccess) gs = rc_api->Recv(d_block_lens + lo, nbs[r] * 4, w3rccl::kUint8, r, cm->comms[root], rt->stream);
             }
             so += totals[r]; lo += nbs[r];
         }
-        const int ge = rc_api->GroupEnd();
+        const int ge = opened ? rc_api->GroupEnd() : w3rccl::kSuccess;
         if (gs != w3rccl::kSuccess || ge != w3rccl::kSuccess) { ctxs[0]->err = std::string("RCCL gather: ") + rc_api->GetErrorString(gs != w3rccl::kSuccess ? gs : ge); return W3_E_HIP; }
         for (int r = 0; r < n_ctx; r++) {
             HIPCHK(ctxs[r], hipSetDevice(ctxs[r]->device));
@@ -1526,6 +1844,7 @@ extern "C" int w3_sweep_ordern_device(w3_ctx *ctx, const uint8_t *d_in, size_t n
                                       size_t ncfg, uint32_t *block_bits) {
     int rc = check_args(ctx, n, block_size);
     if (rc) return rc;
+    if ((rc = jobs_idle(ctx))) return rc;
     const uint32_t nb = (uint32_t)((n + block_size - 1) / block_size);
     if (nb == 0 || ncfg == 0) return W3_OK;
     if (!d_in || !bits || !aligns || !block_bits || ncfg > 4096) return W3_E_INVALID;
@@ -1579,6 +1898,7 @@ extern "C" int w3_sweep_ordern(w3_ctx *ctx, const uint8_t *in, size_t n, size_t 
                                size_t ncfg, uint32_t *block_bits) {
     int rc = check_args(ctx, n, block_size);
     if (rc) return rc;
+    if ((rc = jobs_idle(ctx))) return rc;
     if (n == 0 || ncfg == 0) return W3_OK;
     if (!in) return W3_E_INVALID;
     HIPCHK(ctx, hipSetDevice(ctx->device));
@@ -1595,8 +1915,9 @@ extern "C" int w3_sweep_ordern(w3_ctx *ctx, const uint8_t *in, size_t n, size_t 
 extern "C" int w3_export_counters(w3_ctx *ctx, const w3_model_spec *spec, const uint8_t *in, size_t n, uint32_t *counters) {
     if (!ctx || !counters) return W3_E_INVALID;
     ParsedSpec ps;
-    int rc = parse_spec(spec, ps);
+    int rc = jobs_idle(ctx);
     if (rc) return rc;
+    if ((rc = parse_spec(spec, ps))) return rc;
     if (ps.n_leaves != 1 || ps.n_apm || ps.has_slot || ps.leaf[0].frozen) { ctx->err = "w3_export_counters takes ONE adaptive Counter-table leaf"; return W3_E_UNSUPPORTED; }
     const w3_node &nd = ps.leaf[0];
     if (nd.bits > 28) { ctx->err = "tables above 2^28 counters are not exported"; return W3_E_UNSUPPORTED; }
@@ -1647,6 +1968,7 @@ extern "C" int w3_huff_tables(const uint8_t *buf, size_t n, uint8_t huff_size, u
 extern "C" int w3_predict_blocks(w3_ctx *ctx, const w3_model_spec *spec, const uint8_t *in, size_t n, size_t block_size, uint16_t *p_out) {
     int rc = check_args(ctx, n, block_size);
     if (rc) return rc;
+    if ((rc = jobs_idle(ctx))) return rc;   // (the predict phase runs on job 0's workspace)
     ParsedSpec ps;
     if ((rc = parse_spec(spec, ps))) return rc;
     if (n == 0) return W3_OK;
