@@ -35,9 +35,14 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-# more hardware queues than HIP's default 4 per priority level, so that the streams of one context (launch, side, verification,
-# the two pipeline stages) do not share one and serialise; must be in the environment before the HIP runtime initialises
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+# The library asks nothing of the environment (its pipeline stages use streams of different priority levels, which HIP maps to
+# different hardware queues: INTEGRATION.md).  --hw-queues N sets GPU_MAX_HW_QUEUES=N for THIS run (it must be in the environment before
+# the HIP runtime initialises, hence the early look at argv); whatever is in effect is recorded in config.gpu_max_hw_queues.
+for _i, _a in enumerate(sys.argv):
+    if _a == "--hw-queues" and _i + 1 < len(sys.argv) and int(sys.argv[_i + 1]) > 0:
+        os.environ["GPU_MAX_HW_QUEUES"] = sys.argv[_i + 1]
+    elif _a.startswith("--hw-queues=") and int(_a.split("=")[1]) > 0:
+        os.environ["GPU_MAX_HW_QUEUES"] = _a.split("=")[1]
 
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
 NSETS = 4                # output buffer sets of a regime = the deepest submit / wait pipeline (W3_MAX_JOBS)
@@ -226,13 +231,16 @@ def parse_args(argv=None):
     ap.add_argument("--coder", default="x4", help="two-phase coder kernel: x4 (default; pipelined and half-CU runs use x5 in its place) | x5 | x3 | x2 | fast | robust")
     ap.add_argument("--variant", default="", help="experiments: comma-separated W3_OPT_VARIANT names (Context.set_variant), e.g. no_side_stream, half_cu, full_cu")
     ap.add_argument("--tune", type=int, default=0, help="W3_OPT_TUNE bit mask (scheduling experiments)")
+    ap.add_argument("--verify", type=int, default=1, help="W3_OPT_VERIFY: v / 256 of the blocks are re-predicted with ballot rounds per call (1 = default sample)")
     ap.add_argument("--no-verify", action="store_true", help="switch W3_OPT_VERIFY off (sampled ballot-round re-prediction of every predict phase; on by default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ref-model", action="store_true", help="skip the extra order012 measurement (the largest model whose streams are entirely the reference's)")
     ap.add_argument("--no-decode", action="store_true", help="skip the device round trip of the last step's whole output")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the 3-step runs of BASELINE configs[2] / configs[4]")
-    ap.add_argument("--quick", action="store_true", help="= --no-cpu-baseline --no-ref-model --no-decode --no-other-configs (profiling runs)")
+    ap.add_argument("--quick", action="store_true", help="= --no-cpu-baseline --no-ref-model --no-decode --no-other-configs --no-host-path (profiling runs)")
     ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--hw-queues", type=int, default=0, help="GPU_MAX_HW_QUEUES for this run (0 = leave the environment alone: HIP's default of 4 per priority level)")
+    ap.add_argument("--no-host-path", action="store_true", help="skip the PCIe-inclusive legs (host_path: w3_encode_blocks / w3_encode_host_submit from pinned and pageable memory)")
     ap.add_argument("--force-exchange", action="store_true", help="run the RCCL exchange step even with 1 rank (rehearsal)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL over xGMI, one GPU per rank (the measured path).  gloo = REHEARSAL of the multi-rank control flow on a box with "
@@ -240,7 +248,7 @@ def parse_args(argv=None):
                          "memory; its numbers mean nothing")
     a = ap.parse_args(argv)
     if a.quick:
-        a.no_cpu_baseline = a.no_ref_model = a.no_decode = a.no_other_configs = True
+        a.no_cpu_baseline = a.no_ref_model = a.no_decode = a.no_other_configs = a.no_host_path = True
     return a
 
 
@@ -390,8 +398,15 @@ def kernel_table(model, n, bs, steps, acc, coder_name):
     if napm >= 1:
         rows.append(("k_apm0<%d> (APM stage: two wavefronts per block, table in LDS)%s" % (L, "" if napm == 1 else " + k_apm1 (ORDER1 stage) + k_mix"),
                      per("apm_ms"), n * (16 * L + 1 + 16) + (napm - 1) * n * (8 + 16 + 16)))
-    if nslot:
-        rows.append(("k_slot (slot-state leaves: lane per block, hash map in HBM; all batches of a step)", per("slot_ms"), nslot * n * (1 + 16 + 2 * 192)))
+    if nslot and acc.get("slot_ms", 0) > 0:
+        if acc.get("n_slot_launches", 0) > 0:
+            # the table walk: per leaf and input byte 1 (input) + 16 (stream) + 2 nibbles x (96 B of Cell read + 96 B written) — SURVEY section 8(d)
+            rows.append(("k_slot (slot-state leaves: lane per block, hash map in HBM; all batches of a step)", per("slot_ms"), nslot * n * (1 + 16 + 2 * 192)))
+        else:
+            # the sorted replay (w3_slot2.h; NO table in HBM): per leaf and input byte 1 (input) + 2 nibble events x (8 B record written by
+            # k_slot_events, two 8-bit sort passes of 8 read + 8 written each (2^14 Cells), 8 read and 8 written by k_slot_replay)
+            rows.append(("k_slot_events + k_slot_sort<0|1> + k_slot_replay (slot-state leaves: events sorted by Cell, replayed with the open Cell in LDS; no table in HBM)",
+                         per("slot_ms"), nslot * n * (1 + 2 * (8 + 32 + 8 + 8))))
     if acc.get("achash_ms", 0) > 0:   # ACHistory leaves: one byte read + 8 key bytes written per input byte (+ the 8 MiB prefix table)
         rows.append(("k_achash (ACHistory keys of every step, 16-bit prefix table)", per("achash_ms"), n * 9 + (8 << 20)))
     for w in range(int(acc.get("n_wide", 0))):
@@ -412,7 +427,7 @@ def kernel_table(model, n, bs, steps, acc, coder_name):
 def lookup_traffic(model, n, bs, kernel_name):
     """PMC-measured HBM bytes per launch of this kernel for this exact config: NOT measured in this run — separate rocprofv3 --pmc
     passes (FETCH_SIZE doubled per the gfx950 note + WRITE_SIZE), kept under profiles/ and looked up here."""
-    for fn in ("r3_traffic.json", "r2_traffic.json", "r1_traffic.json"):
+    for fn in ("r4_traffic.json", "r3_traffic.json", "r2_traffic.json", "r1_traffic.json"):
         try:
             for tj in json.load(open(os.path.join(ROOT, "profiles", fn)))["entries"]:
                 if tj["config"] == {"model": model, "bytes_per_gpu": n, "block_size": bs} and kernel_name.startswith(tj["kernel"]):
@@ -483,7 +498,7 @@ def main():
     ctx = w3.Context(local_rank)
     ctx.set_path(args.path)
     ctx.set_coder(args.coder)
-    ctx.set_verify(not args.no_verify)
+    ctx.set_verify(0 if args.no_verify else args.verify)
     ctx.set_tune(args.tune)
     if args.variant:
         ctx.set_variant(*args.variant.split(","))
@@ -528,6 +543,8 @@ def main():
             sync_line = {"value": round(n * 3 / dts / 2**20, 2), "unit": "MiB/s", "ms_per_step": round(dts / 3 * 1e3, 3),
                          "kernel_ms_per_step": {k: round(accs.get(k, 0.0) / 3, 3) for k in ("predict_ms", "apm_ms", "coder_ms", "pack_ms")},
                          "note": "w3_encode_blocks_device, one call at a time (k_coder_x4, full kernel shapes)"}
+            if int(accs.get("path", 0)) == 2:
+                sync_line["_rows"] = kernel_table(args.model, n, bs, 3, accs, "x4" if args.coder == "x4" else args.coder)
         if not args.no_ref_model and args.model != "order012" and args.data == "text":
             # the largest model whose streams are entirely the reference's (no build-defined node): same input, 3 steps, outside the
             # timed region (the main model's outputs are kept aside for the checks first)
@@ -584,6 +601,25 @@ def main():
             dctx.close()
             torch.cuda.empty_cache()
 
+    host_path = None
+    if extras and not args.no_host_path:
+        # PCIe-inclusive ("report H2D/D2H separately"; never part of `value`): the same input from HOST memory —
+        # compress() of main.rs:89-113 is file in, file out.  tools/host_api_rate.py, on a context of its own.
+        try:
+            from tools import host_api_rate
+            hp = host_api_rate.measure(args.model, n, bs, chunks=(0,), calls=max(4, min(args.steps, 8)), pageable=True, resident=False, host=host, log=lambda *_: None)
+            host_path = {"calls_in_flight_pinned_MiBps": hp["in_flight_pinned"]["MiBps"], "calls_in_flight_pinned_ms_per_call": hp["in_flight_pinned"]["ms_per_call"],
+                         "calls_in_flight": hp["in_flight_pinned"]["calls_in_flight"],
+                         "one_call_pinned_MiBps": hp["sync_pinned"][0]["MiBps"], "one_call_pinned_ms": hp["sync_pinned"][0]["ms_per_call"], "one_call_pieces": hp["sync_pinned"][0]["pieces"],
+                         "one_call_pageable_MiBps": hp.get("sync_pageable", {}).get("MiBps"), "one_call_pageable_ms": hp.get("sync_pageable", {}).get("ms_per_call"),
+                         "h2d_pinned_ms": hp["h2d_pinned_ms"], "h2d_pageable_ms": hp.get("h2d_pageable_ms"), "d2h_pinned_ms": hp.get("d2h_pinned_ms"),
+                         "bytes": n, "compressed_ratio": hp.get("compressed_ratio"), "unit": "MiB/s",
+                         "note": "input and output in HOST memory, PCIe both ways inside the timed region; calls_in_flight = w3_encode_host_submit / w3_encode_host_wait "
+                                 "(the next call's H2D and the previous call's D2H overlap this call's encode); one_call = ONE synchronous w3_encode_blocks at a time, "
+                                 "pipelined in pieces inside the call (it cannot hide its first copy in, its last coder chain and its last copy out); outputs byte-identical"}
+        except Exception as e:   # an extra must not lose the main line
+            host_path = {"error": str(e)[:300]}
+
     res = None
     if rank == 0:
         ms_per_step = dt / args.steps * 1e3
@@ -605,6 +641,20 @@ def main():
                           "achieved": round(nbytes / (ms * 1e-3) / 1e9, 2), "frac": round(nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 5),
                           "traffic": tr, "traffic_source": src})
         dom = max(table, key=lambda r: r["avg_launch_ms"])   # the time-dominant kernel
+        # The same choice among the kernels of the ONE-CALL-AT-A-TIME leg (nothing beside any launch): stable from round to round,
+        # where the overlapped pick flips with whatever the pipeline stretches (round 2: k_apm0, round 3: the coder beside the rank kernels).
+        solo = None
+        if sync_line and sync_line.get("_rows"):
+            srows = sync_line.pop("_rows")
+            sname, sms, sbytes = max(srows, key=lambda r: r[1])
+            str_, ssrc = lookup_traffic(args.model, n, bs, sname)
+            solo = {"bound": "hbm", "kernel": sname, "achieved": round(sbytes / (sms * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                    "frac": round(sbytes / (sms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 5), "traffic": str_, "traffic_source": ssrc, "avg_launch_ms": round(sms, 4),
+                    "algorithmic_bytes_per_launch": int(sbytes),
+                    "kernels": [{"kernel": r[0].split(" (")[0], "ms": round(r[1], 3), "frac": round(r[2] / (r[1] * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)} for r in srows],
+                    "chosen_by": "longest average launch of the one-call-at-a-time leg (3 synchronous calls, no other kernel beside any launch)"}
+        elif sync_line:
+            sync_line.pop("_rows", None)
         coder_ms = acc.get("coder_ms", 0.0) / args.steps
         steps_per_lane = 8 * min(bs, max(n, 1))
         readings_txt = {"strong": "ONE stream of %d bytes cut over %d GPU(s)" % (r0["n_global"], world),
@@ -633,14 +683,18 @@ def main():
             "dtype": "u32", "data": "synthetic",
             "config": {"workload": workload, "bytes_per_gpu": n, "bytes_total": n_global, "block_size": bs, "blocks_per_gpu": nb,
                        "context_model": model_name, "path": {1: "generic", 2: "twophase"}.get(path, str(path)), "compressed_ratio": round(ratio, 4),
-                       "encodes_in_flight": pipeline, "exchange": exch, "ranks_seen_by_rccl": dist.get_world_size() if exchange else 1},
+                       "encodes_in_flight": pipeline, "exchange": exch, "ranks_seen_by_rccl": dist.get_world_size() if exchange else 1,
+                       "gpu_max_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES", "unset (HIP default: 4 per priority level)")},
             "roofline": {"bound": "hbm", "kernel": dom["kernel"], "achieved": dom["achieved"], "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": dom["frac"], "traffic": dom["traffic"], "traffic_source": dom["traffic_source"],
                          "avg_launch_ms": dom["avg_launch_ms"], "algorithmic_bytes_per_launch": dom["algorithmic_bytes_per_launch"], "launches_per_step": 1,
                          "chosen_by": "longest average launch among the step's kernels (hipEvents on each kernel's launch stream)",
                          "note": ("with several encodes in flight the coder's launch is stretched by the kernels beside it (one latency chain per lane: %s ms with nothing "
                                   "beside it, floors.coder_floor_ms) — the kernels that own the chip are in roofline_kernels (k_apm0, k_rank_sorted) and whole_step is the step's "
-                                  "algorithmic bytes over its time" % (sync_line["kernel_ms_per_step"]["coder_ms"] if sync_line else "?")) if pipeline >= 2 and "coder" in dom["kernel"] else None},
+                                  "algorithmic bytes over its time" % (sync_line["kernel_ms_per_step"]["coder_ms"] if sync_line else "?")) if pipeline >= 2 and "coder" in dom["kernel"] else None,
+                         "solo": solo,
+                         "kernels": [{"kernel": r["kernel"].split(" (")[0], "ms": r["avg_launch_ms"], "frac": r["frac"]} for r in table]},
+            "roofline_solo": solo,
             "roofline_kernels": table,
             "whole_step": {"algorithmic_bytes": int(sum(r["algorithmic_bytes_per_launch"] for r in table)),
                            "achieved_GBps": round(sum(r["algorithmic_bytes_per_launch"] for r in table) / (ms_per_step * 1e-3) / 1e9, 1),
@@ -665,10 +719,18 @@ def main():
                            "note": "weak reading: every GPU codes its own --size bytes; same K steps, same barriers"}
         if sync_line:
             res["one_call_at_a_time"] = sync_line
+            res["config"]["one_call_at_a_time"] = {"value": sync_line["value"], "unit": "MiB/s", "ms_per_step": sync_line["ms_per_step"]}
         if ref_model:
             res["reference_stream_model"] = ref_model
+            res["reference_stream_model_value"] = ref_model["value"]
+            res["config"]["reference_stream_model"] = {"model": ref_model["model"], "value": ref_model["value"], "unit": "MiB/s", "ms_per_step": ref_model["ms_per_step"],
+                                                       "note": "same input, every node the reference's own (no build-defined APM): these block streams ARE the reference's streams"}
         if decode:
             res["decode"] = decode
+            res["config"]["decode"] = {"value": decode["value"], "unit": "MiB/s", "roundtrip_all_blocks": decode["roundtrip_all_blocks"]}
+        if host_path:
+            res["host_path"] = host_path
+            res["config"]["host_path"] = {k: host_path[k] for k in ("calls_in_flight_pinned_MiBps", "one_call_pinned_MiBps", "one_call_pageable_MiBps", "h2d_pinned_ms", "d2h_pinned_ms") if k in host_path}
 
     if extras and not args.no_other_configs and args.model == "order012apm" and args.data == "text" and args.size >= 100_000_000:
         # BASELINE configs[2] (full CM) at the same size and configs[4]'s shape (Silesia-sized mix, 256 KiB blocks, the hash-map model)

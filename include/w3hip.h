@@ -272,6 +272,23 @@ int w3_encode_blocks_sharded(w3_ctx *const *ctxs, int n_ctx, const w3_model_spec
  * does not link it, and W3_E_HIP with w3_last_error(ctxs[0]) = "RCCL not available ..." is returned when it is missing.
  * Output identical to w3_encode_blocks_device on one context over the concatenated shards.                               */
 enum { W3_GATHER_AUTO = 0, W3_GATHER_RCCL = 1, W3_GATHER_PEER_COPY = 2 };
+/* The same as a STREAM of steps (ABI v8) — the throughput form for a one-process host: every context keeps
+ * w3_encode_sharded_max_in_flight(...) = min over the shards of w3_encode_max_in_flight calls in flight on its device, and a step's
+ * packed streams are gathered when the step is waited for, while the devices are already coding the next steps (at 8 GPUs a 125 MB
+ * shard takes 25.7 ms one call at a time and 12.0 ms with four in flight: DESIGN.md section 5).
+ *   w3_encode_sharded_submit  d_in / n as above; enqueues every shard's encode (w3_encode_submit on its context, into staging buffers
+ *                     of the context) and returns a step handle (0 .. 3).  Inputs must stay valid until the step has been waited
+ *                     for.  W3_E_UNSUPPORTED for specs / shard sizes that w3_encode_submit runs synchronously (use the one-shot call),
+ *                     W3_E_INVALID when w3_encode_sharded_max_in_flight steps are in flight already.
+ *   w3_encode_sharded_wait    completes step sjob's encodes, then the exchange step (as above: sizes all-gather + grouped ncclSend /
+ *                     ncclRecv to ctxs[root]'s d_out / d_block_lens, or device copies) and returns when the streams have landed;
+ *                     totals[r] = compressed bytes of shard r.  Steps may be waited for in any order.
+ * Output identical to w3_encode_blocks_sharded_device's.                                                                       */
+int w3_encode_sharded_submit(w3_ctx *const *ctxs, int n_ctx, const w3_model_spec *spec, const uint8_t *const *d_in, const size_t *n,
+                             size_t block_size, int *sjob);
+int w3_encode_sharded_wait(w3_ctx *const *ctxs, int n_ctx, int sjob, int root, uint8_t *d_out, size_t out_cap, uint32_t *d_block_lens,
+                           uint64_t *totals, int transport);
+int w3_encode_sharded_max_in_flight(const w3_model_spec *spec, const size_t *n, int n_ctx, size_t block_size);
 /* w3_rccl_library: the library to dlopen INSTEAD of the usual sonames ("librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1");
  * only before the first gather or status call of the process (W3_E_INVALID afterwards).  w3_rccl_status resolves RCCL now and
  * reports: W3_OK, or W3_E_HIP with the loader's message in msg ("RCCL not available: ...").  Neither needs a device.          */

@@ -48,14 +48,26 @@ def test_bench_line_contract():
     assert d["floors"]["coder_floor_ms"] > 0 and d["floors"]["bit_steps_per_lane"] == 8 * 65536
     assert d["one_call_at_a_time"]["ms_per_step"] > 0 and d["floors"]["coder_floor_ms"] == d["one_call_at_a_time"]["kernel_ms_per_step"]["coder_ms"]
     assert d["predict_phase"]["algorithmic_bytes_per_step"] == 115 * 6000000          # 3 leaves x 17 B + 2 wide leaves x 32 B of record passes
-    assert d["reference_stream_model"]["value"] > 0
+    assert d["reference_stream_model"]["value"] > 0 and d["reference_stream_model_value"] == d["reference_stream_model"]["value"]
     assert "other_configs" not in d   # (only at enwik8 size and above)
+    # what the driver's record keeps whole is config / roofline / cpu_baseline: the lines a reader must not miss travel there too
+    assert d["config"]["reference_stream_model"]["value"] == d["reference_stream_model"]["value"] and d["config"]["decode"]["roundtrip_all_blocks"] is True
+    assert "unset" in d["config"]["gpu_max_hw_queues"] or d["config"]["gpu_max_hw_queues"] == os.environ.get("GPU_MAX_HW_QUEUES")
+    # the stable pick: longest launch of the one-call-at-a-time leg
+    solo = d["roofline"]["solo"]
+    assert solo == d["roofline_solo"] and solo["avg_launch_ms"] == max(k["ms"] for k in solo["kernels"]) or abs(solo["avg_launch_ms"] - max(k["ms"] for k in solo["kernels"])) < 1e-3
+    assert abs(solo["frac"] - solo["achieved"] / solo["peak"]) < 1e-4 and "k_coder_x4" in " ".join(k["kernel"] for k in solo["kernels"])
+    # PCIe-inclusive legs (never part of value)
+    hp = d["host_path"]
+    assert hp["calls_in_flight_pinned_MiBps"] > 0 and hp["one_call_pinned_MiBps"] > 0 and hp["one_call_pageable_MiBps"] > 0 and hp["h2d_pinned_ms"] > 0 and hp["calls_in_flight"] == 5
+    assert d["config"]["host_path"]["calls_in_flight_pinned_MiBps"] == hp["calls_in_flight_pinned_MiBps"]
 
 
 @pytest.mark.gpu
 def test_bench_readings_models_and_sync_mode():
-    d = run_bench("--scaling", "weak", "--model", "order012", "--quick")
-    assert d["scaling"] == "weak" and d.get("cpu_baseline") is None and "per GPU" in d["config"]["workload"]
+    d = run_bench("--scaling", "weak", "--model", "order012", "--quick", "--hw-queues", "8")
+    assert d["scaling"] == "weak" and d.get("cpu_baseline") is None and "per GPU" in d["config"]["workload"] and d["config"]["gpu_max_hw_queues"] == "8"
+    assert "host_path" not in d
     d = run_bench("--model", "default", "--quick", "--pipeline", "1")
     assert d["config"]["encodes_in_flight"] == 1
     assert "k_achash" in d["roofline"]["kernel"] or "k_coder" in d["roofline"]["kernel"] or "k_predict_small" in d["roofline"]["kernel"]

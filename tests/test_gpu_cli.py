@@ -90,6 +90,31 @@ def test_cli_reference_container_and_directory(cli, tmp_path, oracle):
     assert r.returncode == 0 and (tmp_path / "b.orig").read_bytes() == b
 
 
+def test_cli_directory_with_files_in_flight(cli, tmp_path):
+    """`w3 c <dir>` keeps FILES in flight (w3_encode_host_submit / w3_encode_host_wait: file k+1's input travels and its encode is
+    enqueued while file k is coded): every <name>.bin equals what the one-file-at-a-time path (W3_SERIAL=1) writes, empty and tiny
+    files included, and decompresses to the file."""
+    d = tmp_path / "dir"
+    d.mkdir()
+    files = {"a.txt": markov_text(300000, seed=51), "b.dat": mixed_bytes(150000, seed=52), "c.txt": markov_text(65536 * 3, seed=53),
+             "d.bin": b"", "e.one": b"x", "f.txt": markov_text(70001, seed=54), "g.txt": markov_text(20, seed=55), "h.txt": markov_text(500000, seed=56)}
+    for name, data in files.items():
+        (d / name).write_bytes(data)
+    flight, serial = tmp_path / "flight", tmp_path / "serial"
+    flight.mkdir(); serial.mkdir()
+    r = run(cli, flight, "c", str(d), W3_MODEL="order012apm")
+    assert r.returncode == 0, r.stderr
+    assert r.stdout.count("Compression took") == len(files)
+    r = run(cli, serial, "c", str(d), W3_MODEL="order012apm", W3_SERIAL="1")
+    assert r.returncode == 0, r.stderr
+    for name, data in files.items():
+        stem = name.split(".")[0]
+        a, b = (flight / (stem + ".bin")).read_bytes(), (serial / (stem + ".bin")).read_bytes()
+        assert a == b, name
+        r = run(cli, flight, "d", str(flight / (stem + ".bin")), W3_MODEL="order012apm")
+        assert r.returncode == 0 and (flight / (stem + ".orig")).read_bytes() == data, name
+
+
 def test_cli_errors(cli, tmp_path):
     assert run(cli, tmp_path, "x", "nothing").returncode == 1                             # usage, main.rs:154-161
     assert run(cli, tmp_path, "c", str(tmp_path / "missing")).returncode == 1

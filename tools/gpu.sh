@@ -10,6 +10,11 @@
 #   bench [args]                python3 bench.py args  -> bench_<n>.json
 #   stats [bench args]          rocprofv3 --kernel-trace --stats of bench.py --quick args
 #   pmc <counters> [bench args] one rocprofv3 --pmc pass (counters comma-separated) of bench.py --quick args
+#   timeline [bench args]       rocprofv3 --kernel-trace of bench.py --quick args -> timeline_<n>.txt (tools/pipeline_timeline.py: which
+#                               kernels of step k+1 run beside which of step k) + kernel_stats_<n>.csv
+#   traffic <model> [bench args] the evidence set of one model: kernel stats + FETCH_SIZE pass + WRITE_SIZE pass (separate runs, as
+#                               MI355X_MICROARCH.md prescribes) of bench.py --quick --steps 2 --warmup 1 --model <model> args
+#                               -> traffic_<model>.json (entries in the format of profiles/r*_traffic.json) + the per-pass summaries
 #   decode [model] [bytes]      tools/decode_rate.py
 #   py <script> [args]          python3 <script> args
 #   ubench <file.hip> [args]    hipcc a tools/*.hip microbenchmark and run it
@@ -50,6 +55,24 @@ EOF
         local ctr=$1; shift
         (cd /tmp && timeout -k 10 900 rocprofv3 --pmc ${ctr//,/ } -d "$DST/pmc_${n}" -o run -- python3 "$OLDPWD/bench.py" --quick "$@" > "$DST/pmc_$n.json" 2> "$DST/pmc_$n.err"); local rc=$?
         python3 tools/pmc_sum.py "$DST/pmc_$n" 2>&1 | tail -40; return $rc ;;
+    timeline)
+        (cd /tmp && timeout -k 10 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$DST/kt_$n" -o kt -- python3 "$OLDPWD/bench.py" --steps 6 --warmup 2 --quick "$@" > "$DST/timeline_$n.json" 2> "$DST/timeline_$n.err"); local rc=$?
+        find "$DST/kt_$n" -name '*kernel_stats.csv' -exec cp {} "$DST/kernel_stats_$n.csv" \;
+        local tr=$(find "$DST/kt_$n" -name '*kernel_trace.csv' | head -1)
+        [ -n "$tr" ] && python3 tools/pipeline_timeline.py "$tr" 260 > "$DST/timeline_$n.txt"
+        rm -rf "$DST/kt_$n"; tail -45 "$DST/timeline_$n.txt"; return $rc ;;
+    traffic)
+        local model=$1; shift
+        local A="--quick --steps 2 --warmup 1 --model $model $*"
+        (cd /tmp && timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$DST/tr_${model}_kt" -o kt -- python3 "$OLDPWD/bench.py" $A > "$DST/tr_${model}_kt.json" 2> "$DST/tr_${model}_kt.err") || return 1
+        find "$DST/tr_${model}_kt" -name '*kernel_stats.csv' -exec cp {} "$DST/${model}_kernel_stats.csv" \;
+        rm -rf "$DST/tr_${model}_kt"
+        for c in FETCH_SIZE WRITE_SIZE; do
+            (cd /tmp && timeout -k 10 600 rocprofv3 --pmc $c --output-format csv -d "$DST/tr_${model}_$c" -o p -- python3 "$OLDPWD/bench.py" $A > "$DST/tr_${model}_$c.json" 2> "$DST/tr_${model}_$c.err") || return 1
+            python3 tools/pmc_sum.py "$DST/tr_${model}_$c" --json "$DST/${model}_pmc_$c.json" > /dev/null
+            rm -rf "$DST/tr_${model}_$c"
+        done
+        python3 tools/traffic_json.py "$model" "$DST" "$@" | tail -30; return $? ;;
     decode)
         timeout -k 10 900 python3 tools/decode_rate.py "$@" > "$DST/decode_$n.txt" 2>&1; local rc=$?
         tail -12 "$DST/decode_$n.txt"; return $rc ;;

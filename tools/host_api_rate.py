@@ -19,18 +19,34 @@ import time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
-def measure(name="order012apm", n=1_000_000_000, bs=65536, chunks=(0,), calls=8, pageable=True, resident=True, log=print):
+def measure(name="order012apm", n=1_000_000_000, bs=65536, chunks=(0,), calls=8, pageable=True, resident=True, host=None, log=print, tune=0, churn=0):
     import numpy as np
     import torch
     import weath3rb0i_amd as w3
     from tools import synth
     import bench
     res = {"model": name, "bytes": n, "block_size": bs}
-    host = synth.text(n, seed=1)
+    if host is None:
+        host = synth.text(n, seed=1)
     model, mname = bench.make_model(w3, name)
     res["context_model"] = mname
     nb = (n + bs - 1) // bs
+    if churn:
+        # contexts that come and go before the measured one (bench.py's situation: its main context and its decode context have lived
+        # and died before the host-path leg): their pipelines create the process's streams; the measured context must not end up with
+        # a copy stream on a living predict stream's hardware queue (w3hip.hip: the context's stream comes from the process-wide pool)
+        for _ in range(churn):
+            c0 = w3.Context(0)
+            small = host[: 8 << 20]
+            o0, l0 = np.zeros(len(small) * 2 + 8192, dtype=np.uint8), np.zeros((len(small) + bs - 1) // bs, dtype=np.uint32)
+            for _ in range(3):
+                c0.encode_host_wait(c0.encode_host_submit(model, small, bs, o0, l0))
+            c0.close()
     ctx = w3.Context(0)
+    if tune:
+        ctx.set_tune(tune)
+    res["tune"] = tune
+    res["gpu_max_hw_queues"] = os.environ.get("GPU_MAX_HW_QUEUES", "unset")
     MiB = 2.0 ** 20
 
     pin_in = torch.empty(n, dtype=torch.uint8).pin_memory()
@@ -85,6 +101,14 @@ def measure(name="order012apm", n=1_000_000_000, bs=65536, chunks=(0,), calls=8,
         res["d2h_pinned_ms"] = round(min(ts) * 1e3, 2)
         res["compressed_bytes"] = total
         del d_outs, d_lens, d_tot
+    if not resident:
+        tot0 = int(n * ratio)
+        d_tmp = torch.empty(tot0, dtype=torch.uint8, device="cuda")
+        ts = []
+        for _ in range(3):
+            t0 = time.perf_counter(); pin_outs[0][0][:tot0].copy_(d_tmp, non_blocking=True); torch.cuda.synchronize(); ts.append(time.perf_counter() - t0)
+        res["d2h_pinned_ms"] = round(min(ts) * 1e3, 2)
+        del d_tmp
     del d_in
     torch.cuda.empty_cache()
     log("copies alone: H2D pinned %.1f ms%s, D2H of the streams pinned %s ms" % (res["h2d_pinned_ms"], (", pageable %.1f ms" % res["h2d_pageable_ms"]) if pageable else "", res.get("d2h_pinned_ms")))
@@ -161,8 +185,14 @@ def main():
     ap.add_argument("--calls", type=int, default=8)
     ap.add_argument("--json", default="")
     ap.add_argument("--no-pageable", action="store_true")
+    ap.add_argument("--no-resident", action="store_true")
+    ap.add_argument("--tune", type=int, default=0, help="W3_OPT_TUNE (bit 16 = 65536: the copies on two streams of their own)")
+    ap.add_argument("--churn", type=int, default=0, help="contexts created, used and closed before the measured one")
+    ap.add_argument("--hw-queues", type=int, default=0, help="GPU_MAX_HW_QUEUES for this run (0 = leave the environment alone)")
     a = ap.parse_args()
-    res = measure(a.model, int(a.bytes), chunks=[int(c) for c in a.chunks.split(",")], calls=a.calls, pageable=not a.no_pageable)
+    if a.hw_queues:
+        os.environ["GPU_MAX_HW_QUEUES"] = str(a.hw_queues)   # (before anything initialises the HIP runtime)
+    res = measure(a.model, int(a.bytes), chunks=[int(c) for c in a.chunks.split(",")], calls=a.calls, pageable=not a.no_pageable, resident=not a.no_resident, tune=a.tune, churn=a.churn)
     txt = json.dumps(res)
     print(txt)
     if a.json:

@@ -10,6 +10,8 @@
 #include <sys/stat.h>
 
 #include <chrono>
+#include <deque>
+#include <memory>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -87,6 +89,8 @@ static int die(w3_ctx *ctx, int rc, const char *what) {
     return 1;
 }
 
+static bool write_block_container(const std::string &out, size_t orig, const std::vector<uint32_t> &lens, size_t nb, const uint8_t *body, size_t blen);
+
 static int compress(w3_ctx *ctx, const std::string &in, const std::string &out) {
     std::vector<uint8_t> data;
     if (!read_file(in, data)) { perror(in.c_str()); return 1; }
@@ -125,11 +129,63 @@ static int compress(w3_ctx *ctx, const std::string &in, const std::string &out) 
         if (rc == W3_E_NOSPACE) { body.resize(blen); rc = w3_encode_blocks(ctx, &spec, data.data(), data.size(), kBlock, body.data(), body.size(), &blen, lens.data()); }
         if (rc) return die(ctx, rc, "w3_encode_blocks");
     }
+    return write_block_container(out, data.size(), lens, nb, body.data(), blen) ? 0 : 1;
+}
+
+static bool write_block_container(const std::string &out, size_t orig, const std::vector<uint32_t> &lens, size_t nb, const uint8_t *body, size_t blen) {
     std::vector<uint8_t> file = {'w', '3', 'b', 'k', 1};
-    put_be(file, data.size(), 8); put_be(file, kBlock, 4); put_be(file, nb, 4);
+    put_be(file, orig, 8); put_be(file, kBlock, 4); put_be(file, nb, 4);
     for (size_t b = 0; b < nb; b++) put_be(file, lens[b], 4);
-    file.insert(file.end(), body.begin(), body.begin() + (long)blen);
-    return write_file(out, file.data(), file.size()) ? 0 : 1;
+    file.insert(file.end(), body, body + blen);
+    return write_file(out, file.data(), file.size());
+}
+
+// A DIRECTORY compressed with FILES IN FLIGHT (main.rs:41-50 walks it one file after the other): w3_encode_host_submit takes file k+1 —
+// its input crosses PCIe and its encode is enqueued — while file k is still being coded and file k-1's streams travel back; a file's
+// coder chain (8 x 65,536 dependent steps per lane, ~17 ms however small the file) overlaps the other files' instead of being waited
+// for.  Same container bytes as the one-file-at-a-time path.
+static int compress_dir_in_flight(w3_ctx *ctx, const std::vector<std::string> &files) {
+    struct Pending { std::string in, out; std::vector<uint8_t> data, body; std::vector<uint32_t> lens; size_t nb = 0; int hjob = -1;
+                     std::chrono::steady_clock::time_point t0; };
+    std::deque<std::unique_ptr<Pending>> q;
+    w3_model_spec spec = init_model();
+    int ret = 0;
+    auto finish = [&]() {
+        std::unique_ptr<Pending> p = std::move(q.front());
+        q.pop_front();
+        size_t blen = 0;
+        int rc = w3_encode_host_wait(ctx, p->hjob, &blen);
+        if (rc == W3_E_NOSPACE) {   // (a file that expands past 2 n: once more, alone, with the room it asked for)
+            p->body.resize(blen);
+            rc = w3_encode_blocks(ctx, &spec, p->data.data(), p->data.size(), kBlock, p->body.data(), p->body.size(), &blen, p->lens.data());
+        }
+        if (rc) { ret |= die(ctx, rc, "w3_encode_host_wait"); return; }
+        if (!write_block_container(p->out, p->data.size(), p->lens, p->nb, p->body.data(), blen)) { ret |= 1; return; }
+        printf("Compression took: %.3fs\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - p->t0).count());
+    };
+    for (const std::string &f : files) {
+        std::unique_ptr<Pending> p(new Pending);
+        p->in = f; p->out = out_path(f, "bin"); p->t0 = std::chrono::steady_clock::now();
+        if (!read_file(f, p->data)) { perror(f.c_str()); ret |= 1; continue; }
+        if (p->data.empty()) {   // (nothing to submit: an empty block container)
+            ret |= write_block_container(p->out, 0, p->lens, 0, nullptr, 0) ? 0 : 1;
+            printf("Compression took: %.3fs\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - p->t0).count());
+            continue;
+        }
+        p->nb = (p->data.size() + kBlock - 1) / kBlock;
+        p->body.resize(2 * p->data.size() + 64 * p->nb + 64);
+        p->lens.resize(p->nb);
+        while (!q.empty() && (int)q.size() >= w3_encode_host_max_in_flight(&spec, p->data.size(), kBlock)) finish();
+        int rc = w3_encode_host_submit(ctx, &spec, p->data.data(), p->data.size(), kBlock, p->body.data(), p->body.size(), p->lens.data(), &p->hjob);
+        if (rc == W3_E_INVALID && !q.empty()) {   // (a larger file allows fewer calls in flight than the ones before it: drain, then retry)
+            while (!q.empty()) finish();
+            rc = w3_encode_host_submit(ctx, &spec, p->data.data(), p->data.size(), kBlock, p->body.data(), p->body.size(), p->lens.data(), &p->hjob);
+        }
+        if (rc) { ret |= die(ctx, rc, "w3_encode_host_submit"); continue; }
+        q.push_back(std::move(p));
+    }
+    while (!q.empty()) finish();
+    return ret;
 }
 
 static int decompress(w3_ctx *ctx, const std::string &in, const std::string &out) {
@@ -187,13 +243,18 @@ int main(int argc, char **argv) {
     if (rc) return die(nullptr, rc, "w3_ctx_create (an MI355X is required; there is no CPU path)");
     int ret = 0;
     if (S_ISDIR(st.st_mode)) {
+        std::vector<std::string> files;
         DIR *d = opendir(argv[2]);
         while (dirent *e = d ? readdir(d) : nullptr) {
             std::string p = std::string(argv[2]) + "/" + e->d_name;
             struct stat s2;
-            if (!stat(p.c_str(), &s2) && S_ISREG(s2.st_mode)) ret |= run(ctx, p, action);
+            if (!stat(p.c_str(), &s2) && S_ISREG(s2.st_mode)) files.push_back(p);
         }
         if (d) closedir(d);
+        const char *cont = getenv("W3_CONTAINER"), *sh = getenv("W3_SHARDS"), *serial = getenv("W3_SERIAL");
+        const bool block_container = !(cont && !strcmp(cont, "w30i")) && !(sh && atoi(sh) > 1);
+        if (action == 'c' && block_container && !serial) ret = compress_dir_in_flight(ctx, files);   // files in flight (W3_SERIAL=1: one after the other)
+        else for (const std::string &p : files) ret |= run(ctx, p, action);
     } else {
         ret = run(ctx, argv[2], action);
     }

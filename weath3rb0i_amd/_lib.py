@@ -50,6 +50,7 @@ EXPORTS = [
     "w3_get_timing", "w3_selftest_counter_p", "w3_debug_get_stamps", "w3_state_table", "w3_stretch_squash", "w3_huff_tables",
     "w3_shard_range", "w3_encode_blocks_sharded", "w3_encode_blocks_sharded_device", "w3_encode_stats", "w3_encode_stats_device", "w3_sweep_ordern", "w3_sweep_ordern_device", "w3_export_counters",
     "w3_encode_host_submit", "w3_encode_host_wait", "w3_encode_host_max_in_flight", "w3_rccl_library", "w3_rccl_status",
+    "w3_encode_sharded_submit", "w3_encode_sharded_wait", "w3_encode_sharded_max_in_flight",
 ]
 
 _lib = None
@@ -115,6 +116,10 @@ def load():
     lib.w3_encode_host_wait.argtypes = [vp, C.c_int, C.POINTER(sz)]
     lib.w3_encode_host_max_in_flight.argtypes = [C.POINTER(ModelSpec), sz, sz]
     lib.w3_encode_host_max_in_flight.restype = C.c_int
+    lib.w3_encode_sharded_submit.argtypes = [C.POINTER(vp), C.c_int, C.POINTER(ModelSpec), C.POINTER(vp), C.POINTER(sz), sz, C.POINTER(C.c_int)]
+    lib.w3_encode_sharded_wait.argtypes = [C.POINTER(vp), C.c_int, C.c_int, C.c_int, vp, sz, vp, C.POINTER(C.c_uint64), C.c_int]
+    lib.w3_encode_sharded_max_in_flight.argtypes = [C.POINTER(ModelSpec), C.POINTER(sz), C.c_int, sz]
+    lib.w3_encode_sharded_max_in_flight.restype = C.c_int
     lib.w3_rccl_library.argtypes = [C.c_char_p]
     lib.w3_rccl_status.argtypes = [C.c_char_p, sz]
     _lib = lib

@@ -282,3 +282,37 @@ def encode_blocks_sharded_device(ctxs, model, d_ins, block_size, d_out, d_lens, 
     if rc:
         raise W3Error(rc, ctxs[0].lib.w3_last_error(ctxs[0].h).decode())
     return [int(t) for t in totals]
+
+
+def encode_sharded_submit(ctxs, model, d_ins, block_size):
+    """w3_encode_sharded_submit: one STEP of a stream of sharded encodes — every shard's encode is enqueued on its context (d_ins[r]:
+    torch.uint8 CUDA tensor on ctxs[r]'s device, kept alive until the step has been waited for).  -> step handle"""
+    spec = model.spec() if isinstance(model, Model) else model
+    k = len(ctxs)
+    hs = (C.c_void_p * k)(*[c.h for c in ctxs])
+    ins = (C.c_void_p * k)(*[C.c_void_p(t.data_ptr() if t.numel() else 0) for t in d_ins])
+    ns = (C.c_size_t * k)(*[t.numel() for t in d_ins])
+    sjob = C.c_int(-1)
+    rc = ctxs[0].lib.w3_encode_sharded_submit(hs, k, C.byref(spec), ins, ns, block_size, C.byref(sjob))
+    if rc:
+        raise W3Error(rc, ctxs[0].lib.w3_last_error(ctxs[0].h).decode())
+    return sjob.value
+
+
+def encode_sharded_wait(ctxs, sjob, d_out, d_lens, root=0, transport="auto"):
+    """w3_encode_sharded_wait: completes the step and gathers its packed streams and length table on ctxs[root]'s device.
+    -> per-shard compressed byte counts"""
+    k = len(ctxs)
+    hs = (C.c_void_p * k)(*[c.h for c in ctxs])
+    totals = (C.c_uint64 * k)()
+    tr = {"auto": L.W3_GATHER_AUTO, "rccl": L.W3_GATHER_RCCL, "peer_copy": L.W3_GATHER_PEER_COPY}[transport]
+    rc = ctxs[0].lib.w3_encode_sharded_wait(hs, k, int(sjob), root, C.c_void_p(d_out.data_ptr()), d_out.numel(), C.c_void_p(d_lens.data_ptr()), totals, tr)
+    if rc:
+        raise W3Error(rc, ctxs[0].lib.w3_last_error(ctxs[0].h).decode())
+    return [int(t) for t in totals]
+
+
+def sharded_max_in_flight(ctxs, model, sizes, block_size):
+    spec = model.spec() if isinstance(model, Model) else model
+    ns = (C.c_size_t * len(sizes))(*sizes)
+    return int(ctxs[0].lib.w3_encode_sharded_max_in_flight(C.byref(spec), ns, len(sizes), block_size))

@@ -43,10 +43,15 @@ namespace w3 {
 // another large one — it waits for an empty CU — so nothing here exceeds the half.  The wavefronts of a workgroup never
 // synchronise with each other (wave barriers only).  NW == 1 is the plain one-wavefront workgroup.
 #define W3_HALF_CU_LDS 81920u
-template <int NW, size_t USED> struct HalfCuPad { static constexpr size_t words = (NW > 1 && USED < W3_HALF_CU_LDS) ? (W3_HALF_CU_LDS - USED + 3u) / 4u : 1u; };
-#define W3_HALF_CU_PAD(NW, USED)                                                              \
-    __shared__ uint32_t pad_[HalfCuPad<NW, (USED)>::words];                                   \
-    if constexpr ((NW) > 1) { if (a.n == ~0ull) pad_[threadIdx.x] = 1u; }   /* never true: keeps the padding allocated */
+template <int NW, size_t USED> struct HalfCuPad { static constexpr size_t words = (NW > 1 && USED < W3_HALF_CU_LDS) ? (W3_HALF_CU_LDS - USED + 3u) / 4u : (NW > 1 ? 0u : 1u); };
+template <size_t WORDS> struct HalfCuPadDecl {
+    static __device__ __forceinline__ void keep(uint64_t n) {
+        __shared__ uint32_t pad_[WORDS];
+        if (n == ~0ull) pad_[threadIdx.x % WORDS] = 1u;   /* never true: keeps the padding allocated */
+    }
+};
+template <> struct HalfCuPadDecl<0> { static __device__ __forceinline__ void keep(uint64_t) {} };   // (the wavefronts fill the half exactly)
+#define W3_HALF_CU_PAD(NW, USED) HalfCuPadDecl<((NW) > 1 ? HalfCuPad<NW, (USED)>::words : 0u)>::keep(a.n);
 
 struct PredictArgs {
     const uint8_t *in;      // original bytes (device)
@@ -788,10 +793,11 @@ __global__ void __launch_bounds__(64 * NW) k_partition8(PredictArgs a) {
 // P regions (1 MiB each) then stay in the 256 MiB Infinity Cache, where the eight partial 16-byte
 // writes every 128-byte line receives merge (3.2x cheaper than with 4096 blocks live; see
 // profiles/r1_ubench_partial_line_merge_vs_footprint.txt).
-template <int NBYTES, int NW = 1>
+// PF: rounds per operand batch (8: 12 KiB of LDS per wavefront; 4: 10 KiB, so that EIGHT wavefronts fit the half of a CU)
+template <int NBYTES, int NW = 1, int PF = W3_PF>
 __global__ void __launch_bounds__(64 * NW) k_rank_sorted(PredictArgs a) {
     __shared__ uint32_t tbl_[NW][8 * 256];
-    __shared__ uint2 st_r_[NW][W3_PF * 64];   // record staging (one batch of rounds)
+    __shared__ uint2 st_r_[NW][PF * 64];   // record staging (one batch of rounds)
     W3_HALF_CU_PAD(NW, sizeof(tbl_) + sizeof(st_r_))
     const int lane = threadIdx.x & 63;
     uint32_t *tbl = tbl_[threadIdx.x >> 6];
@@ -824,22 +830,22 @@ __global__ void __launch_bounds__(64 * NW) k_rank_sorted(PredictArgs a) {
         bool exact = (a.dbg_flags & 2u) != 0u;   // ballot rounds only (see atomic_round)
         bool dirty = false;              // table holds states of group open_g
         uint32_t open_g = 0xFFFFFFFFu;   // group the table describes (also: group of the previous round's last element)
-        // records travel in batches of W3_PF rounds through LDS (see k_predict_small: no load is in flight beside the stores)
+        // records travel in batches of PF rounds through LDS (see k_predict_small: no load is in flight beside the stores)
         const uint32_t last = len - 1u;
-        uint2 rn[W3_PF];
+        uint2 rn[PF];
 #pragma unroll
-        for (int r = 0; r < W3_PF; r++) rn[r] = perm[min((uint32_t)(r * 64 + lane), last)];
-        for (uint32_t bbase = 0; bbase < len; bbase += 64u * W3_PF) {
+        for (int r = 0; r < PF; r++) rn[r] = perm[min((uint32_t)(r * 64 + lane), last)];
+        for (uint32_t bbase = 0; bbase < len; bbase += 64u * (uint32_t)PF) {
             __asm__ volatile("" ::: "memory");
             __builtin_amdgcn_wave_barrier();
 #pragma unroll
-            for (int r = 0; r < W3_PF; r++) st_r[r * 64 + lane] = rn[r];
+            for (int r = 0; r < PF; r++) st_r[r * 64 + lane] = rn[r];
             __asm__ volatile("" ::: "memory");
             __builtin_amdgcn_wave_barrier();
 #pragma unroll
-            for (int r = 0; r < W3_PF; r++) rn[r] = perm[min(bbase + (uint32_t)((W3_PF + r) * 64 + lane), last)];
+            for (int r = 0; r < PF; r++) rn[r] = perm[min(bbase + (uint32_t)((PF + r) * 64 + lane), last)];
 #pragma unroll 1
-          for (uint32_t rr = 0; rr < W3_PF; rr++) {
+          for (uint32_t rr = 0; rr < (uint32_t)PF; rr++) {
             const uint32_t base = bbase + rr * 64u;
             if (base >= len) break;
             const uint32_t e = base + lane;

@@ -201,6 +201,7 @@ static inline bool twophase_supported(const ParsedSpec &ps, size_t block_size, s
 #define W3_NW_SMALL 8
 #define W3_NW_PART 4
 #define W3_NW_RANK 6
+#define W3_NW_RANK8 8      // with 4-round operand batches (10 KiB per wavefront): eight wavefronts in the half of a CU (W3_OPT_TUNE bit 15)
 #define W3_HALF_CU_GRID 256u   // one workgroup per CU
 
 template <bool KEYS, int NW = 1>
@@ -483,7 +484,8 @@ static inline int twophase_predict_a(TwoPhaseWs &ws, hipStream_t s, const Parsed
             if (const char *ev_ = w3_tune_env("W3_RANK_GRID")) rank_waves = (uint32_t)std::max(64, atoi(ev_));   // tuning hook
             // half-CU shapes: the FIRST rank kernel starts beside the previous call's coder and must leave it its half of every CU's
             // LDS whichever of the two is dispatched first; the later ones are single wavefronts again (they fill what is free)
-            const uint32_t grid_rank = (ws.half_cu && (w == 0 || (ws.tune & (32u | 64u))) && !(ws.tune & 8u)) ? std::min<uint32_t>((nb * W3_SLICES + W3_NW_RANK - 1) / W3_NW_RANK, W3_HALF_CU_GRID)
+            const uint32_t nw_rank = (ws.tune & 32768u) ? W3_NW_RANK8 : W3_NW_RANK;
+            const uint32_t grid_rank = (ws.half_cu && (w == 0 || (ws.tune & (32u | 64u))) && !(ws.tune & 8u)) ? std::min<uint32_t>((nb * W3_SLICES + nw_rank - 1) / nw_rank, W3_HALF_CU_GRID)
                                                               : std::min<uint32_t>(nb * W3_SLICES, rank_waves);
             // an order-2 leaf behind an Order1 leaf starts from that leaf's records (sorted by c1; same stream, so they are ready)
             const bool chained = c == LEAF_WIDE2 && ws.wide1_slot >= 0 && !(ws.variant & W3_VAR_NO_CHAINED_PARTITION);
@@ -552,7 +554,13 @@ static inline int twophase_predict_b(TwoPhaseWs &ws, hipStream_t s, const Parsed
     for (int w = 0; w < n_def; w++) {
         if (forked) (void)hipStreamWaitEvent(s, ws.ev_join[n_def - 1], 0);   // every leaf's records are sorted
         if (ev) (void)hipEventRecord(ev[2 * (W3_EV_RANK0 + w)], s);
-        if (ws.half_cu && (w == 0 || (ws.tune & (32u | 64u))) && !(ws.tune & 8u)) {
+        if (ws.half_cu && (w == 0 || (ws.tune & (32u | 64u))) && !(ws.tune & 8u) && (ws.tune & 32768u)) {
+            if (deferred[w].cls == LEAF_WIDE1) hipLaunchKernelGGL((w3::k_rank_sorted<1, W3_NW_RANK8, 4>), dim3(deferred[w].grid_rank), dim3(64 * W3_NW_RANK8), 0, s, deferred[w].pa);
+            else hipLaunchKernelGGL((w3::k_rank_sorted<2, W3_NW_RANK8, 4>), dim3(deferred[w].grid_rank), dim3(64 * W3_NW_RANK8), 0, s, deferred[w].pa);
+        } else if (ws.half_cu && (ws.tune & 32768u)) {   // the later rank kernels: single wavefronts of 10 KiB (eight beside the coder's 74 KiB)
+            if (deferred[w].cls == LEAF_WIDE1) hipLaunchKernelGGL((w3::k_rank_sorted<1, 1, 4>), dim3(deferred[w].grid_rank), dim3(64), 0, s, deferred[w].pa);
+            else hipLaunchKernelGGL((w3::k_rank_sorted<2, 1, 4>), dim3(deferred[w].grid_rank), dim3(64), 0, s, deferred[w].pa);
+        } else if (ws.half_cu && (w == 0 || (ws.tune & (32u | 64u))) && !(ws.tune & 8u)) {
             if (deferred[w].cls == LEAF_WIDE1) hipLaunchKernelGGL((w3::k_rank_sorted<1, W3_NW_RANK>), dim3(deferred[w].grid_rank), dim3(64 * W3_NW_RANK), 0, s, deferred[w].pa);
             else hipLaunchKernelGGL((w3::k_rank_sorted<2, W3_NW_RANK>), dim3(deferred[w].grid_rank), dim3(64 * W3_NW_RANK), 0, s, deferred[w].pa);
         } else if (deferred[w].cls == LEAF_WIDE1) hipLaunchKernelGGL(w3::k_rank_sorted<1>, dim3(deferred[w].grid_rank), dim3(64), 0, s, deferred[w].pa);
@@ -704,7 +712,9 @@ static inline int twophase_verify(TwoPhaseWs &ws, hipStream_t s, const ParsedSpe
                                   uint32_t nb, uint32_t *d_mismatch, std::string &err) {
     if (!ws.verify || !ws.used_lds_atomics) return W3_OK;
     const uint32_t nb_full = (uint32_t)(n / block_size);
-    uint32_t S = (uint32_t)std::min<uint64_t>(std::min<uint32_t>(nb_full, std::max<uint32_t>(W3_VERIFY_BLOCKS, nb_full / 256u)), std::max<uint64_t>(1, (64ull << 20) / block_size));
+    // ws.verify = v >= 1: v / 256 of the blocks (W3_OPT_VERIFY; 1 = the default sample), at most 64 MiB x v of input
+    const uint64_t vv = (uint64_t)std::max(1, ws.verify);
+    uint32_t S = (uint32_t)std::min<uint64_t>(std::min<uint64_t>(nb_full, std::max<uint64_t>(W3_VERIFY_BLOCKS, nb_full * vv / 256u)), std::max<uint64_t>(1, vv * (64ull << 20) / block_size));
     size_t vn = (size_t)S * block_size;
     const uint32_t gap = S ? nb_full / S : 0u, rot = gap ? ws.verify_calls++ % gap : 0u;
     const uint8_t *vsrc = nullptr;

@@ -53,6 +53,7 @@ struct JobState {
     w3_timing tm{};
     w3_timing tm_ev{}; bool tm_snap = false;   // the event times, collected early (a synchronous fallback is about to reuse job 0's events)
     int sync_rc = W3_OK;           // state 2: what the synchronous run inside w3_encode_submit returned
+    uint64_t total_out = 0; bool total_valid = false;   // the compressed size w3_encode_wait read from the job's pinned status words
     bool has_apm = false, has_slot = false, timed = false;
     hipStream_t sc = nullptr;      // the stream this job's code stage runs on (free-running jobs: one each; ordered jobs share s_code[0])
 };
@@ -102,9 +103,13 @@ struct w3_ctx {
     int next_job = 0, last_job = -1;
     bool pooled_streams = false;
     hipStream_t s_side = nullptr, s_verify[W3_MAX_JOBS] = {};   // the workspaces' side stream (one: predict phases never overlap) and re-prediction streams
+    // sharded calls in flight (w3_encode_sharded_submit / w3_encode_sharded_wait): this context's shard of step `slot`, in staging
+    // buffers of its own until the step is gathered
+    struct ShardSlot { int state = 0, djob = -1; DevBuf out, lens, total; size_t nb = 0, n = 0, cap = 0; const uint8_t *d_in = nullptr; size_t block_size = 0; w3_model_spec spec{}; w3_huff_table huff_copy[W3_MAX_HUFF]; } ss[W3_MAX_JOBS];
     // host-buffer calls in flight (w3_encode_host_submit / w3_encode_host_wait; w3_encode_blocks cuts its input into such calls)
     HostJob hj[W3_MAX_HOST_JOBS];
-    hipStream_t s_h2d = nullptr, s_d2h = nullptr;   // copy streams: nothing but transfers is ever enqueued on them
+    hipStream_t s_h2d = nullptr, s_d2h = nullptr;   // where the copies go: the context's stream, or (W3_OPT_TUNE bit 16) the two below
+    hipStream_t s_h2d_own = nullptr, s_d2h_own = nullptr;
     uint64_t hseq = 0;
     uint32_t host_chunk_blocks = 0;                 // W3_OPT_HOST_CHUNK_BLOCKS (0 = auto)
 };
@@ -151,6 +156,8 @@ static int jobs_idle(w3_ctx *ctx) {
         if (st.state == 1) { ctx->err = "asynchronous jobs are in flight on this context: w3_encode_wait them first"; return W3_E_INVALID; }
     for (const auto &h : ctx->hj)
         if (h.state != 0) { ctx->err = "host-buffer jobs are in flight on this context: w3_encode_host_wait them first"; return W3_E_INVALID; }
+    for (const auto &x : ctx->ss)
+        if (x.state != 0) { ctx->err = "sharded jobs are in flight on this context: w3_encode_sharded_wait them first"; return W3_E_INVALID; }
     return W3_OK;
 }
 
@@ -171,6 +178,22 @@ extern "C" const char *w3_strerror(int code) {
 
 extern "C" const char *w3_last_error(const w3_ctx *ctx) { return ctx ? ctx->err.c_str() : "null ctx"; }
 
+// The pipeline's streams are kept for the life of the process and handed from context to context (per device and priority): HIP deals
+// hardware queues out when a stream is CREATED, by the queues' reference counts at that moment, and a context created after others
+// had come and gone got code streams that shared queues (bench.py's later lines ran at the two-in-flight rate with four in flight).
+struct StreamPool {
+    std::mutex mu;
+    std::vector<std::pair<long, hipStream_t>> idle;   // key = device * 8 + class (0 = predict, 1 = code, 2 = side, 3 = verification, 4 = the context's own launch / copy stream)
+    hipStream_t take(long key) {
+        std::lock_guard<std::mutex> g(mu);
+        for (size_t i = 0; i < idle.size(); i++)
+            if (idle[i].first == key) { hipStream_t s = idle[i].second; idle.erase(idle.begin() + (long)i); return s; }
+        return nullptr;
+    }
+    void give(long key, hipStream_t s) { std::lock_guard<std::mutex> g(mu); idle.emplace_back(key, s); }
+};
+static StreamPool &stream_pool() { static StreamPool *p = new StreamPool; return *p; }   // (never destroyed: streams outlive static teardown order)
+
 extern "C" int w3_ctx_create(int device, w3_ctx **out) {
     if (!out) return W3_E_INVALID;
     *out = nullptr;
@@ -182,28 +205,17 @@ extern "C" int w3_ctx_create(int device, w3_ctx **out) {
     // A BLOCKING stream: it is ordered against the legacy default (NULL) stream like any ordinary stream, so a caller that
     // produces d_in on the default stream and passes stream = NULL (or torch's default-stream handle, which is 0) gets the
     // order it expects.  The side streams of the predict phase fork from and join the launch stream with events.
-    if (hipStreamCreate(&c->stream) != hipSuccess) { delete c; return W3_E_HIP; }
+    // Taken from the process-wide pool like the pipeline's streams: the host-buffer calls put their PCIe copies on this stream, and a
+    // stream created after other contexts have come and gone can land on the hardware queue of a (pooled, still living) predict stream —
+    // every copy then holds that call's kernels back (measured: 84.5 ms per 1e9-byte call in flight inside bench.py, where two contexts
+    // had lived before, against 71.0 in a fresh process).
+    c->stream = stream_pool().take(device * 8L + 4);
+    if (!c->stream && hipStreamCreate(&c->stream) != hipSuccess) { delete c; return W3_E_HIP; }
     for (auto &e : c->ev)
         if (hipEventCreate(&e) != hipSuccess) { delete c; return W3_E_HIP; }
     *out = c;
     return W3_OK;
 }
-
-// The pipeline's streams are kept for the life of the process and handed from context to context (per device and priority): HIP deals
-// hardware queues out when a stream is CREATED, by the queues' reference counts at that moment, and a context created after others
-// had come and gone got code streams that shared queues (bench.py's later lines ran at the two-in-flight rate with four in flight).
-struct StreamPool {
-    std::mutex mu;
-    std::vector<std::pair<long, hipStream_t>> idle;   // key = device * 4 + class (0 = predict, 1 = code, 2 = side, 3 = verification)
-    hipStream_t take(long key) {
-        std::lock_guard<std::mutex> g(mu);
-        for (size_t i = 0; i < idle.size(); i++)
-            if (idle[i].first == key) { hipStream_t s = idle[i].second; idle.erase(idle.begin() + (long)i); return s; }
-        return nullptr;
-    }
-    void give(long key, hipStream_t s) { std::lock_guard<std::mutex> g(mu); idle.emplace_back(key, s); }
-};
-static StreamPool &stream_pool() { static StreamPool *p = new StreamPool; return *p; }   // (never destroyed: streams outlive static teardown order)
 
 extern "C" void w3_ctx_destroy(w3_ctx *ctx) {
     if (!ctx) return;
@@ -228,14 +240,19 @@ extern "C" void w3_ctx_destroy(w3_ctx *ctx) {
         if (st.ev_apm) (void)hipEventDestroy(st.ev_apm);
         if (st.h_status) (void)hipHostFree(st.h_status);
     }
-    if (ctx->s_side) stream_pool().give(ctx->device * 4L + 2, ctx->s_side);
-    for (auto &sv : ctx->s_verify) if (sv) stream_pool().give(ctx->device * 4L + 3, sv);
+    if (ctx->s_side) stream_pool().give(ctx->device * 8L + 2, ctx->s_side);
+    for (auto &sv : ctx->s_verify) if (sv) stream_pool().give(ctx->device * 8L + 3, sv);
     if (ctx->pooled_streams) {   // (idle by now: the device was synchronised above)
-        if (ctx->s_pred) stream_pool().give(ctx->device * 4L, ctx->s_pred);
-        for (auto &sc : ctx->s_code) if (sc) stream_pool().give(ctx->device * 4L + 1, sc);
+        if (ctx->s_pred) stream_pool().give(ctx->device * 8L, ctx->s_pred);
+        for (auto &sc : ctx->s_code) if (sc) stream_pool().give(ctx->device * 8L + 1, sc);
     } else {
         if (ctx->s_pred) (void)hipStreamDestroy(ctx->s_pred);
         for (auto &sc : ctx->s_code) if (sc) (void)hipStreamDestroy(sc);
+    }
+    for (auto &x : ctx->ss) {
+        DevBuf *bufs3[] = {&x.out, &x.lens, &x.total};
+        for (DevBuf *b : bufs3)
+            if (b->p) (void)hipFree(b->p);
     }
     for (auto &h : ctx->hj) {
         DevBuf *bufs2[] = {&h.d_in, &h.d_out, &h.d_lens, &h.d_total};
@@ -243,11 +260,11 @@ extern "C" void w3_ctx_destroy(w3_ctx *ctx) {
             if (b->p) (void)hipFree(b->p);
         if (h.ev_d2h) (void)hipEventDestroy(h.ev_d2h);
     }
-    if (ctx->s_h2d) (void)hipStreamDestroy(ctx->s_h2d);
-    if (ctx->s_d2h) (void)hipStreamDestroy(ctx->s_d2h);
+    if (ctx->s_h2d_own) (void)hipStreamDestroy(ctx->s_h2d_own);
+    if (ctx->s_d2h_own) (void)hipStreamDestroy(ctx->s_d2h_own);
     for (auto &e : ctx->ev)
         if (e) (void)hipEventDestroy(e);
-    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    if (ctx->stream) stream_pool().give(ctx->device * 8L + 4, ctx->stream);   // (idle: the device was synchronised above)
     delete ctx;
 }
 
@@ -282,14 +299,15 @@ extern "C" int w3_ctx_set_option(w3_ctx *ctx, int opt, int64_t value) {
         return W3_OK;
     case W3_OPT_VERIFY:
         if (!value && (ctx->tp.variant & W3_VAR_INJECT_LDS_FAULT)) { ctx->err = "W3_OPT_VERIFY cannot be switched off while the fault-injection variant is set"; return W3_E_INVALID; }
-        ctx->tp.verify = value ? 1 : 0;
+        if (value < 0 || value > 256) return W3_E_INVALID;
+        ctx->tp.verify = (int)value;   // 0 = off, v >= 1: v / 256 of the blocks are re-predicted per call (twophase_verify)
         return W3_OK;
     case W3_OPT_SLOT_BUDGET_MB:
         if (value < 0 || value > (1 << 20)) return W3_E_INVALID;
         ctx->tp.slot_budget_mb = (uint32_t)value;
         return W3_OK;
     case W3_OPT_TUNE:
-        if (value < 0 || value > 0xFFFF) return W3_E_INVALID;
+        if (value < 0 || value > 0x1FFFF) return W3_E_INVALID;
         ctx->tp.tune = (uint32_t)value;
         return W3_OK;
     case W3_OPT_FAULT_BLOCK:
@@ -752,11 +770,11 @@ static void sync_job_options(w3_ctx *ctx, JobRef &J) {
 // a context does not create streams — and with them hardware-queue assignments — of its own for every workspace.
 static int attach_aux_streams(w3_ctx *ctx, JobRef &J, int j) {
     if (!ctx->s_side) {
-        ctx->s_side = stream_pool().take(ctx->device * 4L + 2);
+        ctx->s_side = stream_pool().take(ctx->device * 8L + 2);
         if (!ctx->s_side) HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->s_side, hipStreamNonBlocking));
     }
     if (!ctx->s_verify[j]) {
-        ctx->s_verify[j] = stream_pool().take(ctx->device * 4L + 3);
+        ctx->s_verify[j] = stream_pool().take(ctx->device * 8L + 3);
         if (!ctx->s_verify[j]) {
             int lo_p = 0, hi_p = 0;
             HIPCHK(ctx, hipDeviceGetStreamPriorityRange(&lo_p, &hi_p));
@@ -958,12 +976,12 @@ static int ensure_pipeline(w3_ctx *ctx) {
         HIPCHK(ctx, hipDeviceGetStreamPriorityRange(&lo_p, &hi_p));
         const bool pred_high = (ctx->tp.tune & 1u) != 0;   // W3_OPT_TUNE bit 0
         const bool plain = !(ctx->tp.tune & (1u | 16u));   // (tuning variants create their own)
-        if (!ctx->s_pred && plain) ctx->s_pred = stream_pool().take(ctx->device * 4L);
+        if (!ctx->s_pred && plain) ctx->s_pred = stream_pool().take(ctx->device * 8L);
         if (!ctx->s_pred) HIPCHK(ctx, hipStreamCreateWithPriority(&ctx->s_pred, hipStreamNonBlocking, pred_high ? hi_p : 0));
         // (created one after the other on one level: HIP deals that level's hardware queues out round-robin, so the W3_MAX_JOBS = 4 code
         // streams get a queue each and the free-running jobs' coders really run side by side)
         for (auto &sc : ctx->s_code) {
-            if (!sc && plain) sc = stream_pool().take(ctx->device * 4L + 1);
+            if (!sc && plain) sc = stream_pool().take(ctx->device * 8L + 1);
             if (!sc) HIPCHK(ctx, hipStreamCreateWithPriority(&sc, hipStreamNonBlocking, (pred_high || (ctx->tp.tune & 16u)) ? 0 : hi_p));
         }
         ctx->pooled_streams = plain;
@@ -1139,6 +1157,7 @@ extern "C" int w3_encode_wait(w3_ctx *ctx, int job) {
     JobRef J = jobref(ctx, job);
     JobState &st = J.st;
     if (st.state == 0) { ctx->err = "no such job in flight"; return W3_E_INVALID; }
+    st.total_valid = false;
     HIPCHK(ctx, hipSetDevice(ctx->device));
     if (st.state == 2) { st.state = 0; ctx->timing = st.tm; return st.sync_rc; }
     if (st.code_pending) {   // no later submit has placed this job's code stage: it goes out now
@@ -1165,6 +1184,7 @@ extern "C" int w3_encode_wait(w3_ctx *ctx, int job) {
         ctx->timing.n_lds_faults += mism;
         return rc;
     }
+    st.total_out = total; st.total_valid = true;
     memset(&ctx->timing, 0, sizeof ctx->timing);
     ctx->timing.path = W3_PATH_TWOPHASE;
     ctx->timing.coder_bytes = st.tm.coder_bytes + total; ctx->timing.predict_bytes = st.tm.predict_bytes;
@@ -1188,8 +1208,20 @@ extern "C" int w3_encode_wait(w3_ctx *ctx, int job) {
 // pageable memory HIP stages them and the enqueueing call blocks — the encodes already submitted keep the GPU busy meanwhile.
 // ---------------------------------------------------------------------------
 static int host_streams(w3_ctx *ctx) {
-    if (!ctx->s_h2d) HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->s_h2d, hipStreamNonBlocking));
-    if (!ctx->s_d2h) HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->s_d2h, hipStreamNonBlocking));
+    // The copies of BOTH directions go to the context's own stream — idle while calls are pipelined (only the synchronous entry points
+    // launch on it) — in the order the host needs them: a call's input long before its encode is submitted, a call's streams after it
+    // has been waited for; together 24 ms of a 68 ms step at 1e9 B, so the link need not run full duplex.  NO stream is created: HIP maps
+    // streams onto 4 hardware queues per priority level (unless GPU_MAX_HW_QUEUES says otherwise) by the queues' use at creation, and a
+    // copy stream that lands on the predict stream's queue holds that call's kernels back for the length of a copy (measured: 84.5 ms
+    // per call with two copy streams of their own against 72.6 with 8 hardware queues in the environment, profiles/r4_host_path/).
+    // W3_OPT_TUNE bit 16: two copy streams of their own, one per direction (for hosts that do raise GPU_MAX_HW_QUEUES).
+    if (ctx->tp.tune & 65536u) {
+        if (!ctx->s_h2d_own) HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->s_h2d_own, hipStreamNonBlocking));
+        if (!ctx->s_d2h_own) HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->s_d2h_own, hipStreamNonBlocking));
+        ctx->s_h2d = ctx->s_h2d_own; ctx->s_d2h = ctx->s_d2h_own;
+    } else {
+        ctx->s_h2d = ctx->s_d2h = ctx->stream;
+    }
     for (auto &h : ctx->hj)
         if (!h.ev_d2h) HIPCHK(ctx, hipEventCreateWithFlags(&h.ev_d2h, hipEventDisableTiming));
     return W3_OK;
@@ -1227,7 +1259,11 @@ static void host_finish_device(w3_ctx *ctx, HostJob &h) {
         HIPCHK(ctx, hipStreamSynchronize(ctx->s_d2h));
         return W3_OK;
     };
-    if (h.rc == W3_OK || h.rc == W3_E_NOSPACE) { const int r = read_total(); if (r) h.rc = r; }
+    if (h.rc == W3_OK || h.rc == W3_E_NOSPACE) {
+        const JobState &ds = ctx->js[h.djob];
+        if (ds.total_valid) h.total = ds.total_out;   // (the usual case: no device access, no wait for a copy that is in flight on the copy stream)
+        else { const int r = read_total(); if (r) h.rc = r; }
+    }
     if (h.rc == W3_E_NOSPACE && h.total > h.dcap) {
         // The device buffer is sized for the realistic bound (2 n + 64 per block: the stripes' own); a call beyond it (adversarial
         // input: up to 16 n) is encoded again, alone, with the room it asked for.
@@ -1599,6 +1635,99 @@ static ShardComms *shard_comms(const std::vector<int> &devs, std::string &err) {
     return c;
 }
 
+// The exchange step of a sharded encode: the ranks' totals (RCCL: an all-gather, checked against what the host knows), then the packed
+// streams and length tables to the root at the exclusive scan of the totals / block counts.  src_*[r]: rank r's packed streams, length
+// table and 8-byte total on ITS device; cm == nullptr: device copies (same device: D2D, other devices: peer copies) instead of RCCL.
+// The transfers run on the contexts' own streams (idle while submitted calls are in flight) and have landed when this returns.
+static int shard_gather(w3_ctx *const *ctxs, int n_ctx, int root, ShardComms *cm, void *const *src_out, void *const *src_lens, void *const *src_total,
+                        const std::vector<size_t> &nbs, const uint64_t *totals, uint8_t *d_out, size_t out_cap, uint32_t *d_block_lens) {
+    const bool use_rccl = cm != nullptr;
+    w3_ctx *rt = ctxs[root];
+    HIPCHK(rt, hipSetDevice(rt->device));
+    // 2. the sizes: with RCCL an all-gather of every rank's total (the exchange step's first half, exercised even with one rank).
+    // Nothing between ncclGroupStart and ncclGroupEnd may leave this function: an open group would swallow every later RCCL call of
+    // this thread.  So whatever can fail for other reasons (allocations, memsets) is done first, and inside a group only RCCL's own
+    // return codes are collected.
+    if (use_rccl) {
+        w3rccl::Api *rc_api = w3rccl::api();
+        for (int r = 0; r < n_ctx; r++) {
+            w3_ctx *c = ctxs[r];
+            HIPCHK(c, hipSetDevice(c->device));
+            if (!nbs[r]) HIPCHK(c, hipMemsetAsync(src_total[r], 0, 8, c->stream));   // (holds this rank's total already when the shard was not empty)
+            ENSURE(c, c->misc, 8 * (size_t)n_ctx);
+        }
+        int gs = rc_api->GroupStart();
+        const bool opened = gs == w3rccl::kSuccess;
+        for (int r = 0; r < n_ctx && gs == w3rccl::kSuccess; r++) {
+            (void)hipSetDevice(ctxs[r]->device);   // (a communicator knows its device; set for RCCL versions that look at the current one)
+            gs = rc_api->AllGather(src_total[r], ctxs[r]->misc.p, 1, w3rccl::kUint64, cm->comms[r], ctxs[r]->stream);
+        }
+        const int ge = opened ? rc_api->GroupEnd() : w3rccl::kSuccess;
+        if (gs != w3rccl::kSuccess || ge != w3rccl::kSuccess) { ctxs[0]->err = std::string("ncclAllGather: ") + rc_api->GetErrorString(gs != w3rccl::kSuccess ? gs : ge); return W3_E_HIP; }
+        std::vector<uint64_t> seen(n_ctx);
+        HIPCHK(rt, hipSetDevice(rt->device));
+        HIPCHK(rt, hipStreamSynchronize(rt->stream));
+        HIPCHK(rt, hipMemcpy(seen.data(), rt->misc.p, 8 * (size_t)n_ctx, hipMemcpyDeviceToHost));
+        for (int r = 0; r < n_ctx; r++)
+            if (seen[r] != totals[r]) { ctxs[0]->err = "sizes all-gather disagrees with the shards' totals (internal error)"; return W3_E_HIP; }
+    }
+    uint64_t sum = 0;
+    for (int r = 0; r < n_ctx; r++) sum += totals[r];
+    if (sum > out_cap) { ctxs[0]->err = "out_cap too small for the gathered streams"; return W3_E_NOSPACE; }
+
+    // 3. the streams and length tables to the root, at the exclusive scan of the totals / block counts
+    if (use_rccl) {
+        w3rccl::Api *rc_api = w3rccl::api();
+        HIPCHK(rt, hipSetDevice(rt->device));
+        {   // the root's own shard: a device copy, outside the group
+            uint64_t so = 0; size_t lo = 0;
+            for (int r = 0; r < root; r++) { so += totals[r]; lo += nbs[r]; }
+            if (totals[root]) HIPCHK(rt, hipMemcpyAsync(d_out + so, src_out[root], (size_t)totals[root], hipMemcpyDeviceToDevice, rt->stream));
+            if (nbs[root]) HIPCHK(rt, hipMemcpyAsync(d_block_lens + lo, src_lens[root], nbs[root] * 4, hipMemcpyDeviceToDevice, rt->stream));
+        }
+        int gs = rc_api->GroupStart();
+        const bool opened = gs == w3rccl::kSuccess;
+        uint64_t so = 0; size_t lo = 0;
+        for (int r = 0; r < n_ctx; r++) {
+            w3_ctx *c = ctxs[r];
+            if (r != root && nbs[r] && gs == w3rccl::kSuccess) {
+                (void)hipSetDevice(c->device);
+                // seven peers each have their own xGMI link to the root: the transfers of one group run concurrently
+                gs = rc_api->Send(src_out[r], (size_t)totals[r], w3rccl::kUint8, root, cm->comms[r], c->stream);
+                if (gs == w3rccl::kSuccess) gs = rc_api->Send(src_lens[r], nbs[r] * 4, w3rccl::kUint8, root, cm->comms[r], c->stream);
+                (void)hipSetDevice(rt->device);
+                if (gs == w3rccl::kSuccess) gs = rc_api->Recv(d_out + so, (size_t)totals[r], w3rccl::kUint8, r, cm->comms[root], rt->stream);
+                if (gs == w3rccl::kSuccess) gs = rc_api->Recv(d_block_lens + lo, nbs[r] * 4, w3rccl::kUint8, r, cm->comms[root], rt->stream);
+            }
+            so += totals[r]; lo += nbs[r];
+        }
+        const int ge = opened ? rc_api->GroupEnd() : w3rccl::kSuccess;
+        if (gs != w3rccl::kSuccess || ge != w3rccl::kSuccess) { ctxs[0]->err = std::string("RCCL gather: ") + rc_api->GetErrorString(gs != w3rccl::kSuccess ? gs : ge); return W3_E_HIP; }
+        for (int r = 0; r < n_ctx; r++) {
+            HIPCHK(ctxs[r], hipSetDevice(ctxs[r]->device));
+            HIPCHK(ctxs[r], hipStreamSynchronize(ctxs[r]->stream));
+        }
+    } else {
+        // device copies (same device: D2D; other devices: peer copies over xGMI / PCIe, no RCCL needed)
+        uint64_t so = 0; size_t lo = 0;
+        for (int r = 0; r < n_ctx; r++) {
+            w3_ctx *c = ctxs[r];
+            if (nbs[r]) {
+                if (c->device == rt->device) {
+                    HIPCHK(rt, hipMemcpyAsync(d_out + so, src_out[r], (size_t)totals[r], hipMemcpyDeviceToDevice, rt->stream));
+                    HIPCHK(rt, hipMemcpyAsync(d_block_lens + lo, src_lens[r], nbs[r] * 4, hipMemcpyDeviceToDevice, rt->stream));
+                } else {
+                    HIPCHK(rt, hipMemcpyPeerAsync(d_out + so, rt->device, src_out[r], c->device, (size_t)totals[r], rt->stream));
+                    HIPCHK(rt, hipMemcpyPeerAsync(d_block_lens + lo, rt->device, src_lens[r], c->device, nbs[r] * 4, rt->stream));
+                }
+            }
+            so += totals[r]; lo += nbs[r];
+        }
+        HIPCHK(rt, hipStreamSynchronize(rt->stream));
+    }
+    return W3_OK;
+}
+
 extern "C" int w3_rccl_library(const char *path) {
     std::lock_guard<std::mutex> lk(g_comm_mu);
     if (w3rccl::resolved()) return W3_E_INVALID;   // (the library is resolved once per process, at the first gather or status call)
@@ -1679,91 +1808,171 @@ extern "C" int w3_encode_blocks_sharded_device(w3_ctx *const *ctxs, int n_ctx, c
     for (int r = 0; r < n_ctx; r++)
         if (rcs[r]) { if (r) ctxs[0]->err = "shard " + std::to_string(r) + ": " + (ctxs[r]->err.empty() ? w3_strerror(rcs[r]) : ctxs[r]->err); return rcs[r]; }
 
-    w3_ctx *rt = ctxs[root];
-    HIPCHK(rt, hipSetDevice(rt->device));
-    // 2. the sizes: with RCCL an all-gather of every rank's total (the exchange step's first half, exercised even with one rank).
-    // Nothing between ncclGroupStart and ncclGroupEnd may leave this function: an open group would swallow every later RCCL call of
-    // this thread.  So whatever can fail for other reasons (allocations, memsets) is done first, and inside a group only RCCL's own
-    // return codes are collected.
-    if (use_rccl) {
-        w3rccl::Api *rc_api = w3rccl::api();
-        for (int r = 0; r < n_ctx; r++) {
-            w3_ctx *c = ctxs[r];
-            HIPCHK(c, hipSetDevice(c->device));
-            ENSURE(c, c->total, 8);                          // (holds this rank's total already when the shard was not empty)
-            if (!nbs[r]) HIPCHK(c, hipMemsetAsync(c->total.p, 0, 8, c->stream));
-            ENSURE(c, c->misc, 8 * (size_t)n_ctx);
-        }
-        int gs = rc_api->GroupStart();
-        const bool opened = gs == w3rccl::kSuccess;
-        for (int r = 0; r < n_ctx && gs == w3rccl::kSuccess; r++) {
-            (void)hipSetDevice(ctxs[r]->device);   // (a communicator knows its device; set for RCCL versions that look at the current one)
-            gs = rc_api->AllGather(ctxs[r]->total.p, ctxs[r]->misc.p, 1, w3rccl::kUint64, cm->comms[r], ctxs[r]->stream);
-        }
-        const int ge = opened ? rc_api->GroupEnd() : w3rccl::kSuccess;
-        if (gs != w3rccl::kSuccess || ge != w3rccl::kSuccess) { ctxs[0]->err = std::string("ncclAllGather: ") + rc_api->GetErrorString(gs != w3rccl::kSuccess ? gs : ge); return W3_E_HIP; }
-        std::vector<uint64_t> seen(n_ctx);
-        HIPCHK(rt, hipSetDevice(rt->device));
-        HIPCHK(rt, hipStreamSynchronize(rt->stream));
-        HIPCHK(rt, hipMemcpy(seen.data(), rt->misc.p, 8 * (size_t)n_ctx, hipMemcpyDeviceToHost));
-        for (int r = 0; r < n_ctx; r++)
-            if (seen[r] != totals[r]) { ctxs[0]->err = "sizes all-gather disagrees with the shards' totals (internal error)"; return W3_E_HIP; }
+    std::vector<void *> so(n_ctx), sl(n_ctx), st(n_ctx);
+    for (int r = 0; r < n_ctx; r++) {
+        w3_ctx *c = ctxs[r];
+        HIPCHK(c, hipSetDevice(c->device));
+        ENSURE(c, c->total, 8);
+        so[r] = c->io_out.p; sl[r] = c->lens.p; st[r] = c->total.p;
     }
-    uint64_t sum = 0;
-    for (int r = 0; r < n_ctx; r++) sum += totals[r];
-    if (sum > out_cap) { ctxs[0]->err = "out_cap too small for the gathered streams"; return W3_E_NOSPACE; }
+    return shard_gather(ctxs, n_ctx, root, cm, so.data(), sl.data(), st.data(), nbs, totals, d_out, out_cap, d_block_lens);
+}
 
-    // 3. the streams and length tables to the root, at the exclusive scan of the totals / block counts
-    if (use_rccl) {
-        w3rccl::Api *rc_api = w3rccl::api();
-        HIPCHK(rt, hipSetDevice(rt->device));
-        {   // the root's own shard: a device copy, outside the group
-            uint64_t so = 0; size_t lo = 0;
-            for (int r = 0; r < root; r++) { so += totals[r]; lo += nbs[r]; }
-            if (totals[root]) HIPCHK(rt, hipMemcpyAsync(d_out + so, rt->io_out.p, (size_t)totals[root], hipMemcpyDeviceToDevice, rt->stream));
-            if (nbs[root]) HIPCHK(rt, hipMemcpyAsync(d_block_lens + lo, rt->lens.p, nbs[root] * 4, hipMemcpyDeviceToDevice, rt->stream));
+// ---------------------------------------------------------------------------
+// The sharded encode as a STREAM of steps (ABI v8): every context keeps w3_encode_max_in_flight calls in flight on its device
+// (w3_encode_submit), and a step's packed streams are gathered on the root when the step is waited for — the exchange step of step k
+// runs on the contexts' own streams while the devices are already coding step k+1.  What bench.py --gpus N does through
+// torch.distributed (one process per GPU), for a host that is ONE process.
+// ---------------------------------------------------------------------------
+static int sharded_args(w3_ctx *const *ctxs, int n_ctx, std::vector<int> &devs, bool &distinct) {
+    if (!ctxs || n_ctx <= 0 || n_ctx > 64) return W3_E_INVALID;
+    devs.assign(n_ctx, 0);
+    distinct = true;
+    for (int r = 0; r < n_ctx; r++) {
+        if (!ctxs[r]) return W3_E_INVALID;
+        for (int q = 0; q < r; q++) {
+            if (ctxs[q] == ctxs[r]) { ctxs[0]->err = "the same context appears twice in ctxs[] (a context is not thread-safe)"; return W3_E_INVALID; }
+            distinct &= ctxs[q]->device != ctxs[r]->device;
         }
-        int gs = rc_api->GroupStart();
-        const bool opened = gs == w3rccl::kSuccess;
-        uint64_t so = 0; size_t lo = 0;
-        for (int r = 0; r < n_ctx; r++) {
-            w3_ctx *c = ctxs[r];
-            if (r != root && nbs[r] && gs == w3rccl::kSuccess) {
-                (void)hipSetDevice(c->device);
-                // seven peers each have their own xGMI link to the root: the transfers of one group run concurrently
-                gs = rc_api->Send(c->io_out.p, (size_t)totals[r], w3rccl::kUint8, root, cm->comms[r], c->stream);
-                if (gs == w3rccl::kSuccess) gs = rc_api->Send(c->lens.p, nbs[r] * 4, w3rccl::kUint8, root, cm->comms[r], c->stream);
-                (void)hipSetDevice(rt->device);
-                if (gs == w3rccl::kSuccess) gs = rc_api->Recv(d_out + so, (size_t)totals[r], w3rccl::kUint8, r, cm->comms[root], rt->stream);
-                if (gs == w3rccl::kSuccess) gs = rc_api->Recv(d_block_lens + lo, nbs[r] * 4, w3rccl::kUint8, r, cm->comms[root], rt->stream);
-            }
-            so += totals[r]; lo += nbs[r];
-        }
-        const int ge = opened ? rc_api->GroupEnd() : w3rccl::kSuccess;
-        if (gs != w3rccl::kSuccess || ge != w3rccl::kSuccess) { ctxs[0]->err = std::string("RCCL gather: ") + rc_api->GetErrorString(gs != w3rccl::kSuccess ? gs : ge); return W3_E_HIP; }
-        for (int r = 0; r < n_ctx; r++) {
-            HIPCHK(ctxs[r], hipSetDevice(ctxs[r]->device));
-            HIPCHK(ctxs[r], hipStreamSynchronize(ctxs[r]->stream));
-        }
-    } else {
-        // device copies (same device: D2D; other devices: peer copies over xGMI / PCIe, no RCCL needed)
-        uint64_t so = 0; size_t lo = 0;
-        for (int r = 0; r < n_ctx; r++) {
-            w3_ctx *c = ctxs[r];
-            if (nbs[r]) {
-                if (c->device == rt->device) {
-                    HIPCHK(rt, hipMemcpyAsync(d_out + so, c->io_out.p, (size_t)totals[r], hipMemcpyDeviceToDevice, rt->stream));
-                    HIPCHK(rt, hipMemcpyAsync(d_block_lens + lo, c->lens.p, nbs[r] * 4, hipMemcpyDeviceToDevice, rt->stream));
-                } else {
-                    HIPCHK(rt, hipMemcpyPeerAsync(d_out + so, rt->device, c->io_out.p, c->device, (size_t)totals[r], rt->stream));
-                    HIPCHK(rt, hipMemcpyPeerAsync(d_block_lens + lo, rt->device, c->lens.p, c->device, nbs[r] * 4, rt->stream));
-                }
-            }
-            so += totals[r]; lo += nbs[r];
-        }
-        HIPCHK(rt, hipStreamSynchronize(rt->stream));
+        devs[r] = ctxs[r]->device;
     }
     return W3_OK;
+}
+
+extern "C" int w3_encode_sharded_max_in_flight(const w3_model_spec *spec, const size_t *n, int n_ctx, size_t block_size) {
+    if (!n || n_ctx <= 0 || !block_size) return 0;
+    int depth = W3_MAX_JOBS;
+    for (int r = 0; r < n_ctx; r++)
+        if (n[r]) depth = std::min(depth, w3_encode_max_in_flight(spec, n[r], block_size));
+    return depth;
+}
+
+extern "C" int w3_encode_sharded_submit(w3_ctx *const *ctxs, int n_ctx, const w3_model_spec *spec, const uint8_t *const *d_in, const size_t *n,
+                                        size_t block_size, int *sjob) {
+    if (!sjob || !d_in || !n) return W3_E_INVALID;
+    *sjob = -1;
+    std::vector<int> devs;
+    bool distinct;
+    int rc = sharded_args(ctxs, n_ctx, devs, distinct);
+    if (rc) return rc;
+    ParsedSpec ps;
+    if ((rc = parse_spec(spec, ps))) { ctxs[0]->err = "malformed model spec"; return rc; }
+    size_t nb_total = 0;
+    for (int r = 0; r < n_ctx; r++) {
+        if ((rc = check_args(ctxs[r], n[r], block_size))) return rc;
+        if (n[r] && !d_in[r]) return W3_E_INVALID;
+        if (r + 1 < n_ctx && n[r] % block_size) { ctxs[0]->err = "every shard but the last must be a whole number of blocks (w3_shard_range)"; return W3_E_INVALID; }
+        const size_t nb = (n[r] + block_size - 1) / block_size;
+        nb_total += nb;
+        if (nb && !submit_pipelines(ctxs[r], ps, (uint32_t)nb, block_size, n[r])) {
+            ctxs[0]->err = "this spec / shard size runs synchronously inside w3_encode_submit: use the one-shot w3_encode_blocks_sharded_device";
+            return W3_E_UNSUPPORTED;
+        }
+        for (const auto &h : ctxs[r]->hj)
+            if (h.state != 0) { ctxs[0]->err = "host-buffer jobs are in flight on a context"; return W3_E_INVALID; }
+    }
+    if (nb_total == 0) { ctxs[0]->err = "nothing to encode"; return W3_E_INVALID; }
+    // the same slot on every context; as many steps in flight as the smallest w3_encode_max_in_flight among the shards
+    int slot = -1, busy = 0;
+    for (int k = 0; k < W3_MAX_JOBS; k++) {
+        bool free_everywhere = true, used = false;
+        for (int r = 0; r < n_ctx; r++) { free_everywhere &= ctxs[r]->ss[k].state == 0; used |= ctxs[r]->ss[k].state != 0; }
+        busy += used;
+        if (free_everywhere && slot < 0) slot = k;
+    }
+    const int depth = w3_encode_sharded_max_in_flight(spec, n, n_ctx, block_size);
+    if (slot < 0 || busy >= depth) {
+        ctxs[0]->err = std::to_string(busy) + " sharded steps are in flight already (at most " + std::to_string(depth) + " for shards of this size): w3_encode_sharded_wait the oldest one first";
+        return W3_E_INVALID;
+    }
+    for (int r = 0; r < n_ctx; r++) {
+        w3_ctx *c = ctxs[r];
+        w3_ctx::ShardSlot &x = c->ss[slot];
+        auto body = [&]() -> int {
+            HIPCHK(c, hipSetDevice(c->device));
+            x.nb = (n[r] + block_size - 1) / block_size; x.n = n[r]; x.d_in = d_in[r]; x.block_size = block_size; x.djob = -1;
+            x.spec = *spec;
+            if (ps.n_huff) { memcpy(x.huff_copy, ps.huff, sizeof(w3_huff_table) * ps.n_huff); x.spec.huff = x.huff_copy; }
+            ENSURE(c, x.total, 8);
+            if (!x.nb) { HIPCHK(c, hipMemsetAsync(x.total.p, 0, 8, c->stream)); return W3_OK; }
+            x.cap = n[r] + n[r] / 4 + 64 * x.nb + 1024;   // realistic bound; a shard beyond it is redone with the room it asks for (the wait)
+            ENSURE(c, x.out, x.cap);
+            ENSURE(c, x.lens, x.nb * 4);
+            return w3_encode_submit(c, &x.spec, d_in[r], n[r], block_size, (uint8_t *)x.out.p, x.cap, (uint32_t *)x.lens.p, (uint64_t *)x.total.p, nullptr, &x.djob);
+        };
+        rc = body();
+        if (rc) {   // leave nothing in flight behind an error: the shards submitted so far are completed and dropped
+            if (r) ctxs[0]->err = "shard " + std::to_string(r) + ": " + (c->err.empty() ? w3_strerror(rc) : c->err);
+            for (int q = 0; q < r; q++) {
+                w3_ctx::ShardSlot &y = ctxs[q]->ss[slot];
+                if (y.djob >= 0) (void)w3_encode_wait(ctxs[q], y.djob);
+                y.state = 0; y.djob = -1;
+            }
+            return rc;
+        }
+        x.state = 1;
+    }
+    *sjob = slot;
+    return W3_OK;
+}
+
+extern "C" int w3_encode_sharded_wait(w3_ctx *const *ctxs, int n_ctx, int sjob, int root, uint8_t *d_out, size_t out_cap, uint32_t *d_block_lens,
+                                      uint64_t *totals, int transport) {
+    if (!totals || sjob < 0 || sjob >= W3_MAX_JOBS || root < 0 || root >= n_ctx) return W3_E_INVALID;
+    if (transport < W3_GATHER_AUTO || transport > W3_GATHER_PEER_COPY) return W3_E_INVALID;
+    std::vector<int> devs;
+    bool distinct;
+    int rc = sharded_args(ctxs, n_ctx, devs, distinct);
+    if (rc) return rc;
+    for (int r = 0; r < n_ctx; r++)
+        if (ctxs[r]->ss[sjob].state != 1) { ctxs[0]->err = "no such sharded step in flight"; return W3_E_INVALID; }
+    if (!d_out || !d_block_lens) return W3_E_INVALID;
+    const bool use_rccl = transport == W3_GATHER_RCCL || (transport == W3_GATHER_AUTO && distinct && n_ctx > 1);
+    if (use_rccl && !distinct) { ctxs[0]->err = "W3_GATHER_RCCL needs one device per context"; return W3_E_INVALID; }
+    // 1. the shards' encodes (the devices run them concurrently; the waits only read pinned status words)
+    std::vector<size_t> nbs(n_ctx, 0);
+    int first_rc = W3_OK;
+    for (int r = 0; r < n_ctx; r++) {
+        w3_ctx *c = ctxs[r];
+        w3_ctx::ShardSlot &x = c->ss[sjob];
+        nbs[r] = x.nb;
+        totals[r] = 0;
+        auto body = [&]() -> int {
+            if (x.djob < 0) return W3_OK;
+            int rc1 = w3_encode_wait(c, x.djob);
+            uint64_t t = 0;
+            const JobState &ds = c->js[x.djob];
+            if (rc1 == W3_OK || rc1 == W3_E_NOSPACE) {
+                if (ds.total_valid) t = ds.total_out;
+                else { HIPCHK(c, hipSetDevice(c->device)); HIPCHK(c, hipMemcpy(&t, x.total.p, 8, hipMemcpyDeviceToHost)); }
+            }
+            if (rc1 == W3_E_NOSPACE && t > x.cap) {   // beyond the realistic bound: once more, alone, with the room it asked for
+                HIPCHK(c, hipSetDevice(c->device));
+                HIPCHK(c, hipDeviceSynchronize());
+                ENSURE(c, x.out, (size_t)t);
+                x.cap = (size_t)t;
+                rc1 = encode_core(c, jobref(c, x.djob), &x.spec, x.d_in, x.n, x.block_size, (uint8_t *)x.out.p, x.cap, (uint32_t *)x.lens.p, (uint64_t *)x.total.p, c->stream);
+                if (rc1 == W3_OK) HIPCHK(c, hipMemcpy(&t, x.total.p, 8, hipMemcpyDeviceToHost));
+            }
+            totals[r] = t;
+            return rc1;
+        };
+        const int rc1 = body();
+        if (rc1 && first_rc == W3_OK) { first_rc = rc1; if (r) ctxs[0]->err = "shard " + std::to_string(r) + ": " + (c->err.empty() ? w3_strerror(rc1) : c->err); }
+    }
+    // 2. the exchange step
+    int grc = first_rc;
+    if (grc == W3_OK) {
+        ShardComms *cm = nullptr;
+        if (use_rccl && !(cm = shard_comms(devs, ctxs[0]->err))) grc = W3_E_HIP;
+        if (grc == W3_OK) {
+            std::vector<void *> so(n_ctx), sl(n_ctx), st(n_ctx);
+            for (int r = 0; r < n_ctx; r++) { w3_ctx::ShardSlot &x = ctxs[r]->ss[sjob]; so[r] = x.out.p; sl[r] = x.lens.p; st[r] = x.total.p; }
+            grc = shard_gather(ctxs, n_ctx, root, cm, so.data(), sl.data(), st.data(), nbs, totals, d_out, out_cap, d_block_lens);
+        }
+    }
+    for (int r = 0; r < n_ctx; r++) { ctxs[r]->ss[sjob].state = 0; ctxs[r]->ss[sjob].djob = -1; }
+    return grc;
 }
 
 // ---------------------------------------------------------------------------

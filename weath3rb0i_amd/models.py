@@ -76,9 +76,8 @@ class ACHistoryCached(ACHistory):
     cache_size (and cache_size/2) history bits and the alignment.  The memo only skips re-encoding a prefix whose
     coder state is a pure function of its key, so hash() returns exactly ACHistory's value: cache_size changes the
     reference's CPU time, not its output (its own logs agree: bin/entropy-hashing-ac-cached/book1.mc.3.log:362 and
-    bin/entropy-hashing-ac/book1.log:139 both give 262,871 bytes at (20, 3)).  Tested, not only argued: the oracle restates
-    ac_history_cached.rs:37-76 with its memo (oracle/w3_oracle.c, w3o_achc_*) and tests/test_oracle_kats.py::
-    test_ac_history_cached_equals_ac_history compares hash() with ACHistory's after every update for cache sizes 0..24, every
+    bin/entropy-hashing-ac/book1.log:139 both give 262,871 bytes at (20, 3)).  Tested, not only argued: the CPU checker restates
+    ac_history_cached.rs:37-76 with its memo, and tests/test_oracle_kats.py::test_ac_history_cached_equals_ac_history compares hash() with ACHistory's after every update for cache sizes 0..24, every
     alignment and three tables.  On the GPU every step's hash is computed in parallel (k_achash), so there is nothing to
     memoise: same spec as ACHistory."""
 
