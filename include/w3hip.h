@@ -278,7 +278,8 @@ enum { W3_GATHER_AUTO = 0, W3_GATHER_RCCL = 1, W3_GATHER_PEER_COPY = 2 };
  * shard takes 25.7 ms one call at a time and 12.0 ms with four in flight: DESIGN.md section 5).
  *   w3_encode_sharded_submit  d_in / n as above; enqueues every shard's encode (w3_encode_submit on its context, into staging buffers
  *                     of the context) and returns a step handle (0 .. 3).  Inputs must stay valid until the step has been waited
- *                     for.  W3_E_UNSUPPORTED for specs / shard sizes that w3_encode_submit runs synchronously (use the one-shot call),
+ *                     for.  Shards that w3_encode_submit runs synchronously (a tail below 8 bytes, lane-per-block specs) are coded
+ *                     inside this call, one context after the other (such specs are better served by the one-shot call).
  *                     W3_E_INVALID when w3_encode_sharded_max_in_flight steps are in flight already.
  *   w3_encode_sharded_wait    completes step sjob's encodes, then the exchange step (as above: sizes all-gather + grouped ncclSend /
  *                     ncclRecv to ctxs[root]'s d_out / d_block_lens, or device copies) and returns when the streams have landed;

@@ -105,7 +105,7 @@ def test_sharded_stream_of_steps_one_device():
 def test_failing_shard_leaves_no_group_open_and_nothing_in_flight():
     """One shard fails (its context is pinned to the two-phase path and its shard is too short for it): the one-shot sharded call
     returns that shard's error — and the NEXT calls on the same contexts, RCCL transport included, work: no RCCL group was left open,
-    no job in flight.  The stream form refuses what it cannot pipeline."""
+    no job in flight.  The stream form reports the same error from its wait."""
     import torch
     from weath3rb0i_amd import _lib as L
     cs = [w3.Context(0) for _ in range(2)]
@@ -123,10 +123,14 @@ def test_failing_shard_leaves_no_group_open_and_nothing_in_flight():
         with pytest.raises(w3.W3Error) as e:
             w3.encode_blocks_sharded_device(cs, model, [head, tail], bs, d_out, d_lens)
         assert e.value.code == L.W3_E_UNSUPPORTED and "shard 1" in str(e.value)
+        sj = w3.encode_sharded_submit(cs, model, [head, tail], bs)   # (the short shard runs inside submit; its error comes from the wait)
         with pytest.raises(w3.W3Error) as e:
-            w3.encode_sharded_submit(cs, model, [head, tail], bs)
-        assert e.value.code == L.W3_E_UNSUPPORTED
+            w3.encode_sharded_wait(cs, sj, d_out, d_lens)
+        assert e.value.code == L.W3_E_UNSUPPORTED and "shard 1" in str(e.value)
         cs[1].set_path("auto")
+        sj = w3.encode_sharded_submit(cs, model, [head, tail], bs)
+        totals = w3.encode_sharded_wait(cs, sj, d_out, d_lens)
+        assert sum(totals) == len(want) and d_out[:len(want)].cpu().numpy().tobytes() == want.tobytes()
         totals = w3.encode_blocks_sharded_device(cs, model, [head, tail], bs, d_out, d_lens)
         assert sum(totals) == len(want) and d_out[:len(want)].cpu().numpy().tobytes() == want.tobytes()
         totals = w3.encode_blocks_sharded_device(cs[:1], model, [torch.from_numpy(data).cuda()], bs, d_out, d_lens, transport="rccl")

@@ -4,7 +4,8 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SO = os.path.join(HERE, "libw3hip.so")
+# W3HIP_SO: another build of the same library (A/B experiments: `python -m weath3rb0i_amd.build --out libw3hip_x.so -DW3_...`)
+SO = os.environ.get("W3HIP_SO") or os.path.join(HERE, "libw3hip.so")
 
 W3_MAX_NODES = 31
 W3_NODE_ORDERN, W3_NODE_BEST_OF_TWO, W3_NODE_SLOT_STATE, W3_NODE_APM = 1, 2, 3, 4

@@ -303,6 +303,7 @@ __device__ __forceinline__ uint2 x4_step_c(uint32_t &x1, uint32_t &d, const uint
 }
 
 typedef uint32_t w3_u32x3 __attribute__((ext_vector_type(3)));
+typedef uint32_t w3_u32x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) uint8_t w3_lds_u8;
 
 // L > 1 leaf streams: the mix makes the M-wave's chunk longer than the X-wave's, so TWO M-waves take alternate chunks

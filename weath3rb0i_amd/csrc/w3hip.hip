@@ -1864,10 +1864,9 @@ extern "C" int w3_encode_sharded_submit(w3_ctx *const *ctxs, int n_ctx, const w3
         if (r + 1 < n_ctx && n[r] % block_size) { ctxs[0]->err = "every shard but the last must be a whole number of blocks (w3_shard_range)"; return W3_E_INVALID; }
         const size_t nb = (n[r] + block_size - 1) / block_size;
         nb_total += nb;
-        if (nb && !submit_pipelines(ctxs[r], ps, (uint32_t)nb, block_size, n[r])) {
-            ctxs[0]->err = "this spec / shard size runs synchronously inside w3_encode_submit: use the one-shot w3_encode_blocks_sharded_device";
-            return W3_E_UNSUPPORTED;
-        }
+        // (a shard that w3_encode_submit runs synchronously — a ragged tail below 8 bytes, a lane-per-block spec — is coded inside this
+        // call, one context after the other: correct, but such specs are better served by the one-shot form, which codes the shards from
+        // one host thread each)
         for (const auto &h : ctxs[r]->hj)
             if (h.state != 0) { ctxs[0]->err = "host-buffer jobs are in flight on a context"; return W3_E_INVALID; }
     }
