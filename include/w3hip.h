@@ -140,14 +140,17 @@ enum {
                            32 = FAULT INJECTION (test hook of the sampled verification): one LDS-add round of every block returns two
                            lanes each other's value; refused (W3_E_INVALID) unless W3_OPT_VERIFY is on, so it cannot corrupt output */
     W3_OPT_SLOT_BUDGET_MB = 8, /* cap (MiB) on the device memory one batch of slot-state hash maps may take; 0 = derive from free memory */
-    W3_OPT_VERIFY = 9,  /* 1 (default): after every two-phase predict that used returning LDS adds — whose lane-ordered resolution is
-                           measured, not documented by the ISA — max(16, nblocks / 256) sampled full-length blocks (at most 64 MiB of
-                           input; the sample rotates from call to call) are predicted again with ballot rounds and compared on the
-                           device; on a mismatch the call is re-encoded on the ballot path (w3_timing.n_lds_faults) and the context
-                           stays there.  What it covers: a SYSTEMATIC change of the hardware's behaviour shows in any block and is
-                           caught by the first call; a sporadic mis-order in one unsampled block is caught only with probability
-                           sample / nblocks per call.  Full coverage = decode the output (w3_decode_blocks_device shares no kernel
-                           with the predict phase; bench.py does that for every block of its last step).  0 = off */
+    W3_OPT_VERIFY = 9,  /* v = 1 (default) .. 256: after every two-phase predict that used returning LDS adds — whose lane-ordered resolution
+                           is measured, not documented by the ISA — max(16, nblocks * v / 256) sampled full-length blocks (at most v x 64 MiB of
+                           input; the sample ROTATES from call to call, over all blocks in 256 / v calls) are predicted again with ballot rounds
+                           and compared on the device; on a mismatch the call is re-encoded on the ballot path (w3_timing.n_lds_faults) and the
+                           context stays there.  Cost at 1e9 B beside the coder: v = 1 +1.0 ms per 67.5 ms step, v = 2 +1.3, v = 4 +2.1.
+                           RESIDUAL RISK, per call: a SYSTEMATIC change of the hardware's behaviour shows in any block and is caught by the
+                           first call; a fault confined to ONE block is missed with probability 1 - v/256 (and met after at most 256 / v
+                           calls); a fault that hits each block independently with probability q is missed with probability (1 - q)^S,
+                           S = the sample size.  A full in-round check needs a second returning LDS atomic per add (+6 ms per
+                           step) and was not built.  Full coverage = decode the output (w3_decode_blocks_device shares no kernel with the
+                           predict phase; bench.py does that for every block of its last step).  0 = off */
     W3_OPT_TUNE = 11,   /* scheduling experiments of the submit / wait pipeline (bit mask; output is identical whatever is set) */
     W3_OPT_FAULT_BLOCK = 10, /* test hook, with W3_OPT_VARIANT bit 32: the one block the injected fault hits (-1 = every block, default) */
     W3_OPT_HOST_CHUNK_BLOCKS = 12 /* w3_encode_blocks: blocks per pipelined piece of a host-buffer call (0 = default: equal pieces of at most
@@ -327,7 +330,9 @@ int w3_export_counters(w3_ctx *ctx, const w3_model_spec *spec, const uint8_t *in
 
 /* ---- the reference's whole-file container ----------------------------------
  * compress()/decompress() of main.rs:89-144: b"w30i" + u64 BE length + ONE
- * stream.  One serial chain => one GPU lane; provided for format parity.     */
+ * stream.  One serial chain => one GPU lane; provided for format parity.
+ * Inputs above 2^28 bytes are refused with W3_E_UNSUPPORTED (w3_last_error names the block container as the route:
+ * a single lane codes 2^28 bytes in about ten minutes; the reference's format has no blocks to code in parallel). */
 int w3_compress_stream(w3_ctx *ctx, const w3_model_spec *spec,
                        const uint8_t *in, size_t n, uint8_t *out, size_t out_cap, size_t *out_len);
 int w3_decompress_stream(w3_ctx *ctx, const w3_model_spec *spec,

@@ -199,26 +199,13 @@ __global__ void __launch_bounds__(L > 1 ? 256 : 192) k_coder_x5(Coder3Args a) {
         auto load = [&](Buf &bf, uint32_t i0) {
             // the chunk's input bytes as ONE unaligned dword load at min(i0, len - 4) (never past the block's end); shifted into place after
             const uint64_t want = off + i0, at = want < blk_end4 ? want : blk_end4;
-#ifdef W3_EXP_CODER_NOLOAD   // timing experiment (profiles/r4_experiments): the M-wave without its global loads — WRONG OUTPUT
-            uint32_t w = (uint32_t)at * 2654435761u;
-#else
             uint32_t w; __builtin_memcpy(&w, a.in + at, 4);
-#endif
             bf.bytes = w; bf.sh = (uint32_t)(want - at) * 8u;
 #pragma unroll
             for (uint32_t k = 0; k < CH; k++) {
                 const uint32_t ic = min(i0 + k, last);
 #pragma unroll
-                for (int l = 0; l < L; l++) {
-#ifdef W3_EXP_CODER_NOLOAD
-                    bf.p[l][k] = make_uint4(0x80007000u + ic, 0x90008000u, 0x70008800u, 0x80009000u + lane);
-#elif defined(W3_CODER_NT)   // experiment (profiles/r4_experiments): the streams as non-temporal loads, so that 16 GB read once do not sweep the Infinity Cache the rank kernels' partial lines merge in
-                    const w3_u32x4 t_ = __builtin_nontemporal_load(reinterpret_cast<const w3_u32x4 *>(a.src[l] + off + ic));
-                    bf.p[l][k] = make_uint4(t_.x, t_.y, t_.z, t_.w);
-#else
-                    bf.p[l][k] = a.src[l][off + ic];
-#endif
-                }
+                for (int l = 0; l < L; l++) bf.p[l][k] = a.src[l][off + ic];
             }
         };
         uint32_t seen = 0;   // last value read from x_done

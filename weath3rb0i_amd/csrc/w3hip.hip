@@ -112,6 +112,7 @@ struct w3_ctx {
     hipStream_t s_h2d_own = nullptr, s_d2h_own = nullptr;
     uint64_t hseq = 0;
     uint32_t host_chunk_blocks = 0;                 // W3_OPT_HOST_CHUNK_BLOCKS (0 = auto)
+    uint32_t n_encodes = 0;                         // rotates the sampled verification over the blocks, whichever job slot a call lands on
 };
 
 // the members of job j under one name
@@ -823,6 +824,7 @@ static int encode_core(w3_ctx *ctx, JobRef J, const w3_model_spec *spec, const u
     sync_job_options(ctx, J);
     if ((rc = attach_aux_streams(ctx, J, &J.tp == &ctx->tp ? 0 : (int)(&J.st - ctx->js)))) return rc;
     J.tp.half_cu = (ctx->tp.variant & W3_VAR_HALF_CU) != 0;
+    J.tp.verify_calls = ctx->n_encodes++;
 
     hipEvent_t *evp = ctx->opt_timing ? J.ev : nullptr;
     uint32_t cap = default_stripe_cap(block_size);
@@ -1096,6 +1098,7 @@ extern "C" int w3_encode_submit(w3_ctx *ctx, const w3_model_spec *spec, const ui
     sync_job_options(ctx, J);
     if ((rc = attach_aux_streams(ctx, J, j))) return rc;
     J.tp.half_cu = !(ctx->tp.variant & W3_VAR_FULL_CU);
+    J.tp.verify_calls = ctx->n_encodes++;   // (the sample's rotation is the context's: a call's job slot does not matter)
     st.cap = default_stripe_cap(block_size);
     ENSURE(ctx, J.stripes, (size_t)nb * st.cap);
     hipEvent_t *evp = st.timed ? J.ev : nullptr;
@@ -1981,7 +1984,9 @@ extern "C" int w3_compress_stream(w3_ctx *ctx, const w3_model_spec *spec, const 
                                   size_t *out_len) {
     if (!ctx || !out_len) return W3_E_INVALID;
     *out_len = 0;
-    if (n > (1u << 28)) { ctx->err = "single-stream container limited to 2^28 bytes on the device"; return W3_E_UNSUPPORTED; }
+    // One stream is one serial chain = ONE GPU lane (~260 ns per bit-step: 2^28 bytes take ~10 minutes); larger inputs belong in the block
+    // container, which is what the device is for — the reference's format has no blocks to code in parallel.
+    if (n > (1u << 28)) { ctx->err = "the w30i single-stream container is limited to 2^28 bytes on the device (one serial chain = one GPU lane): use the block container (w3_encode_blocks; tools/w3cli without W3_CONTAINER=w30i) for larger inputs"; return W3_E_UNSUPPORTED; }
     int rc = w3_spec_validate(spec);
     if (rc) return rc;
     uint8_t hdr[12] = {'w', '3', '0', 'i'};
@@ -2013,7 +2018,7 @@ extern "C" int w3_decompress_stream(w3_ctx *ctx, const w3_model_spec *spec, cons
     for (int i = 0; i < 8; i++) len = (len << 8) | in[4 + i];
     *out_len = (size_t)len;
     if (len == 0) return w3_spec_validate(spec);
-    if (len > (1u << 28)) { ctx->err = "single-stream container limited to 2^28 bytes on the device"; return W3_E_UNSUPPORTED; }
+    if (len > (1u << 28)) { ctx->err = "the w30i single-stream container is limited to 2^28 bytes on the device (one serial chain = one GPU lane); larger inputs use the block container (w3_decode_blocks)"; return W3_E_UNSUPPORTED; }
     if (len > out_cap || !out) return W3_E_NOSPACE;
     uint32_t blen = (uint32_t)(in_len - 12);
     uint8_t zero = 0;
