@@ -15,6 +15,8 @@ model, mname = bench.make_model(w3, name)
 ctx = w3.Context(0)
 if len(sys.argv) > 3 and sys.argv[3] == "lane":
     ctx.set_variant("decode_lane")
+if len(sys.argv) > 3 and sys.argv[3].isdigit():
+    ctx.set_tune(int(sys.argv[3]))   # W3_OPT_TUNE: 131072 = exact maps probed slot by slot, 262144 = APM tables row-major (k_decode_spec's table formats)
 host = synth.text(n, seed=1)
 d_in = torch.from_numpy(host).cuda()
 d_out = torch.empty(n + n // 4 + 64 * nb + 1024, dtype=torch.uint8, device="cuda")

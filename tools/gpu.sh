@@ -15,6 +15,8 @@
 #   traffic <model> [bench args] the evidence set of one model: kernel stats + FETCH_SIZE pass + WRITE_SIZE pass (separate runs, as
 #                               MI355X_MICROARCH.md prescribes) of bench.py --quick --steps 2 --warmup 1 --model <model> args
 #                               -> traffic_<model>.json (entries in the format of profiles/r*_traffic.json) + the per-pass summaries
+#   pmcpy <counters> <script> [args]   one rocprofv3 --pmc pass of python3 <script> args (e.g. tools/decode_rate.py); per-kernel sums
+#   statspy <script> [args]     rocprofv3 --kernel-trace --stats of python3 <script> args
 #   decode [model] [bytes]      tools/decode_rate.py
 #   py <script> [args]          python3 <script> args
 #   ubench <file.hip> [args]    hipcc a tools/*.hip microbenchmark and run it
@@ -49,11 +51,11 @@ except Exception as e:
 EOF
         tail -3 "$DST/bench_$n.err"; return $rc ;;
     stats)
-        (cd /tmp && timeout -k 10 900 rocprofv3 --kernel-trace --stats -d "$DST/stats_$n" -o run -- python3 "$OLDPWD/bench.py" --quick "$@" > "$DST/stats_$n.json" 2> "$DST/stats_$n.err"); local rc=$?
+        (cd /tmp && timeout -k 10 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$DST/stats_$n" -o run -- python3 "$OLDPWD/bench.py" --quick "$@" > "$DST/stats_$n.json" 2> "$DST/stats_$n.err"); local rc=$?
         find "$DST/stats_$n" -name '*kernel_stats.csv' | head -1 | xargs -r head -25; return $rc ;;
     pmc)
         local ctr=$1; shift
-        (cd /tmp && timeout -k 10 900 rocprofv3 --pmc ${ctr//,/ } -d "$DST/pmc_${n}" -o run -- python3 "$OLDPWD/bench.py" --quick "$@" > "$DST/pmc_$n.json" 2> "$DST/pmc_$n.err"); local rc=$?
+        (cd /tmp && timeout -k 10 900 rocprofv3 --pmc ${ctr//,/ } --output-format csv -d "$DST/pmc_${n}" -o run -- python3 "$OLDPWD/bench.py" --quick "$@" > "$DST/pmc_$n.json" 2> "$DST/pmc_$n.err"); local rc=$?
         python3 tools/pmc_sum.py "$DST/pmc_$n" 2>&1 | tail -40; return $rc ;;
     timeline)
         (cd /tmp && timeout -k 10 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$DST/kt_$n" -o kt -- python3 "$OLDPWD/bench.py" --steps 6 --warmup 2 --quick "$@" > "$DST/timeline_$n.json" 2> "$DST/timeline_$n.err"); local rc=$?
@@ -73,6 +75,14 @@ EOF
             rm -rf "$DST/tr_${model}_$c"
         done
         python3 tools/traffic_json.py "$model" "$DST" "$@" | tail -30; return $? ;;
+    pmcpy)
+        local ctr=$1; shift
+        (cd /tmp && timeout -k 10 900 rocprofv3 --pmc ${ctr//,/ } --output-format csv -d "$DST/pmcpy_${n}" -o run -- python3 "$OLDPWD/$1" "${@:2}" > "$DST/pmcpy_$n.txt" 2> "$DST/pmcpy_$n.err"); local rc=$?
+        python3 tools/pmc_sum.py "$DST/pmcpy_$n" --json "$DST/pmcpy_$n.json" 2>&1 | tail -30; rm -rf "$DST/pmcpy_$n"; tail -2 "$DST/pmcpy_$n.txt"; return $rc ;;
+    statspy)
+        (cd /tmp && timeout -k 10 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$DST/statspy_$n" -o run -- python3 "$OLDPWD/$1" "${@:2}" > "$DST/statspy_$n.txt" 2> "$DST/statspy_$n.err"); local rc=$?
+        find "$DST/statspy_$n" -name '*kernel_stats.csv' -exec cp {} "$DST/statspy_${n}_kernel_stats.csv" \;
+        rm -rf "$DST/statspy_$n"; head -12 "$DST/statspy_${n}_kernel_stats.csv"; tail -2 "$DST/statspy_$n.txt"; return $rc ;;
     decode)
         timeout -k 10 900 python3 tools/decode_rate.py "$@" > "$DST/decode_$n.txt" 2>&1; local rc=$?
         tail -12 "$DST/decode_$n.txt"; return $rc ;;

@@ -27,6 +27,7 @@ struct CmArgs {
     const uint2   *st;        // [kStSize] {prob | next0 << 16, next1 | conf << 16}
     const int16_t *stretch;   // [4096]
     const uint16_t *squash;   // [4095] (APM table initialisation only)
+    uint32_t dflags;          // k_decode_spec table formats (W3_OPT_TUNE bits 17 / 18): bit 0 = exact maps probed slot by slot, bit 1 = APM tables row-major
 };
 
 // ---- Cell / Slot (hashmap.rs:31-129), byte-exact layout: 6 tag bytes + 90 state bytes ----------------
@@ -97,16 +98,19 @@ __device__ __forceinline__ uint8_t *slot_select(uint8_t *cells, uint32_t log_cel
 }
 
 // APM tables start as the identity map: t[row][j] = squash((j - 16) * 128)
+// rows x 33 identity entries per lane.  nibble_major: k_decode_spec's layout [page][17 groups][33][16 nodes] (rows = pages * 272): an entry's
+// value depends on its j alone, which is (index / 16) % 33 there and index % 33 in the row-major tables of every other kernel.
 __global__ void __launch_bounds__(256) k_cm_init_apm(uint8_t *tables, uint64_t lane_stride, uint64_t off, uint32_t rows,
-                                                    uint32_t n_lanes, const uint16_t *squash) {
+                                                    uint32_t n_lanes, const uint16_t *squash, uint32_t nibble_major) {
     const uint64_t per_lane = (uint64_t)rows * 33u;
     const uint64_t total = per_lane * n_lanes;
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (uint64_t)gridDim.x * blockDim.x) {
         const uint64_t lane = i / per_lane;
-        const uint32_t j = (uint32_t)((i - lane * per_lane) % 33u);
+        const uint64_t e = i - lane * per_lane;
+        const uint32_t j = (uint32_t)((nibble_major ? e / 16u : e) % 33u);
         int d = ((int)j - 16) * 128;
         d = d < -2047 ? -2047 : d > 2047 ? 2047 : d;
-        reinterpret_cast<uint16_t *>(tables + lane * lane_stride + off)[i - lane * per_lane] = squash[d + 2047];
+        reinterpret_cast<uint16_t *>(tables + lane * lane_stride + off)[e] = squash[d + 2047];
     }
 }
 

@@ -35,6 +35,47 @@ __device__ __forceinline__ uint32_t pl_ld32(const uint32_t *p) { return __hip_at
 __device__ __forceinline__ void pl_st32(uint32_t *p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 __device__ __forceinline__ void pl_st16(uint16_t *p, uint16_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 
+// Bucketed exact map, SIXTEEN LANES PER BLOCK (D = 4): one load per lane.  Lane r of the row fetches slot r of the family's bucket — one
+// 128-byte request per row instead of sixteen 8-byte loads per lane (with those the kernel was no longer bound by HBM traffic, which the
+// buckets had cut from 7.2 to 2.9 TB per 1e9 B, but by its load instructions: profiles/r4_decode/) — and DECODES the key it finds: a stored
+// context (window << 3 | bit position) names its own node of the nibble's tree (bit position & 3 = k, the window's low k bits = x) and the
+// history it belongs to (the window's other bits); if that is this nibble's history the holder posts {slot + 1, counts} to the node's lane
+// through a 512-byte LDS board.  A lane is through when its context was posted (found), or when the bucket has an empty slot (absent: a path
+// node claims from there); a full bucket without it makes the whole row go on to the next bucket.
+__device__ __forceinline__ void bucket_lookup16(uint32_t *tbl, uint32_t bmask, uint32_t fam, uint64_t hn, uint32_t H, uint32_t half, uint32_t mykey,
+                                                uint32_t lane, uint32_t r, uint32_t row0, uint64_t *board, uint32_t *&slot, uint32_t &val, uint32_t &ins) {
+    uint32_t hb = (fam * 2654435761u) ^ (fam >> 13);
+    bool done = false;
+    ins = 0xFFFFFFFFu;
+    (void)mykey;
+    for (;;) {
+        hb &= bmask;
+        const uint64_t kv = ds_ld64(reinterpret_cast<const uint64_t *>(tbl + 32u * hb) + r);
+        const uint32_t key = (uint32_t)kv;
+        __asm__ volatile("" ::: "memory");
+        board[lane] = 0ull;
+        __asm__ volatile("" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+        {
+            const uint32_t c = key - 1u, bp = c & 7u, kn = bp & 3u, W = c >> 3;
+            const uint32_t xh = W & ((1u << kn) - 1u), Rh = W >> kn;
+            const bool cand = key != 0u && (bp >> 2) == half && Rh == ((uint32_t)hn & ((1u << (H - kn)) - 1u));
+            if (cand) board[row0 + (1u << kn) - 1u + xh] = ((uint64_t)(hb * 16u + r + 1u) << 32) | (kv >> 32);
+        }
+        __asm__ volatile("" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+        const uint64_t e = board[lane];
+        const uint32_t empties = (uint32_t)(__ballot(key == 0u) >> row0) & 0xFFFFu;
+        if (!done) {
+            if ((uint32_t)(e >> 32)) { slot = tbl + 2u * ((uint32_t)(e >> 32) - 1u) + 1u; val = (uint32_t)e; done = true; }
+            else if (empties) { ins = hb * 16u + (uint32_t)(__ffs((int)empties) - 1); done = true; }
+        }
+        const uint32_t pending = (uint32_t)(__ballot(!done) >> row0) & 0xFFFFu;   // some lane of my row has to look into the next bucket: the row goes on together
+        if (!__ballot(pending != 0u)) break;
+        if (pending) hb++;
+    }
+}
+
 // The Counter look-up of one leaf of k_decode_spec's node (its own macro: the kernel issues these before it stages the slot leaves' Cells).
 // Direct tables are NIBBLE-MAJOR (this kernel's own layout; the table is scratch, zeroed per call): a raw-history context of alignment 3 is a
 // window of H = bits - 3 history bits plus the bit position.  For node (k, x) of a nibble that starts with history h the window is
@@ -55,6 +96,38 @@ __device__ __forceinline__ void pl_st16(uint16_t *p, uint16_t v) { __hip_atomic_
                             idx = (((((t >> 2) & 1u) << (H - 3u)) | gq) << 5) | (kn << 3) | (v << kn) | xn; \
                         } \
                         slot[l] = tbl + idx; val[l] = pl_ld32(slot[l]); \
+                    } \
+                    else if (!(a.dflags & 1u) && lp[l].hist <= W3_HIST_RAW && lp[l].align == 3u && lp[l].bits >= 6u) { \
+                        /* NIBBLE-MAJOR BUCKETS of the exact map (raw history, alignment 3): the 15 candidate contexts of a nibble differ only in   \
+                           the bits the nibble decodes, so they share (half, g) — hash THAT to a 128-byte bucket of 16 slots {ctx + 1, counts}: one   \
+                           line per nibble and leaf instead of 15 random 8-byte probes (1.5 KB of lines, profiles/r3_decode_spec/README.md).        \
+                           Found, or absent (a bucket with an empty slot ends the probe); a full bucket without the key continues in the next one. */ \
+                        const uint32_t H = lp[l].bits - 3u; \
+                        const uint32_t tb = t & 3u; \
+                        const uint64_t hn = hist64 >> tb; \
+                        const uint32_t fam = ((((t >> 2) & 1u) << (H - 3u)) | ((uint32_t)hn & ((1u << (H - 3u)) - 1u))) + 1u; \
+                        const uint32_t bmask = lp[l].hash_mask >> 4; \
+                        if constexpr (D == 4) { \
+                            bucket_lookup16(tbl, bmask, fam, hn, H, (t >> 2) & 1u, ctx[l] + 1u, lane, r, row0, s_board, slot[l], val[l], ins[l]); \
+                        } else { \
+                        uint32_t hb = (fam * 2654435761u) ^ (fam >> 13); \
+                        ins[l] = 0xFFFFFFFFu; \
+                        for (;;) { \
+                            hb &= bmask; \
+                            const uint64_t *bk = reinterpret_cast<const uint64_t *>(tbl + 32u * hb); \
+                            uint64_t kv[16]; \
+                            _Pragma("unroll") for (int sl_ = 0; sl_ < 16; sl_++) kv[sl_] = ds_ld64(bk + sl_); \
+                            bool hit = false; uint32_t first_empty = 16u; \
+                            _Pragma("unroll") for (int sl_ = 15; sl_ >= 0; sl_--) { \
+                                const uint32_t key = (uint32_t)kv[sl_]; \
+                                if (key == ctx[l] + 1u) { slot[l] = tbl + 32u * hb + 2u * (uint32_t)sl_ + 1u; val[l] = (uint32_t)(kv[sl_] >> 32); hit = true; } \
+                                if (key == 0u) first_empty = (uint32_t)sl_; \
+                            } \
+                            if (hit) break; \
+                            if (first_empty < 16u) { ins[l] = hb * 16u + first_empty; break; }   /* absent: a path node claims from here on */ \
+                            hb++; \
+                        } \
+                        } \
                     } \
                     else { \
                         uint32_t h = (ctx[l] * 2654435761u) ^ (ctx[l] >> 15); \
@@ -90,6 +163,7 @@ __global__ void __launch_bounds__(64) k_decode_spec(CmArgs a) {
     __shared__ uint32_t s_sid[HS ? 64 : 1];   // the selected slot of every staged Cell
     __shared__ LeafParam s_leaf[W3_MAX_LEAVES];
     __shared__ ApmParam s_apm[W3_MAX_APM];
+    __shared__ uint64_t s_board[64];   // bucket_lookup16: what the bucket's holders post to the node lanes
     if (threadIdx.x == 0) {
 #pragma unroll
         for (int k = 0; k < W3_MAX_APM; k++) s_apm[k] = a.apm[k];
@@ -127,6 +201,7 @@ __global__ void __launch_bounds__(64) k_decode_spec(CmArgs a) {
             const uint64_t hist_n = (hist64 << k) | x;
             const uint32_t t_n = t + k;
             uint32_t *slot[NL]; uint32_t val[NL], ctx[NL];
+            uint32_t ins[NL];   // bucketed exact maps: where an absent context's claim starts (bucket * 16 + first empty slot), or ~0
             uint32_t p = 32768u, best = 0u;
             uint8_t *cellp[HS ? NL : 1]; uint32_t sid[HS ? NL : 1];
             cm_u32x4 cq[HS ? NL : 1];
@@ -148,7 +223,7 @@ __global__ void __launch_bounds__(64) k_decode_spec(CmArgs a) {
             // ---- Counter-table leaves: contexts, look-ups ----
 #pragma unroll
             for (int l = 0; l < NL; l++) {
-                slot[l] = nullptr; val[l] = 0u; ctx[l] = 0u;
+                slot[l] = nullptr; val[l] = 0u; ctx[l] = 0u; ins[l] = 0xFFFFFFFFu;
                 if (lp[l].kind == 0 && !lp[l].frozen) {
                     W3_DS_COUNTER_LOOKUP
                 }
@@ -194,15 +269,26 @@ __global__ void __launch_bounds__(64) k_decode_spec(CmArgs a) {
             uint16_t *aslot[NA > 0 ? NA : 1]; int tv[NA > 0 ? NA : 1];
 #pragma unroll
             for (int s = 0; s < NA; s++) {   // APM chain (build-defined), as k_cm_nl
-                const uint32_t row = s_apm[s].ctx_kind ? (c0_n | (c1 << 8)) : c0_n;
+                // NIBBLE-MAJOR APM table (this kernel's own layout of the stage's 256 rows per previous-byte page: [17 groups][33][16 node columns]):
+                // group 0 = the first nibble's rows 1 .. 15, group 1 + h = the second nibble's 15 rows after high nibble h; the column is the node
+                // of the nibble's tree.  The 15 entries a nibble's candidates read for one j are 30 contiguous bytes, so the nibble touches the lines
+                // of the j values its candidates' probabilities fall on (confident predictions cluster at the ends) instead of 15 rows 66 bytes apart.
+                uint32_t G, col;
+                if (c0_n < 16u) { G = 0u; col = c0_n - 1u; }
+                else {
+                    const uint32_t kk2 = 27u - (uint32_t)__builtin_clz(c0_n);        // bits decoded inside the second nibble
+                    G = 1u + ((c0_n >> kk2) & 15u); col = (1u << kk2) - 1u + (c0_n & ((1u << kk2) - 1u));
+                }
+                const uint32_t page = s_apm[s].ctx_kind ? c1 : 0u;
                 const uint32_t pos = (uint32_t)((int)s_str[p >> 4] + 2048) * 32u;
                 const uint32_t j = pos >> 12, w = pos & 4095u;
-                uint16_t *tr = reinterpret_cast<uint16_t *>(blk_tbl + s_apm[s].off) + row * 33u + j;
-                uint32_t pairv;   // the two adjacent entries in one (possibly unaligned) 4-byte load
-                __builtin_memcpy(&pairv, tr, 4);
-                const uint32_t v0 = pairv & 0xFFFFu, v1 = pairv >> 16;
+                const bool rowmajor = (a.dflags & 2u) != 0u;
+                const uint32_t estride = rowmajor ? 1u : 16u;   // distance (in entries) between t[j] and t[j + 1]
+                uint16_t *tr = reinterpret_cast<uint16_t *>(blk_tbl + s_apm[s].off) +
+                               (rowmajor ? ((s_apm[s].ctx_kind ? (c0_n | (c1 << 8)) : c0_n) * 33u + j) : ((((page * 17u + G) * 33u + j) << 4) + col));
+                const uint32_t v0 = tr[0], v1 = tr[estride];
                 const uint32_t pa = (v0 * (4096u - w) + v1 * w) >> 12;
-                aslot[s] = tr + (w >> 11);
+                aslot[s] = tr + ((w >> 11) ? estride : 0u);
                 tv[s] = (int)((w >> 11) ? v1 : v0);
                 const uint32_t o = (p + 3u * pa + 2u) >> 2;
                 p = o < 1u ? 1u : o > 65535u ? 65535u : o;
@@ -250,6 +336,24 @@ __global__ void __launch_bounds__(64) k_decode_spec(CmArgs a) {
                     if (lp[l].kind != 0 || lp[l].frozen) continue;
                     const uint32_t nv = counter_update_packed(val[l], mybit);
                     if (slot[l]) { if (lp[l].use_hash) ds_st32(slot[l], nv); else pl_st32(slot[l], nv); }
+                    else if (ins[l] != 0xFFFFFFFFu) {
+                        // bucketed exact map: claim the first empty slot from where the look-up stopped — another path node of this nibble (same
+                        // bucket: the nibble's contexts share it) may be after the same one; a bucket that filled up continues in the next
+                        uint32_t *tbl = reinterpret_cast<uint32_t *>(blk_tbl + lp[l].tbl_off);
+                        const uint32_t smask = lp[l].hash_mask;   // slots are numbered bucket * 16 + slot: consecutive, wrapping with the table
+                        uint32_t h = ins[l];
+                        for (;;) {
+                            h &= smask;
+                            uint32_t key = ds_ld32(tbl + 2u * h);
+                            if (key == 0u) {
+                                uint32_t expect = 0u;
+                                __hip_atomic_compare_exchange_strong(tbl + 2u * h, &expect, ctx[l] + 1u, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                key = expect == 0u ? ctx[l] + 1u : expect;
+                            }
+                            if (key == ctx[l] + 1u) { ds_st32(tbl + 2u * h + 1u, nv); break; }
+                            h++;
+                        }
+                    }
                     else {   // claim a slot of the exact map: another path node of this nibble may be after the same empty one
                         uint32_t *tbl = reinterpret_cast<uint32_t *>(blk_tbl + lp[l].tbl_off);
                         uint32_t h = (ctx[l] * 2654435761u) ^ (ctx[l] >> 15);

@@ -308,7 +308,7 @@ extern "C" int w3_ctx_set_option(w3_ctx *ctx, int opt, int64_t value) {
         ctx->tp.slot_budget_mb = (uint32_t)value;
         return W3_OK;
     case W3_OPT_TUNE:
-        if (value < 0 || value > 0x1FFFF) return W3_E_INVALID;
+        if (value < 0 || value > 0x7FFFF) return W3_E_INVALID;
         ctx->tp.tune = (uint32_t)value;
         return W3_OK;
     case W3_OPT_FAULT_BLOCK:
@@ -575,6 +575,7 @@ static int generic_decode(w3_ctx *ctx, hipStream_t s, const ParsedSpec &ps, cons
             CmArgs ca;
             memset(&ca, 0, sizeof ca);
             ca.g = ga;
+            ca.dflags = (ctx->tp.tune >> 17) & 3u;
             if (decode_spec_covers(ca) && !(ctx->tp.variant & W3_VAR_DECODE_LANE)) {
                 launch_decode_spec(ca, cnt, s, decode_group_bits(ctx, cnt));
                 HIPCHK(ctx, hipGetLastError());
@@ -630,7 +631,8 @@ static uint64_t layout_cm(const ParsedSpec &ps, size_t block_size, CmArgs &ca) {
         ca.apm[k].ctx_kind = ps.apm[k].align;
         ca.apm[k].rate = ps.apm[k].max_bits;
         ca.apm[k].off = off;
-        off += ((ps.apm[k].align == W3_APM_ORDER1 ? 65536ull : 256ull) * 33 * 2 + 15) / 16 * 16;
+        // (272 rows per page of 256: k_decode_spec keeps the table nibble-major, 17 groups of 16 node columns — w3_decode_spec.h)
+        off += ((ps.apm[k].align == W3_APM_ORDER1 ? 256ull : 1ull) * 272 * 33 * 2 + 15) / 16 * 16;
     }
     return off;
 }
@@ -648,13 +650,15 @@ static int cm_run(w3_ctx *ctx, hipStream_t s, CmArgs &ca, uint64_t lane_stride, 
         ca.g.first_block = first; ca.g.n_lanes = cnt;
         if (!DECODE) ca.g.stripes = (uint8_t *)ctx->stripes.p + (uint64_t)first * stripe_cap;
         HIPCHK(ctx, hipMemsetAsync(ctx->tables.p, 0, (size_t)cnt * lane_stride, s));
+        const bool spec_dec = DECODE && decode_spec_covers(ca) && !(ctx->tp.variant & W3_VAR_DECODE_LANE);
+        ca.dflags = (ctx->tp.tune >> 17) & 3u;
         for (int k = 0; k < ca.n_apm; k++)
             hipLaunchKernelGGL(k_cm_init_apm, dim3(2048), dim3(256), 0, s, ca.g.tables, lane_stride, ca.apm[k].off,
-                               ca.apm[k].ctx_kind ? 65536u : 256u, cnt, ca.squash);
+                               (spec_dec && !(ca.dflags & 2u)) ? (ca.apm[k].ctx_kind ? 256u * 272u : 272u) : (ca.apm[k].ctx_kind ? 65536u : 256u), cnt, ca.squash, (spec_dec && !(ca.dflags & 2u)) ? 1u : 0u);
         bool has_slot = false;
         for (int l = 0; l < ca.g.n_leaves; l++) has_slot |= ca.g.leaf[l].kind == 1;
         const dim3 grid((cnt + 63) / 64), blk(64);
-        if (DECODE && decode_spec_covers(ca) && !(ctx->tp.variant & W3_VAR_DECODE_LANE)) launch_decode_spec(ca, cnt, s, decode_group_bits(ctx, cnt));   // (w3_decode_spec.h)
+        if (spec_dec) launch_decode_spec(ca, cnt, s, decode_group_bits(ctx, cnt));   // (w3_decode_spec.h)
         else if (!has_slot && ca.g.n_leaves <= 4) {   // Counter leaves + APM chain: all Counter loads of a step in flight together
             switch (ca.g.n_leaves) {
             case 1: hipLaunchKernelGGL((k_cm_nl<DECODE, 1>), grid, blk, 0, s, ca); break;
