@@ -102,6 +102,11 @@ def check(ctx, oracle, name, data, bs, decode=True):
             assert ctx.decode_blocks(dev(), out, lens, bs, len(data)).tobytes() == bytes(data), name + " (k_decode_spec, two-bit groups)"
         finally:
             ctx.set_tune(0)
+        ctx.set_tune(262144)             # k_decode_spec with the nibble-major table formats of large batches (bucketed exact maps, APM tables by nibble group)
+        try:
+            assert ctx.decode_blocks(dev(), out, lens, bs, len(data)).tobytes() == bytes(data), name + " (k_decode_spec, nibble-major table formats)"
+        finally:
+            ctx.set_tune(0)
     return out, lens
 
 

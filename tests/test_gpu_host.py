@@ -48,6 +48,25 @@ def test_encode_blocks_in_ragged_pieces(ctx, oracle, name):
         assert out.tobytes() == want.tobytes(), (name, pieces_of)
 
 
+def test_encode_blocks_default_piece_schedule(ctx, oracle):
+    """More than 4,096 blocks: the default schedule (a half-size first and last piece around equal pieces of at most 4,096 blocks;
+    W3_OPT_TUNE bit 19: all equal) gives the oracle's streams, like the one-piece call."""
+    bs = 64
+    data = markov_text(bs * 9001 + 17, seed=73)
+    dev, orc = mk(oracle, "best012")
+    want, wlens = oracle.encode_blocks(orc(), data, bs, nthreads=8)
+    out, lens = ctx.encode_blocks(dev(), data, bs)
+    assert ctx.timing()["n_parts"] == 4          # 9,002 blocks: pieces of 1,500 / 3,001 / 3,001 / 1,500
+    assert lens.tolist() == wlens.tolist() and out.tobytes() == want.tobytes()
+    ctx.set_tune(524288)
+    try:
+        out, lens = ctx.encode_blocks(dev(), data, bs)
+        assert ctx.timing()["n_parts"] == 3
+    finally:
+        ctx.set_tune(0)
+    assert lens.tolist() == wlens.tolist() and out.tobytes() == want.tobytes()
+
+
 def test_encode_blocks_pieces_nospace_and_lane_per_block_specs(ctx, oracle):
     """A call in pieces that runs out of room reports the size needed and the whole length table (as the one-piece call does); specs
     that w3_encode_submit runs synchronously (lane-per-block path) are one piece whatever the option says."""

@@ -127,6 +127,12 @@ def decode_both(ctx, model, out, lens, bs, n):
     finally:
         ctx.set_tune(0)
     assert a == c, "k_decode_spec: the two-bit groups and the nibble groups disagree"
+    ctx.set_tune(262144)   # k_decode_spec with the nibble-major table formats of large batches (bucketed exact maps, APM tables by nibble group)
+    try:
+        d = ctx.decode_blocks(model, out, lens, bs, n).tobytes()
+    finally:
+        ctx.set_tune(0)
+    assert a == d, "k_decode_spec: the nibble-major table formats and the round-3 formats disagree"
     return np.frombuffer(a, dtype=np.uint8)
 
 

@@ -27,7 +27,7 @@ struct CmArgs {
     const uint2   *st;        // [kStSize] {prob | next0 << 16, next1 | conf << 16}
     const int16_t *stretch;   // [4096]
     const uint16_t *squash;   // [4095] (APM table initialisation only)
-    uint32_t dflags;          // k_decode_spec table formats (W3_OPT_TUNE bits 17 / 18): bit 0 = exact maps probed slot by slot, bit 1 = APM tables row-major
+    uint32_t dflags;          // k_decode_spec table formats (W3_OPT_TUNE bits 17 / 18): bit 0 = the round-3 formats whatever the batch size, bit 1 = the nibble-major ones (default: by size)
 };
 
 // ---- Cell / Slot (hashmap.rs:31-129), byte-exact layout: 6 tag bytes + 90 state bytes ----------------

@@ -97,7 +97,7 @@ __device__ __forceinline__ void bucket_lookup16(uint32_t *tbl, uint32_t bmask, u
                         } \
                         slot[l] = tbl + idx; val[l] = pl_ld32(slot[l]); \
                     } \
-                    else if (!(a.dflags & 1u) && lp[l].hist <= W3_HIST_RAW && lp[l].align == 3u && lp[l].bits >= 6u) { \
+                    else if (NM && lp[l].hist <= W3_HIST_RAW && lp[l].align == 3u && lp[l].bits >= 6u) { \
                         /* NIBBLE-MAJOR BUCKETS of the exact map (raw history, alignment 3): the 15 candidate contexts of a nibble differ only in   \
                            the bits the nibble decodes, so they share (half, g) — hash THAT to a 128-byte bucket of 16 slots {ctx + 1, counts}: one   \
                            line per nibble and leaf instead of 15 random 8-byte probes (1.5 KB of lines, profiles/r3_decode_spec/README.md).        \
@@ -150,7 +150,12 @@ __device__ __forceinline__ void bucket_lookup16(uint32_t *tbl, uint32_t bmask, u
 // state (hashmap.rs:86-97) and looks its probability up in the state table (staged in LDS), and lane 0 walks the four path states on
 // (hashmap.rs:99-112: the packed states share bytes, so one lane writes them one after the other).  The Cell is staged in LDS for the
 // nibble (six 16-byte loads by six lanes, w3_cm.h's cmc_* helpers on the copy, six stores back).  D = 4 only.
-template <int NL, int NA, int D, bool HS = false>
+// NM = the nibble-major table formats of LARGE batches (bucketed exact maps, APM tables [group][j][node]): they cut the HBM traffic a large
+// batch is bound by (7.2 -> 3.0 TB per 1e9 B) at the price of a longer dependent chain per nibble (the look-up's LDS exchange), which is
+// what a SMALL batch — a few wavefronts per SIMD, nothing to hide latency behind — is bound by: below W3_DECODE_NM_MIN_BLOCKS the round-3
+// formats (slot-by-slot probes, row-major APM tables) stay.  A template parameter, not a run-time flag: the flag's branches alone cost the
+// small batches 18 % (profiles/r4_decode/).
+template <int NL, int NA, int D, bool HS = false, bool NM = false>
 __global__ void __launch_bounds__(64) k_decode_spec(CmArgs a) {
     constexpr uint32_t LPB = 1u << D, BPW = 64u / LPB;        // lanes per block, blocks per wavefront
     static_assert(!HS || D == 4, "slot-state leaves: one Cell per nibble");
@@ -282,8 +287,8 @@ __global__ void __launch_bounds__(64) k_decode_spec(CmArgs a) {
                 const uint32_t page = s_apm[s].ctx_kind ? c1 : 0u;
                 const uint32_t pos = (uint32_t)((int)s_str[p >> 4] + 2048) * 32u;
                 const uint32_t j = pos >> 12, w = pos & 4095u;
-                const bool rowmajor = (a.dflags & 2u) != 0u;
-                const uint32_t estride = rowmajor ? 1u : 16u;   // distance (in entries) between t[j] and t[j + 1]
+                constexpr bool rowmajor = !NM;
+                constexpr uint32_t estride = rowmajor ? 1u : 16u;   // distance (in entries) between t[j] and t[j + 1]
                 uint16_t *tr = reinterpret_cast<uint16_t *>(blk_tbl + s_apm[s].off) +
                                (rowmajor ? ((s_apm[s].ctx_kind ? (c0_n | (c1 << 8)) : c0_n) * 33u + j) : ((((page * 17u + G) * 33u + j) << 4) + col));
                 const uint32_t v0 = tr[0], v1 = tr[estride];
@@ -407,46 +412,65 @@ static inline bool decode_spec_covers(const CmArgs &ca) {
     return true;
 }
 
+#define W3_DECODE_NM_MIN_BLOCKS 8192u   // batches of at least this many blocks decode with the nibble-major table formats (measured: 4e8 B 462 against 490 MiB/s, 1e9 B 885 against 684)
+
 // up to eight leaves (the full CM has seven) and slot-state leaves: one instantiation with NL = 8, unused entries marked kind 2
-template <bool HS>
+template <bool HS, bool NM>
 static inline void launch_decode_spec_8(CmArgs ca, uint32_t cnt, hipStream_t s) {
     for (int l = ca.g.n_leaves; l < 8; l++) { ca.g.leaf[l] = LeafParam{}; ca.g.leaf[l].kind = 2; ca.g.leaf[l].frozen = 1; }
     const dim3 grid((cnt + 3u) / 4u), blk(64);
     switch (ca.n_apm) {
-    case 0: hipLaunchKernelGGL((k_decode_spec<8, 0, 4, HS>), grid, blk, 0, s, ca); break;
-    case 1: hipLaunchKernelGGL((k_decode_spec<8, 1, 4, HS>), grid, blk, 0, s, ca); break;
-    default: hipLaunchKernelGGL((k_decode_spec<8, 2, 4, HS>), grid, blk, 0, s, ca); break;
+    case 0: hipLaunchKernelGGL((k_decode_spec<8, 0, 4, HS, NM>), grid, blk, 0, s, ca); break;
+    case 1: hipLaunchKernelGGL((k_decode_spec<8, 1, 4, HS, NM>), grid, blk, 0, s, ca); break;
+    default: hipLaunchKernelGGL((k_decode_spec<8, 2, 4, HS, NM>), grid, blk, 0, s, ca); break;
     }
 }
 
-template <int NL, int D>
+template <int NL, int D, bool NM>
 static inline void launch_decode_spec_na(const CmArgs &ca, uint32_t cnt, hipStream_t s) {
     constexpr uint32_t BPW = 64u >> D;
     const dim3 grid((cnt + BPW - 1u) / BPW), blk(64);
     switch (ca.n_apm) {
-    case 0: hipLaunchKernelGGL((k_decode_spec<NL, 0, D>), grid, blk, 0, s, ca); break;
-    case 1: hipLaunchKernelGGL((k_decode_spec<NL, 1, D>), grid, blk, 0, s, ca); break;
-    default: hipLaunchKernelGGL((k_decode_spec<NL, 2, D>), grid, blk, 0, s, ca); break;
+    case 0: hipLaunchKernelGGL((k_decode_spec<NL, 0, D, false, NM>), grid, blk, 0, s, ca); break;
+    case 1: hipLaunchKernelGGL((k_decode_spec<NL, 1, D, false, NM>), grid, blk, 0, s, ca); break;
+    default: hipLaunchKernelGGL((k_decode_spec<NL, 2, D, false, NM>), grid, blk, 0, s, ca); break;
     }
 }
-// bits_per_group: 4 = the nibble (small batches: latency), 2 = half a nibble (large batches: HBM traffic)
+// table formats of this batch (the APM tables' initialisation must agree: cm_run asks the same question)
+static inline bool decode_spec_nibble_major(const CmArgs &ca, uint32_t cnt, int bits_per_group) {
+    if (bits_per_group != 4) return false;                      // (the two-bit-group variant keeps the round-3 formats)
+    if (ca.dflags & 1u) return false;                           // W3_OPT_TUNE bit 17: round-3 formats whatever the size
+    if (ca.dflags & 2u) return true;                            // bit 18: nibble-major formats whatever the size
+    return cnt >= W3_DECODE_NM_MIN_BLOCKS;
+}
+// bits_per_group: 4 = the nibble (the shipped form), 2 = half a nibble (a tested variant)
 static inline void launch_decode_spec(const CmArgs &ca, uint32_t cnt, hipStream_t s, int bits_per_group) {
-    if (decode_spec_has_slot(ca)) { launch_decode_spec_8<true>(ca, cnt, s); return; }
-    if (ca.g.n_leaves > 4) { launch_decode_spec_8<false>(ca, cnt, s); return; }
+    const bool nm = decode_spec_nibble_major(ca, cnt, bits_per_group);
+    if (decode_spec_has_slot(ca)) { if (nm) launch_decode_spec_8<true, true>(ca, cnt, s); else launch_decode_spec_8<true, false>(ca, cnt, s); return; }
+    if (ca.g.n_leaves > 4) { if (nm) launch_decode_spec_8<false, true>(ca, cnt, s); else launch_decode_spec_8<false, false>(ca, cnt, s); return; }
     if (bits_per_group == 2) {
         switch (ca.g.n_leaves) {
-        case 1: launch_decode_spec_na<1, 2>(ca, cnt, s); break;
-        case 2: launch_decode_spec_na<2, 2>(ca, cnt, s); break;
-        case 3: launch_decode_spec_na<3, 2>(ca, cnt, s); break;
-        default: launch_decode_spec_na<4, 2>(ca, cnt, s); break;
+        case 1: launch_decode_spec_na<1, 2, false>(ca, cnt, s); break;
+        case 2: launch_decode_spec_na<2, 2, false>(ca, cnt, s); break;
+        case 3: launch_decode_spec_na<3, 2, false>(ca, cnt, s); break;
+        default: launch_decode_spec_na<4, 2, false>(ca, cnt, s); break;
+        }
+        return;
+    }
+    if (nm) {
+        switch (ca.g.n_leaves) {
+        case 1: launch_decode_spec_na<1, 4, true>(ca, cnt, s); break;
+        case 2: launch_decode_spec_na<2, 4, true>(ca, cnt, s); break;
+        case 3: launch_decode_spec_na<3, 4, true>(ca, cnt, s); break;
+        default: launch_decode_spec_na<4, 4, true>(ca, cnt, s); break;
         }
         return;
     }
     switch (ca.g.n_leaves) {
-    case 1: launch_decode_spec_na<1, 4>(ca, cnt, s); break;
-    case 2: launch_decode_spec_na<2, 4>(ca, cnt, s); break;
-    case 3: launch_decode_spec_na<3, 4>(ca, cnt, s); break;
-    default: launch_decode_spec_na<4, 4>(ca, cnt, s); break;
+    case 1: launch_decode_spec_na<1, 4, false>(ca, cnt, s); break;
+    case 2: launch_decode_spec_na<2, 4, false>(ca, cnt, s); break;
+    case 3: launch_decode_spec_na<3, 4, false>(ca, cnt, s); break;
+    default: launch_decode_spec_na<4, 4, false>(ca, cnt, s); break;
     }
 }
 

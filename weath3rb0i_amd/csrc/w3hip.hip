@@ -308,7 +308,7 @@ extern "C" int w3_ctx_set_option(w3_ctx *ctx, int opt, int64_t value) {
         ctx->tp.slot_budget_mb = (uint32_t)value;
         return W3_OK;
     case W3_OPT_TUNE:
-        if (value < 0 || value > 0x7FFFF) return W3_E_INVALID;
+        if (value < 0 || value > 0xFFFFF) return W3_E_INVALID;
         ctx->tp.tune = (uint32_t)value;
         return W3_OK;
     case W3_OPT_FAULT_BLOCK:
@@ -652,9 +652,10 @@ static int cm_run(w3_ctx *ctx, hipStream_t s, CmArgs &ca, uint64_t lane_stride, 
         HIPCHK(ctx, hipMemsetAsync(ctx->tables.p, 0, (size_t)cnt * lane_stride, s));
         const bool spec_dec = DECODE && decode_spec_covers(ca) && !(ctx->tp.variant & W3_VAR_DECODE_LANE);
         ca.dflags = (ctx->tp.tune >> 17) & 3u;
+        const bool nm_tables = spec_dec && decode_spec_nibble_major(ca, cnt, decode_group_bits(ctx, cnt));   // (the APM tables' layout follows the kernel's)
         for (int k = 0; k < ca.n_apm; k++)
             hipLaunchKernelGGL(k_cm_init_apm, dim3(2048), dim3(256), 0, s, ca.g.tables, lane_stride, ca.apm[k].off,
-                               (spec_dec && !(ca.dflags & 2u)) ? (ca.apm[k].ctx_kind ? 256u * 272u : 272u) : (ca.apm[k].ctx_kind ? 65536u : 256u), cnt, ca.squash, (spec_dec && !(ca.dflags & 2u)) ? 1u : 0u);
+                               nm_tables ? (ca.apm[k].ctx_kind ? 256u * 272u : 272u) : (ca.apm[k].ctx_kind ? 65536u : 256u), cnt, ca.squash, nm_tables ? 1u : 0u);
         bool has_slot = false;
         for (int l = 0; l < ca.g.n_leaves; l++) has_slot |= ca.g.leaf[l].kind == 1;
         const dim3 grid((cnt + 63) / 64), blk(64);
@@ -1517,8 +1518,25 @@ extern "C" int w3_encode_blocks(w3_ctx *ctx, const w3_model_spec *spec, const ui
         sum.n_coder_launches += t.n_coder_launches; sum.coder_bytes += t.coder_bytes; sum.predict_bytes += t.predict_bytes;
         sum.n_recoded_blocks += t.n_recoded_blocks; sum.n_slot_launches += t.n_slot_launches; sum.n_lds_faults += t.n_lds_faults;
     };
-    for (size_t b0 = 0; b0 < nb; b0 += cb) {
-        const size_t lo = b0 * block_size, hi = std::min(n, (b0 + cb) * block_size);
+    // Piece schedule.  W3_OPT_HOST_CHUNK_BLOCKS / one piece: uniform.  Default for large inputs: a HALF-size first piece (the call's first
+    // H2D and first predict phase overlap nothing) and a half-size last piece (neither does the last piece's predict + APM; its coder
+    // chain is 16.6 ms whatever its size) around the equal pieces — W3_OPT_TUNE bit 19 keeps them all equal.
+    std::vector<size_t> cuts;   // piece k = blocks [cuts[k], cuts[k + 1])
+    cuts.push_back(0);
+    if (cb < nb && !ctx->host_chunk_blocks && !(ctx->tp.tune & 524288u) && cb >= 512) {
+        const size_t half = cb / 2;
+        size_t b = half;
+        cuts.push_back(b);
+        while (nb - b > cb + half) { b += cb; cuts.push_back(b); }
+        if (nb - b > half) { cuts.push_back(nb - std::min(half, (nb - b) / 2)); }
+        cuts.push_back(nb);
+    } else {
+        for (size_t b = cb; b < nb; b += cb) cuts.push_back(b);
+        cuts.push_back(nb);
+    }
+    for (size_t k = 0; k + 1 < cuts.size(); k++) {
+        const size_t b0 = cuts[k];
+        const size_t lo = b0 * block_size, hi = std::min(n, cuts[k + 1] * block_size);
         // (an error that is not "out of room" ends the call: nothing more is submitted, what is in flight is drained below)
         if (first_err != W3_OK && first_err != W3_E_NOSPACE) break;
         while (qn >= host_depth(spec, hi - lo, block_size)) wait_oldest();
