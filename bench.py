@@ -641,7 +641,7 @@ def main():
                           "achieved": round(nbytes / (ms * 1e-3) / 1e9, 2), "frac": round(nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 5),
                           "traffic": tr, "traffic_source": src})
         dom = max(table, key=lambda r: r["avg_launch_ms"])   # the time-dominant kernel
-        # The same choice among the kernels of the ONE-CALL-AT-A-TIME leg (nothing beside any launch): stable from round to round,
+        # The same choice among the kernels of the ONE-CALL-AT-A-TIME leg (no other call's kernels beside any launch): stable from round to round,
         # where the overlapped pick flips with whatever the pipeline stretches (round 2: k_apm0, round 3: the coder beside the rank kernels).
         solo = None
         if sync_line and sync_line.get("_rows"):
@@ -652,7 +652,8 @@ def main():
                     "frac": round(sbytes / (sms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 5), "traffic": str_, "traffic_source": ssrc, "avg_launch_ms": round(sms, 4),
                     "algorithmic_bytes_per_launch": int(sbytes),
                     "kernels": [{"kernel": r[0].split(" (")[0], "ms": round(r[1], 3), "frac": round(r[2] / (r[1] * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)} for r in srows],
-                    "chosen_by": "longest average launch of the one-call-at-a-time leg (3 synchronous calls, no other kernel beside any launch)"}
+                    "chosen_by": "longest average launch of the one-call-at-a-time leg (3 synchronous calls: no other CALL's kernels beside any launch; inside a call the "
+                                 "time-ordered leaf's kernel runs on the side stream beside the first rank kernel, which is why that launch is the longest)"}
         elif sync_line:
             sync_line.pop("_rows", None)
         coder_ms = acc.get("coder_ms", 0.0) / args.steps

@@ -49,21 +49,14 @@ def test_encode_blocks_in_ragged_pieces(ctx, oracle, name):
 
 
 def test_encode_blocks_default_piece_schedule(ctx, oracle):
-    """More than 4,096 blocks: the default schedule (a half-size first and last piece around equal pieces of at most 4,096 blocks;
-    W3_OPT_TUNE bit 19: all equal) gives the oracle's streams, like the one-piece call."""
+    """More than 4,096 blocks: the default schedule (equal pieces of at most 4,096 blocks) gives the oracle's streams, like the
+    one-piece call."""
     bs = 64
     data = markov_text(bs * 9001 + 17, seed=73)
     dev, orc = mk(oracle, "best012")
     want, wlens = oracle.encode_blocks(orc(), data, bs, nthreads=8)
     out, lens = ctx.encode_blocks(dev(), data, bs)
-    assert ctx.timing()["n_parts"] == 4          # 9,002 blocks: pieces of 1,500 / 3,001 / 3,001 / 1,500
-    assert lens.tolist() == wlens.tolist() and out.tobytes() == want.tobytes()
-    ctx.set_tune(524288)
-    try:
-        out, lens = ctx.encode_blocks(dev(), data, bs)
-        assert ctx.timing()["n_parts"] == 3
-    finally:
-        ctx.set_tune(0)
+    assert ctx.timing()["n_parts"] == 3          # 9,002 blocks: pieces of 3,001 / 3,001 / 3,000
     assert lens.tolist() == wlens.tolist() and out.tobytes() == want.tobytes()
 
 
