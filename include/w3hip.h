@@ -151,7 +151,10 @@ enum {
                            S = the sample size.  A full in-round check needs a second returning LDS atomic per add (+6 ms per
                            step) and was not built.  Full coverage = decode the output (w3_decode_blocks_device shares no kernel with the
                            predict phase; bench.py does that for every block of its last step).  0 = off */
-    W3_OPT_TUNE = 11,   /* scheduling experiments of the submit / wait pipeline (bit mask; output is identical whatever is set) */
+    W3_OPT_TUNE = 11,   /* scheduling / layout experiments (bit mask; output is identical whatever is set).  Bits 0 – 14: the submit / wait
+                           pipeline's arrangements and the slot replay's shapes (HISTORY.md 2.8); 15: rank kernels with eight wavefronts per half
+                           CU; 16: host-buffer copies on two streams of their own instead of the context's stream; 17 / 18: k_decode_spec with
+                           the round-3 table formats / with the nibble-major ones whatever the batch size (default: by size) */
     W3_OPT_FAULT_BLOCK = 10, /* test hook, with W3_OPT_VARIANT bit 32: the one block the injected fault hits (-1 = every block, default) */
     W3_OPT_HOST_CHUNK_BLOCKS = 12 /* w3_encode_blocks: blocks per pipelined piece of a host-buffer call (0 = default: equal pieces of at most
                            4,096 blocks; tests use small values to get ragged pieces) */
