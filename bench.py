@@ -600,6 +600,8 @@ def main():
         finally:
             dctx.close()
             torch.cuda.empty_cache()
+        if not decode["roundtrip_all_blocks"]:   # a rate for streams that do not decode is not a result: no line is printed
+            raise SystemExit("bench.py: the device round trip of the last timed step's output FAILED (model %s, %d bytes): encoder and decoder disagree" % (args.model, n))
 
     host_path = None
     if extras and not args.no_host_path:

@@ -175,7 +175,10 @@ size_t      w3_max_compressed_size(size_t n, size_t block_size);
  * w3_encode_blocks is PIPELINED inside the call (ABI v8): inputs of more than 4,096 blocks are cut into equal pieces of whole
  * blocks, each a w3_encode_host_submit call (below) — piece k+1's input crosses PCIe while piece k is encoded and piece k-1's
  * streams travel back; the output is byte-identical to the one-piece call's.  `in` / `out` may be pageable or pinned
- * (hipHostMalloc / hipHostRegister) memory; pinned buffers make the copies asynchronous.                                    */
+ * (hipHostMalloc / hipHostRegister) memory; pinned buffers make the copies asynchronous.
+ * Size limit of ONE call on one device (every encode / decode / predict entry point): n < 2^32 - 4096 bytes, W3_E_UNSUPPORTED above
+ * (a dispatch counts its work-items in 32 bits and the per-byte kernels use one per input byte).  Blocks are independent: a
+ * larger input is split by the caller at block boundaries; w3_encode_sharded's limit applies to each device's shard.            */
 int w3_encode_blocks(w3_ctx *ctx, const w3_model_spec *spec,
                      const uint8_t *in, size_t n, size_t block_size,
                      uint8_t *out, size_t out_cap, size_t *out_len, uint32_t *block_lens);

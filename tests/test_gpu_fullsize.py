@@ -36,6 +36,14 @@ def models(oracle, name):
         for order in (1, 2, 3, 4):
             t = oracle.BestOfTwoModel(t, oracle.SlotModel(order, 14))
         return w3.full_cm(), oracle.APM(oracle.APM(t, 0, 7), 1, 6)
+    if name == "ac20":             # bin/entropy-hashing-ac (book1.log:139): one wide leaf keyed by ACHistory hashes (k_achash32 -> k_predict_wave)
+        book1 = [1, 50188, 62497, 15819, 22545, 31499, 22988, 29616]
+        return (w3.OrderNEntropy(20, 3, w3.ACHistory(17, w3.StationaryModel.for_book1())),
+                oracle.OrderNEntropy(20, 3, oracle.ACHistory(17, oracle.StationaryModel.from_table(book1))))
+    if name == "huff19":           # the same with HuffHistory keys (k_huffkeys<true>)
+        from tests.test_gpu_parity import huff_pair
+        dev_h, orc_t = huff_pair(oracle, "text")
+        return w3.OrderNEntropy(19, 3, dev_h), oracle.OrderNEntropy(19, 3, oracle.HuffHistory(tables=orc_t))
     return o012(w3), o012(oracle)
 
 
@@ -106,3 +114,17 @@ def test_silesia_size_256k_blocks_full_cm(ctx, oracle):
     host = synth.mixed(211_938_580, seed=2)
     nb = (len(host) + 262143) // 262144
     check_properties(ctx, oracle, "fullcm", host, 262144, [0, 403, nb - 1], (200, 204))
+
+
+@pytest.mark.parametrize("name", ["ac20", "huff19"])
+def test_keyed_leaf_beyond_2_pow_32_steps(ctx, oracle, name):
+    """More than 2^32 bit-steps in one call (n > 2^29 bytes) with a leaf whose contexts are precomputed per step: a dispatch counts its
+    work-items in 32 bits, and k_achash32 launched as one thread per step covered only 8 n mod 2^32 of them until round 4 (every step
+    after those coded with stale keys: streams that still decoded to garbage only, found by a 1e9-byte decode run).  Sampled blocks on
+    both sides of the 2^32nd step against the oracle, a sub-range re-encoded alone, and the round trip of that range."""
+    n = (1 << 29) + 5 * 65536 + 123
+    host = synth.text(n, seed=5)
+    nb = (n + 65535) // 65536
+    wrap = (8 * n - (1 << 32)) // 8 // 65536   # the block holding step 8 n mod 2^32: the first one the old launch left out
+    ratio = check_properties(ctx, oracle, name, host, 65536, [0, wrap - 1, wrap, wrap + 1, 4099, nb - 2, nb - 1], (8000, 8000 + 24))
+    assert 0.2 < ratio < 0.7

@@ -662,6 +662,10 @@ def test_nospace_and_errors(ctx):
     with pytest.raises(w3.W3Error) as e:
         ctx.encode_blocks(w3.Order0(), data, 0)
     assert e.value.code == L.W3_E_INVALID
+    # one call handles less than 4 GiB (a dispatch counts work-items in 32 bits): refused before any buffer is touched
+    rc = ctx.lib.w3_encode_blocks(ctx.h, C.byref(spec), data.ctypes.data_as(C.c_void_p), 1 << 32, 65536,
+                                  out.ctypes.data_as(C.c_void_p), 100, C.byref(olen), lens.ctypes.data_as(C.c_void_p))
+    assert rc == L.W3_E_UNSUPPORTED and b"4 GiB" in ctx.lib.w3_last_error(ctx.h)
 
 
 def test_decode_rejects_inflated_length_table(ctx):

@@ -136,7 +136,7 @@ __device__ __forceinline__ void bucket_lookup16(uint32_t *tbl, uint32_t bmask, u
                             const uint64_t kv = ds_ld64(reinterpret_cast<const uint64_t *>(tbl + 2u * h)); \
                             const uint32_t key = (uint32_t)kv; \
                             if (key == ctx[l] + 1u) { slot[l] = tbl + 2u * h + 1u; val[l] = (uint32_t)(kv >> 32); break; } \
-                            if (key == 0u) break; \
+                            if (key == 0u) { if constexpr (NM) ins[l] = h; break; }   /* absent: a path node claims from here on */ \
                             h++; \
                         } \
                     }
@@ -335,31 +335,41 @@ __global__ void __launch_bounds__(64) k_decode_spec(CmArgs a) {
                 for (int l = 0; l < NL; l++)
                     if (lp[l].kind == 1 && r < 6u) *reinterpret_cast<cm_u32x4 *>(cellp[l] + 16u * r) = s_cell[r][grp * 8u + (uint32_t)l];
             }
+            uint32_t claim_rank[NL];
+#pragma unroll
+            for (int l = 0; l < NL; l++) {   // (wave-uniform conditions: every lane takes part in the ballots)
+                claim_rank[l] = 0u;
+                if (NM && lp[l].kind == 0 && !lp[l].frozen && lp[l].use_hash && lp[l].hist <= W3_HIST_RAW && lp[l].align == 3u && lp[l].bits >= 6u) {   // a bucketed map
+                    const uint32_t claimers = (uint32_t)(__ballot(on && slot[l] == nullptr && ins[l] != 0xFFFFFFFFu) >> row0) & 0xFFFFu;
+                    claim_rank[l] = (uint32_t)__popc(claimers & ((1u << r) - 1u));
+                }
+            }
             if (on) {
 #pragma unroll
                 for (int l = 0; l < NL; l++) {
                     if (lp[l].kind != 0 || lp[l].frozen) continue;
                     const uint32_t nv = counter_update_packed(val[l], mybit);
                     if (slot[l]) { if (lp[l].use_hash) ds_st32(slot[l], nv); else pl_st32(slot[l], nv); }
-                    else if (ins[l] != 0xFFFFFFFFu) {
-                        // bucketed exact map: claim the first empty slot from where the look-up stopped — another path node of this nibble (same
-                        // bucket: the nibble's contexts share it) may be after the same one; a bucket that filled up continues in the next
-                        uint32_t *tbl = reinterpret_cast<uint32_t *>(blk_tbl + lp[l].tbl_off);
-                        const uint32_t smask = lp[l].hash_mask;   // slots are numbered bucket * 16 + slot: consecutive, wrapping with the table
-                        uint32_t h = ins[l];
+                    else if (NM) {
+                        // The kernels of large batches claim with ONE 8-byte compare-and-swap {context + 1, counts} at the slot the look-up found
+                        // empty — no load first, no separate store of the counts (the claim was three dependent round trips on the nibble's
+                        // critical path).  Bucketed maps: the path nodes of a nibble that claim are new contexts of ONE family, i.e. of one bucket,
+                        // and a bucket fills from slot 0 without holes, so node k takes the k-th empty slot (claim_rank; 0 for a hashed map, where
+                        // a probe ends at the first empty slot and none may be skipped) instead of racing for the first.  A slot that is taken
+                        // after all (a full bucket continues in the next one; another context hashed there since the look-up) sends the claim on.
+                        // Measured at 1e9 B: bench model 839 -> 1,012 - 1,024 MiB/s, Order0+1+2 1,019 -> 1,221 (profiles/r4_decode/decode_rates_claim_variants.txt).
+                        uint64_t *tbl64 = reinterpret_cast<uint64_t *>(blk_tbl + lp[l].tbl_off);
+                        const uint64_t mine = (uint64_t)(ctx[l] + 1u) | ((uint64_t)nv << 32);
+                        uint32_t h = ins[l] + claim_rank[l];   // slots are numbered bucket * 16 + slot: consecutive, wrapping with the table
                         for (;;) {
-                            h &= smask;
-                            uint32_t key = ds_ld32(tbl + 2u * h);
-                            if (key == 0u) {
-                                uint32_t expect = 0u;
-                                __hip_atomic_compare_exchange_strong(tbl + 2u * h, &expect, ctx[l] + 1u, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                                key = expect == 0u ? ctx[l] + 1u : expect;
-                            }
-                            if (key == ctx[l] + 1u) { ds_st32(tbl + 2u * h + 1u, nv); break; }
+                            h &= lp[l].hash_mask;
+                            uint64_t expect = 0ull;
+                            if (__hip_atomic_compare_exchange_strong(tbl64 + h, &expect, mine, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
                             h++;
                         }
                     }
-                    else {   // claim a slot of the exact map: another path node of this nibble may be after the same empty one
+                    else {   // the kernels of small batches (round-3 formats): probe again and claim; another path node of this nibble may be after
+                             // the same empty slot.  (The one-CAS claim was measured here too: 11% SLOWER, 182 -> 163 MiB/s at 1e8 B, 565 -> 500 at 4e8.)
                         uint32_t *tbl = reinterpret_cast<uint32_t *>(blk_tbl + lp[l].tbl_off);
                         uint32_t h = (ctx[l] * 2654435761u) ^ (ctx[l] >> 15);
                         for (;;) {

@@ -170,30 +170,33 @@ struct Hash32Args {
 };
 
 __global__ void __launch_bounds__(256) k_achash32(Hash32Args a) {
-    const uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;   // step index over the whole input: g = 8 * byte + j
-    if (g >= a.n * 8u) return;
-    const uint64_t pos = g >> 3;
-    const uint32_t j = (uint32_t)g & 7u;
-    const uint64_t b = pos / a.block_size;
-    const uint32_t i = (uint32_t)(pos - b * a.block_size);
-    const uint8_t *blk = a.in + b * a.block_size;
-    // the last 64 bits before bit j of byte i, newest at bit 0 (zeros before the block start)
-    uint64_t hist = 0;
-    for (uint32_t k = 1; k <= 8 && k <= i; k++) hist |= (uint64_t)blk[i - k] << (8 * (k - 1));
-    hist = (hist << j) | (uint64_t)(blk[i] >> (8u - j));
-    uint32_t p32t[8], rot[8];
+    // step index over the whole input: g = 8 * byte + j.  A grid-stride loop: an AQL dispatch counts its work-items in 32 bits, so a launch
+    // of one thread per step would silently cover only 8 n mod 2^32 steps of an input of 2^29 bytes or more (it did until round 4:
+    // tests/test_gpu_parity.py::test_keyed_leaf_beyond_2_pow_32_steps).
+    for (uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; g < a.n * 8u; g += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t pos = g >> 3;
+        const uint32_t j = (uint32_t)g & 7u;
+        const uint64_t b = pos / a.block_size;
+        const uint32_t i = (uint32_t)(pos - b * a.block_size);
+        const uint8_t *blk = a.in + b * a.block_size;
+        // the last 64 bits before bit j of byte i, newest at bit 0 (zeros before the block start)
+        uint64_t hist = 0;
+        for (uint32_t k = 1; k <= 8 && k <= i; k++) hist |= (uint64_t)blk[i - k] << (8 * (k - 1));
+        hist = (hist << j) | (uint64_t)(blk[i] >> (8u - j));
+        uint32_t p32t[8], rot[8];
 #pragma unroll
-    for (int k = 0; k < 8; k++) p32t[k] = a.table[k] ? ((uint32_t)a.table[k] << 16) : 1u;   // lerp operand, arithmetic_coder.rs:111
-    // StationaryModel::predict walks the bit positions backwards from j: the r-th coded history bit uses table[(j - 1 - r) & 7]
+        for (int k = 0; k < 8; k++) p32t[k] = a.table[k] ? ((uint32_t)a.table[k] << 16) : 1u;   // lerp operand, arithmetic_coder.rs:111
+        // StationaryModel::predict walks the bit positions backwards from j: the r-th coded history bit uses table[(j - 1 - r) & 7]
 #pragma unroll
-    for (int r = 0; r < 8; r++) {
-        const uint32_t k = (j + 7u - (uint32_t)r) & 7u;
-        rot[r] = k == 0 ? p32t[0] : k == 1 ? p32t[1] : k == 2 ? p32t[2] : k == 3 ? p32t[3] : k == 4 ? p32t[4] : k == 5 ? p32t[5] : k == 6 ? p32t[6] : p32t[7];
+        for (int r = 0; r < 8; r++) {
+            const uint32_t k = (j + 7u - (uint32_t)r) & 7u;
+            rot[r] = k == 0 ? p32t[0] : k == 1 ? p32t[1] : k == 2 ? p32t[2] : k == 3 ? p32t[3] : k == 4 ? p32t[4] : k == 5 ? p32t[5] : k == 6 ? p32t[6] : p32t[7];
+        }
+        const uint4 sv = a.lut[((uint32_t)hist & ((1u << W3_ACHASH_LUT_BITS) - 1u)) * 8u + j];
+        ACHashState st; st.x1 = sv.x; st.x2 = sv.y; st.hash = sv.z; st.meta = sv.w;
+        st = ac_history_hash_steps(hist, a.max_bits, rot, st, W3_ACHASH_LUT_BITS, 64);
+        a.keys32[g] = ac_hash_finish(st, a.max_bits);
     }
-    const uint4 sv = a.lut[((uint32_t)hist & ((1u << W3_ACHASH_LUT_BITS) - 1u)) * 8u + j];
-    ACHashState st; st.x1 = sv.x; st.x2 = sv.y; st.hash = sv.z; st.meta = sv.w;
-    st = ac_history_hash_steps(hist, a.max_bits, rot, st, W3_ACHASH_LUT_BITS, 64);
-    a.keys32[g] = ac_hash_finish(st, a.max_bits);
 }
 
 }  // namespace w3

@@ -391,7 +391,7 @@ static inline int twophase_predict_a(TwoPhaseWs &ws, hipStream_t s, const Parsed
                     h3.in = d_in; h3.n = n; h3.block_size = (uint32_t)block_size; h3.max_bits = nd.max_bits;
                     memcpy(h3.table, nd.table, sizeof h3.table);
                     h3.lut = (const uint4 *)ws.achash_lut; h3.keys32 = (uint32_t *)ws.keys32;
-                    hipLaunchKernelGGL(w3::k_achash32, dim3((unsigned)((n * 8 + 255) / 256)), dim3(256), 0, s, h3);
+                    hipLaunchKernelGGL(w3::k_achash32, dim3((unsigned)std::min<uint64_t>(((uint64_t)n * 8 + 255) / 256, 1u << 22)), dim3(256), 0, s, h3);   // (grid-stride: < 2^32 work-items)
                 } else {
                     if (!ws.huff) { err = "HuffHistory tables not staged"; return W3_E_HIP; }
                     w3::HuffKeyArgs hk;

@@ -719,10 +719,13 @@ static uint32_t worst_stripe_cap(size_t block_size) {
     return (uint32_t)((c + 15) / 16 * 16);
 }
 
-static int check_args(w3_ctx *ctx, size_t n, size_t block_size) {
+static int check_args(w3_ctx *ctx, size_t n, size_t block_size, bool one_device = true) {
     if (!ctx) return W3_E_INVALID;
     if (block_size == 0 || block_size > (1u << 28)) { ctx->err = "block_size must be in 1..2^28"; return W3_E_INVALID; }
     if ((n + block_size - 1) / block_size > 0x7FFFFFFFull) { ctx->err = "too many blocks"; return W3_E_INVALID; }
+    // One call handles less than 4 GiB: the per-byte kernels are launched with one work-item per input byte, and a dispatch counts its
+    // work-items in 32 bits (a larger launch would silently cover n mod 2^32 bytes).  Blocks are independent: larger inputs are split by the caller.
+    if (one_device && n >= (1ull << 32) - 4096u) { ctx->err = "one call handles less than 4 GiB of input: split larger inputs at block boundaries (blocks are independent)"; return W3_E_UNSUPPORTED; }
     return W3_OK;
 }
 
@@ -1581,7 +1584,7 @@ extern "C" int w3_encode_blocks_sharded(w3_ctx *const *ctxs, int n_ctx, const w3
             if (ctxs[q] == ctxs[r]) { ctxs[0]->err = "the same context appears twice in ctxs[] (a context is not thread-safe)"; return W3_E_INVALID; }
     }
     *out_len = 0;
-    int rc = check_args(ctxs[0], n, block_size);
+    int rc = check_args(ctxs[0], n, block_size, false);   // (the size limit of one call applies to each shard)
     if (rc) return rc;
     const size_t nb = (n + block_size - 1) / block_size;
     if (nb == 0) return w3_spec_validate(spec);
