@@ -154,7 +154,8 @@ enum {
     W3_OPT_TUNE = 11,   /* scheduling / layout experiments (bit mask; output is identical whatever is set).  Bits 0 – 14: the submit / wait
                            pipeline's arrangements and the slot replay's shapes (HISTORY.md 2.8); 15: rank kernels with eight wavefronts per half
                            CU; 16: host-buffer copies on two streams of their own instead of the context's stream; 17 / 18: k_decode_spec with
-                           the round-3 table formats / with the nibble-major ones whatever the batch size (default: by size) */
+                           the round-3 table formats / with the nibble-major ones whatever the batch size (default: by size); 19: the general k_decode_spec
+                           where the instance specialised for all-raw-history models would run */
     W3_OPT_FAULT_BLOCK = 10, /* test hook, with W3_OPT_VARIANT bit 32: the one block the injected fault hits (-1 = every block, default) */
     W3_OPT_HOST_CHUNK_BLOCKS = 12 /* w3_encode_blocks: blocks per pipelined piece of a host-buffer call (0 = default: equal pieces of at most
                            4,096 blocks; tests use small values to get ragged pieces) */

@@ -106,6 +106,9 @@ def check(ctx, oracle, name, data, bs, decode=True):
         ctx.set_tune(262144)             # k_decode_spec with the nibble-major table formats of large batches (bucketed exact maps, APM tables by nibble group)
         try:
             assert ctx.decode_blocks(dev(), out, lens, bs, len(data)).tobytes() == bytes(data), name + " (k_decode_spec, nibble-major table formats)"
+            if bs < 262144:
+                ctx.set_tune(262144 | 524288)   # ... with the general kernel where the all-raw-history instance would run
+                assert ctx.decode_blocks(dev(), out, lens, bs, len(data)).tobytes() == bytes(data), name + " (k_decode_spec, nibble-major, general kernel)"
         finally:
             ctx.set_tune(0)
     return out, lens

@@ -113,7 +113,8 @@ def check_blocks(ctx, oracle, name, data, bs, path):
 
 def decode_both(ctx, model, out, lens, bs, n, forms=4):
     """Decode with the default kernels (k_decode_spec: sixteen lanes per block, where it applies) and with the lane-per-block kernels
-    (W3_OPT_VARIANT decode_lane); both must agree."""
+    (W3_OPT_VARIANT decode_lane); both must agree — and so must k_decode_spec's other forms (two-bit groups, the nibble-major table
+    formats of large batches with the all-raw-history instance and with the general kernel)."""
     a = ctx.decode_blocks(model, out, lens, bs, n).tobytes()
     ctx.set_variant("decode_lane")
     try:
@@ -135,6 +136,12 @@ def decode_both(ctx, model, out, lens, bs, n, forms=4):
     finally:
         ctx.set_tune(0)
     assert a == d, "k_decode_spec: the nibble-major table formats and the round-3 formats disagree"
+    ctx.set_tune(262144 | 524288)   # the same with the general kernel where the all-raw-history instance would run (bit 19)
+    try:
+        e = ctx.decode_blocks(model, out, lens, bs, n).tobytes()
+    finally:
+        ctx.set_tune(0)
+    assert a == e, "k_decode_spec: the all-raw instance and the general kernel disagree"
     return np.frombuffer(a, dtype=np.uint8)
 
 

@@ -84,11 +84,12 @@ __device__ __forceinline__ void bucket_lookup16(uint32_t *tbl, uint32_t bmask, u
 // passes of the first version: 4.3 KB fetched per nibble and block, HBM-bound at 5 TB/s).  A group may start inside the nibble (D = 2: tb bits
 // of it are decoded already).  Exact maps {ctx + 1, counts}: found, or absent (the empty slot ends the probe; only a path node claims one).
 #define W3_DS_COUNTER_LOOKUP \
-                    ctx[l] = leaf_ctx(lp[l], hist_n, t_n, hs, g.huff); \
+                    if constexpr (RAW) ctx[l] = t_n == 0u ? 0u : ((((uint32_t)hist_n & lp[l].hist_mask) << 3) | (t_n & 7u)); \
+                    else ctx[l] = leaf_ctx(lp[l], hist_n, t_n, hs, g.huff); \
                     uint32_t *tbl = reinterpret_cast<uint32_t *>(blk_tbl + lp[l].tbl_off); \
                     if (!lp[l].use_hash) { \
                         uint32_t idx = ctx[l]; \
-                        if (lp[l].hist <= W3_HIST_RAW && lp[l].align == 3u && lp[l].bits >= 6u) { \
+                        if (RAW || (lp[l].hist <= W3_HIST_RAW && lp[l].align == 3u && lp[l].bits >= 6u)) { \
                             const uint32_t H = lp[l].bits - 3u; \
                             const uint32_t tb = t & 3u, kn = tb + k, xn = (((uint32_t)hist64 & ((1u << tb) - 1u)) << k) | x; \
                             const uint64_t hn = hist64 >> tb; \
@@ -97,7 +98,7 @@ __device__ __forceinline__ void bucket_lookup16(uint32_t *tbl, uint32_t bmask, u
                         } \
                         slot[l] = tbl + idx; val[l] = pl_ld32(slot[l]); \
                     } \
-                    else if (NM && lp[l].hist <= W3_HIST_RAW && lp[l].align == 3u && lp[l].bits >= 6u) { \
+                    else if (NM && (RAW || (lp[l].hist <= W3_HIST_RAW && lp[l].align == 3u && lp[l].bits >= 6u))) { \
                         /* NIBBLE-MAJOR BUCKETS of the exact map (raw history, alignment 3): the 15 candidate contexts of a nibble differ only in   \
                            the bits the nibble decodes, so they share (half, g) — hash THAT to a 128-byte bucket of 16 slots {ctx + 1, counts}: one   \
                            line per nibble and leaf instead of 15 random 8-byte probes (1.5 KB of lines, profiles/r3_decode_spec/README.md).        \
@@ -155,8 +156,9 @@ __device__ __forceinline__ void bucket_lookup16(uint32_t *tbl, uint32_t bmask, u
 // what a SMALL batch — a few wavefronts per SIMD, nothing to hide latency behind — is bound by: below W3_DECODE_NM_MIN_BLOCKS the round-3
 // formats (slot-by-slot probes, row-major APM tables) stay.  A template parameter, not a run-time flag: the flag's branches alone cost the
 // small batches 18 % (profiles/r4_decode/).
-template <int NL, int NA, int D, bool HS = false, bool NM = false>
+template <int NL, int NA, int D, bool HS = false, bool NM = false, bool RAW = false>
 __global__ void __launch_bounds__(64) k_decode_spec(CmArgs a) {
+    static_assert(!RAW || (!HS && D == 4 && NL <= 4), "RAW: all-raw-history models, nibble groups");
     constexpr uint32_t LPB = 1u << D, BPW = 64u / LPB;        // lanes per block, blocks per wavefront
     static_assert(!HS || D == 4, "slot-state leaves: one Cell per nibble");
     __shared__ int16_t s_str[NA > 0 ? 4096 : 1];
@@ -175,7 +177,8 @@ __global__ void __launch_bounds__(64) k_decode_spec(CmArgs a) {
     }
     stage_leaves(s_leaf, a.g);   // (also the barrier for the tables above)
     const GenericArgs &g = a.g;
-    const LeafParam *lp = s_leaf;
+    // up to four leaves: their parameters straight from the kernel arguments (scalar loads, hoisted out of the loops); the eight-leaf instances keep them in LDS
+    const LeafParam *lp = (RAW || (!HS && NL <= 4)) ? a.g.leaf : s_leaf;   // (eight leaves from the kernel arguments: measured, no difference)
     const uint32_t lane = threadIdx.x & 63u, r = lane & (LPB - 1u), grp = lane / LPB;
     const uint32_t bl = blockIdx.x * BPW + grp;              // block of this row of LPB lanes inside the batch
     const bool live = bl < g.n_lanes;
@@ -192,7 +195,7 @@ __global__ void __launch_bounds__(64) k_decode_spec(CmArgs a) {
     const uint32_t row0 = lane & ~(LPB - 1u);
     bool fence_each = false;   // (D = 2: consecutive groups differ in t mod 4, so even alignment 2 never reads what the group before stored)
 #pragma unroll
-    for (int l = 0; l < NL; l++) fence_each |= D == 4 && lp[l].kind == 0 && !lp[l].frozen && lp[l].align < 3;
+    for (int l = 0; l < NL; l++) fence_each |= !RAW && D == 4 && lp[l].kind == 0 && !lp[l].frozen && lp[l].align < 3;
     if (HS) fence_each = true;   // (two nibbles in a row may hash to one Cell: what the first stored must have landed)
     const bool leader = HS && r < (uint32_t)NL && lp[r < (uint32_t)NL ? r : 0u].kind == 1;
     Decoder dec;
@@ -229,7 +232,7 @@ __global__ void __launch_bounds__(64) k_decode_spec(CmArgs a) {
 #pragma unroll
             for (int l = 0; l < NL; l++) {
                 slot[l] = nullptr; val[l] = 0u; ctx[l] = 0u; ins[l] = 0xFFFFFFFFu;
-                if (lp[l].kind == 0 && !lp[l].frozen) {
+                if (RAW || (lp[l].kind == 0 && !lp[l].frozen)) {
                     W3_DS_COUNTER_LOOKUP
                 }
             }
@@ -264,8 +267,9 @@ __global__ void __launch_bounds__(64) k_decode_spec(CmArgs a) {
             bool first_leaf = true;
 #pragma unroll
             for (int l = 0; l < NL; l++) {
-                if (lp[l].kind > 1) continue;   // (NL is an upper bound: unused entries)
-                const uint32_t pl = (HS && lp[l].kind == 1) ? (s_st[val[l]].x & 0xFFFFu)      // StateTable::p, state_table/mod.rs:47-49
+                if (!RAW && lp[l].kind > 1) continue;   // (NL is an upper bound: unused entries)
+                const uint32_t pl = RAW ? counter_p_packed(val[l])
+                                  : (HS && lp[l].kind == 1) ? (s_st[val[l]].x & 0xFFFFu)      // StateTable::p, state_table/mod.rs:47-49
                                                             : lp[l].frozen ? 32768u : counter_p_packed(val[l]);
                 const uint32_t d = opinion_dist(pl);
                 if (first_leaf || d > best) { p = pl; best = d; first_leaf = false; }
@@ -305,7 +309,7 @@ __global__ void __launch_bounds__(64) k_decode_spec(CmArgs a) {
             for (uint32_t kk = 0; kk < (uint32_t)D; kk++) {
                 const uint32_t src = row0 | ((1u << kk) - 1u + xk);
                 const uint32_t psel = (uint32_t)__shfl((int)p, (int)src, 64);
-                const uint32_t bit = dec.decode(psel);
+                const uint32_t bit = RAW ? dec.decode_nz(psel) : dec.decode(psel);   // (RAW: Counter::p and the APM clamp give 1 .. 65535)
                 if (node && k == kk && x == xk) { on = true; mybit = bit; }
                 xk = (xk << 1) | bit;
             }
@@ -339,7 +343,7 @@ __global__ void __launch_bounds__(64) k_decode_spec(CmArgs a) {
 #pragma unroll
             for (int l = 0; l < NL; l++) {   // (wave-uniform conditions: every lane takes part in the ballots)
                 claim_rank[l] = 0u;
-                if (NM && lp[l].kind == 0 && !lp[l].frozen && lp[l].use_hash && lp[l].hist <= W3_HIST_RAW && lp[l].align == 3u && lp[l].bits >= 6u) {   // a bucketed map
+                if (NM && lp[l].use_hash && (RAW || (lp[l].kind == 0 && !lp[l].frozen && lp[l].hist <= W3_HIST_RAW && lp[l].align == 3u && lp[l].bits >= 6u))) {   // a bucketed map
                     const uint32_t claimers = (uint32_t)(__ballot(on && slot[l] == nullptr && ins[l] != 0xFFFFFFFFu) >> row0) & 0xFFFFu;
                     claim_rank[l] = (uint32_t)__popc(claimers & ((1u << r) - 1u));
                 }
@@ -347,7 +351,7 @@ __global__ void __launch_bounds__(64) k_decode_spec(CmArgs a) {
             if (on) {
 #pragma unroll
                 for (int l = 0; l < NL; l++) {
-                    if (lp[l].kind != 0 || lp[l].frozen) continue;
+                    if (!RAW && (lp[l].kind != 0 || lp[l].frozen)) continue;
                     const uint32_t nv = counter_update_packed(val[l], mybit);
                     if (slot[l]) { if (lp[l].use_hash) ds_st32(slot[l], nv); else pl_st32(slot[l], nv); }
                     else if (NM) {
@@ -402,7 +406,7 @@ __global__ void __launch_bounds__(64) k_decode_spec(CmArgs a) {
         }
         const uint32_t byte = c0 & 0xFFu;
         c1 = byte; c0 = 1u;
-        if (g.n_huff) hs.push_byte(g.huff, g.n_huff, byte);
+        if (!RAW && g.n_huff) hs.push_byte(g.huff, g.n_huff, byte);
         if (r == 0u) g.dout[off + i] = (uint8_t)byte;
     }
 }
@@ -422,6 +426,20 @@ static inline bool decode_spec_covers(const CmArgs &ca) {
     return true;
 }
 
+// RAW: every leaf a live Counter table over raw history with alignment 3 (Order0 / Order1 / OrderN(.., 3) and their mixes, the bench model):
+// the large-batch kernel is instantiated once more with all of that known at compile time and the leaf parameters read as scalars from the
+// kernel arguments (the general kernel keeps eight leaves' parameters in LDS and branches on each leaf's kind, history and alignment per nibble)
+static inline bool decode_spec_all_raw(const CmArgs &ca) {
+    if (ca.dflags & 4u) return false;                           // W3_OPT_TUNE bit 19: the general kernel (tests run both)
+    if (ca.g.n_leaves > 4 || ca.g.n_huff) return false;
+    for (int l = 0; l < ca.g.n_leaves; l++) {
+        const LeafParam &lp = ca.g.leaf[l];
+        if (lp.kind != 0 || lp.frozen || lp.hist > W3_HIST_RAW || lp.align != 3u || lp.bits < 6u) return false;
+    }
+    return true;
+}
+
+#define W3_DECODE_NM_MIN_BLOCKS_RAW 1024u   // ... for the all-raw-history instances (decode_spec_all_raw): never slower there (1e8 B 286 against 277 MiB/s, 4e8 B 823 against 677; equal below)
 #define W3_DECODE_NM_MIN_BLOCKS 8192u   // batches of at least this many blocks decode with the nibble-major table formats (measured: 4e8 B 462 against 490 MiB/s, 1e9 B 885 against 684)
 
 // up to eight leaves (the full CM has seven) and slot-state leaves: one instantiation with NL = 8, unused entries marked kind 2
@@ -436,14 +454,14 @@ static inline void launch_decode_spec_8(CmArgs ca, uint32_t cnt, hipStream_t s) 
     }
 }
 
-template <int NL, int D, bool NM>
+template <int NL, int D, bool NM, bool RAW = false>
 static inline void launch_decode_spec_na(const CmArgs &ca, uint32_t cnt, hipStream_t s) {
     constexpr uint32_t BPW = 64u >> D;
     const dim3 grid((cnt + BPW - 1u) / BPW), blk(64);
     switch (ca.n_apm) {
-    case 0: hipLaunchKernelGGL((k_decode_spec<NL, 0, D, false, NM>), grid, blk, 0, s, ca); break;
-    case 1: hipLaunchKernelGGL((k_decode_spec<NL, 1, D, false, NM>), grid, blk, 0, s, ca); break;
-    default: hipLaunchKernelGGL((k_decode_spec<NL, 2, D, false, NM>), grid, blk, 0, s, ca); break;
+    case 0: hipLaunchKernelGGL((k_decode_spec<NL, 0, D, false, NM, RAW>), grid, blk, 0, s, ca); break;
+    case 1: hipLaunchKernelGGL((k_decode_spec<NL, 1, D, false, NM, RAW>), grid, blk, 0, s, ca); break;
+    default: hipLaunchKernelGGL((k_decode_spec<NL, 2, D, false, NM, RAW>), grid, blk, 0, s, ca); break;
     }
 }
 // table formats of this batch (the APM tables' initialisation must agree: cm_run asks the same question)
@@ -451,7 +469,7 @@ static inline bool decode_spec_nibble_major(const CmArgs &ca, uint32_t cnt, int 
     if (bits_per_group != 4) return false;                      // (the two-bit-group variant keeps the round-3 formats)
     if (ca.dflags & 1u) return false;                           // W3_OPT_TUNE bit 17: round-3 formats whatever the size
     if (ca.dflags & 2u) return true;                            // bit 18: nibble-major formats whatever the size
-    return cnt >= W3_DECODE_NM_MIN_BLOCKS;
+    return cnt >= (decode_spec_all_raw(ca) ? W3_DECODE_NM_MIN_BLOCKS_RAW : W3_DECODE_NM_MIN_BLOCKS);
 }
 // bits_per_group: 4 = the nibble (the shipped form), 2 = half a nibble (a tested variant)
 static inline void launch_decode_spec(const CmArgs &ca, uint32_t cnt, hipStream_t s, int bits_per_group) {
@@ -467,12 +485,30 @@ static inline void launch_decode_spec(const CmArgs &ca, uint32_t cnt, hipStream_
         }
         return;
     }
+    if (nm && decode_spec_all_raw(ca)) {
+        switch (ca.g.n_leaves) {
+        case 1: launch_decode_spec_na<1, 4, true, true>(ca, cnt, s); break;
+        case 2: launch_decode_spec_na<2, 4, true, true>(ca, cnt, s); break;
+        case 3: launch_decode_spec_na<3, 4, true, true>(ca, cnt, s); break;
+        default: launch_decode_spec_na<4, 4, true, true>(ca, cnt, s); break;
+        }
+        return;
+    }
     if (nm) {
         switch (ca.g.n_leaves) {
         case 1: launch_decode_spec_na<1, 4, true>(ca, cnt, s); break;
         case 2: launch_decode_spec_na<2, 4, true>(ca, cnt, s); break;
         case 3: launch_decode_spec_na<3, 4, true>(ca, cnt, s); break;
         default: launch_decode_spec_na<4, 4, true>(ca, cnt, s); break;
+        }
+        return;
+    }
+    if (decode_spec_all_raw(ca)) {
+        switch (ca.g.n_leaves) {
+        case 1: launch_decode_spec_na<1, 4, false, true>(ca, cnt, s); break;
+        case 2: launch_decode_spec_na<2, 4, false, true>(ca, cnt, s); break;
+        case 3: launch_decode_spec_na<3, 4, false, true>(ca, cnt, s); break;
+        default: launch_decode_spec_na<4, 4, false, true>(ca, cnt, s); break;
         }
         return;
     }

@@ -217,6 +217,18 @@ struct Decoder {
         x2 = X2 | 0x80000000u;
         return bit;
     }
+    // the same for a caller whose probabilities are never 0 (no fallback inlined beside every step)
+    __device__ __forceinline__ uint32_t decode_nz(uint32_t prob) {
+        const uint32_t xmid = x1 + __umulhi(x2 - x1, prob << 16);
+        const uint32_t bit = x <= xmid;
+        if (bit) x2 = xmid; else x1 = xmid + 1u;
+        const uint32_t s = (uint32_t)__builtin_clz((x1 ^ x2) & (((~x1 | x2) << 1) | 1u));
+        const uint32_t X1 = x1 << s, X2 = ((x2 + 1u) << s) - 1u;
+        x = ((x << s) | in.get(s)) ^ (X1 & 0x80000000u);
+        x1 = X1 & 0x7FFFFFFFu;
+        x2 = X2 | 0x80000000u;
+        return bit;
+    }
     __device__ __forceinline__ uint32_t decode_general(uint32_t prob) {
         const uint32_t p32 = prob ? (prob << 16) : 1u;
         const uint32_t xmid = x1 + __umulhi(x2 - x1, p32);

@@ -308,7 +308,7 @@ extern "C" int w3_ctx_set_option(w3_ctx *ctx, int opt, int64_t value) {
         ctx->tp.slot_budget_mb = (uint32_t)value;
         return W3_OK;
     case W3_OPT_TUNE:
-        if (value < 0 || value > 0x7FFFF) return W3_E_INVALID;
+        if (value < 0 || value > 0xFFFFF) return W3_E_INVALID;
         ctx->tp.tune = (uint32_t)value;
         return W3_OK;
     case W3_OPT_FAULT_BLOCK:
@@ -575,7 +575,7 @@ static int generic_decode(w3_ctx *ctx, hipStream_t s, const ParsedSpec &ps, cons
             CmArgs ca;
             memset(&ca, 0, sizeof ca);
             ca.g = ga;
-            ca.dflags = (ctx->tp.tune >> 17) & 3u;
+            ca.dflags = (ctx->tp.tune >> 17) & 7u;
             if (decode_spec_covers(ca) && !(ctx->tp.variant & W3_VAR_DECODE_LANE)) {
                 launch_decode_spec(ca, cnt, s, decode_group_bits(ctx, cnt));
                 HIPCHK(ctx, hipGetLastError());
@@ -651,7 +651,7 @@ static int cm_run(w3_ctx *ctx, hipStream_t s, CmArgs &ca, uint64_t lane_stride, 
         if (!DECODE) ca.g.stripes = (uint8_t *)ctx->stripes.p + (uint64_t)first * stripe_cap;
         HIPCHK(ctx, hipMemsetAsync(ctx->tables.p, 0, (size_t)cnt * lane_stride, s));
         const bool spec_dec = DECODE && decode_spec_covers(ca) && !(ctx->tp.variant & W3_VAR_DECODE_LANE);
-        ca.dflags = (ctx->tp.tune >> 17) & 3u;
+        ca.dflags = (ctx->tp.tune >> 17) & 7u;
         const bool nm_tables = spec_dec && decode_spec_nibble_major(ca, cnt, decode_group_bits(ctx, cnt));   // (the APM tables' layout follows the kernel's)
         for (int k = 0; k < ca.n_apm; k++)
             hipLaunchKernelGGL(k_cm_init_apm, dim3(2048), dim3(256), 0, s, ca.g.tables, lane_stride, ca.apm[k].off,
