@@ -107,7 +107,9 @@ def check(ctx, oracle, name, data, bs, decode=True):
         try:
             assert ctx.decode_blocks(dev(), out, lens, bs, len(data)).tobytes() == bytes(data), name + " (k_decode_spec, nibble-major table formats)"
             if bs < 262144:
-                ctx.set_tune(262144 | 524288)   # ... with the general kernel where the all-raw-history instance would run
+                ctx.set_tune(524288)            # the general kernel where an instance specialised for the model's shape would run (round-3 formats)
+                assert ctx.decode_blocks(dev(), out, lens, bs, len(data)).tobytes() == bytes(data), name + " (k_decode_spec, general kernel)"
+                ctx.set_tune(262144 | 524288)   # ... and with the nibble-major formats
                 assert ctx.decode_blocks(dev(), out, lens, bs, len(data)).tobytes() == bytes(data), name + " (k_decode_spec, nibble-major, general kernel)"
         finally:
             ctx.set_tune(0)

@@ -156,9 +156,12 @@ __device__ __forceinline__ void bucket_lookup16(uint32_t *tbl, uint32_t bmask, u
 // what a SMALL batch — a few wavefronts per SIMD, nothing to hide latency behind — is bound by: below W3_DECODE_NM_MIN_BLOCKS the round-3
 // formats (slot-by-slot probes, row-major APM tables) stay.  A template parameter, not a run-time flag: the flag's branches alone cost the
 // small batches 18 % (profiles/r4_decode/).
-template <int NL, int NA, int D, bool HS = false, bool NM = false, bool RAW = false>
+template <int NL, int NA, int D, bool HS = false, bool NM = false, bool RAW = false, int KM = 0>
 __global__ void __launch_bounds__(64) k_decode_spec(CmArgs a) {
-    static_assert(!RAW || (!HS && D == 4 && NL <= 4), "RAW: all-raw-history models, nibble groups");
+    // RAW: every Counter leaf is live, over raw history, alignment 3, bits >= 6, and bit l of KM says whether leaf l is a slot-state leaf — all known
+    // at compile time (decode_spec_all_raw / launch_decode_spec)
+    static_assert(!RAW || (D == 4 && NL <= 8 && HS == (KM != 0)), "RAW: all-raw-history models, nibble groups");
+    static_assert(RAW || KM == 0, "the leaf-kind mask belongs to the RAW instances");
     constexpr uint32_t LPB = 1u << D, BPW = 64u / LPB;        // lanes per block, blocks per wavefront
     static_assert(!HS || D == 4, "slot-state leaves: one Cell per nibble");
     __shared__ int16_t s_str[NA > 0 ? 4096 : 1];
@@ -178,7 +181,9 @@ __global__ void __launch_bounds__(64) k_decode_spec(CmArgs a) {
     stage_leaves(s_leaf, a.g);   // (also the barrier for the tables above)
     const GenericArgs &g = a.g;
     // up to four leaves: their parameters straight from the kernel arguments (scalar loads, hoisted out of the loops); the eight-leaf instances keep them in LDS
-    const LeafParam *lp = (RAW || (!HS && NL <= 4)) ? a.g.leaf : s_leaf;   // (eight leaves from the kernel arguments: measured, no difference)
+    const LeafParam *lp = (RAW || (!HS && NL <= 4)) ? a.g.leaf : s_leaf;   // (the general eight-leaf instances from the kernel arguments: measured, no difference)
+    auto is_slot = [&](int l) -> bool { return RAW ? ((KM >> l) & 1) != 0 : lp[l].kind == 1; };
+    auto is_ctr = [&](int l) -> bool { return RAW ? ((KM >> l) & 1) == 0 : (lp[l].kind == 0 && !lp[l].frozen); };
     const uint32_t lane = threadIdx.x & 63u, r = lane & (LPB - 1u), grp = lane / LPB;
     const uint32_t bl = blockIdx.x * BPW + grp;              // block of this row of LPB lanes inside the batch
     const bool live = bl < g.n_lanes;
@@ -195,9 +200,9 @@ __global__ void __launch_bounds__(64) k_decode_spec(CmArgs a) {
     const uint32_t row0 = lane & ~(LPB - 1u);
     bool fence_each = false;   // (D = 2: consecutive groups differ in t mod 4, so even alignment 2 never reads what the group before stored)
 #pragma unroll
-    for (int l = 0; l < NL; l++) fence_each |= !RAW && D == 4 && lp[l].kind == 0 && !lp[l].frozen && lp[l].align < 3;
+    for (int l = 0; l < NL; l++) fence_each |= !RAW && D == 4 && is_ctr(l) && lp[l].align < 3;
     if (HS) fence_each = true;   // (two nibbles in a row may hash to one Cell: what the first stored must have landed)
-    const bool leader = HS && r < (uint32_t)NL && lp[r < (uint32_t)NL ? r : 0u].kind == 1;
+    const bool leader = HS && r < (uint32_t)NL && (RAW ? ((KM >> r) & 1u) != 0u : lp[r < (uint32_t)NL ? r : 0u].kind == 1);
     Decoder dec;
     dec.init(g.cin + g.coffs[b], live ? g.clens[b] : 0u);
 
@@ -221,7 +226,7 @@ __global__ void __launch_bounds__(64) k_decode_spec(CmArgs a) {
 #pragma unroll
                 for (int l = 0; l < NL; l++) {
                     cellp[l] = nullptr; sid[l] = 0u;
-                    if (lp[l].kind == 1) {
+                    if (is_slot(l)) {
                         const uint64_t h = slot_hash(lp[l].order, hb, tb8 != 0u, (uint32_t)hist64 & 15u);
                         cellp[l] = blk_tbl + lp[l].tbl_off + (h >> (64u - lp[l].log_cells)) * 96ull;
                         if (r < 6u) cq[l] = *reinterpret_cast<const cm_u32x4 *>(cellp[l] + 16u * r);   // (in flight beside the Counter look-ups below)
@@ -232,7 +237,7 @@ __global__ void __launch_bounds__(64) k_decode_spec(CmArgs a) {
 #pragma unroll
             for (int l = 0; l < NL; l++) {
                 slot[l] = nullptr; val[l] = 0u; ctx[l] = 0u; ins[l] = 0xFFFFFFFFu;
-                if (RAW || (lp[l].kind == 0 && !lp[l].frozen)) {
+                if (is_ctr(l)) {
                     W3_DS_COUNTER_LOOKUP
                 }
             }
@@ -241,25 +246,30 @@ __global__ void __launch_bounds__(64) k_decode_spec(CmArgs a) {
                 const uint64_t hb = hist64 >> tb8;
 #pragma unroll
                 for (int l = 0; l < NL; l++)
-                    if (lp[l].kind == 1 && r < 6u) s_cell[r][grp * 8u + (uint32_t)l] = cq[l];
+                    if (is_slot(l) && r < 6u) s_cell[r][grp * 8u + (uint32_t)l] = cq[l];
                 __asm__ volatile("" ::: "memory");
                 __builtin_amdgcn_wave_barrier();
                 // lane r of the row is the LEADER of leaf r: the slot leaves' selects run side by side (one code path, several lanes), not one
                 // after the other on lane 0
                 if (leader) {
-                    const uint64_t h = slot_hash(lp[r].order, hb, tb8 != 0u, (uint32_t)hist64 & 15u);
+                    uint32_t my_order = 0u;
+                    if constexpr (RAW) {   // (the parameters sit in scalar registers: a select over the leaves, not an index)
+#pragma unroll
+                        for (int l = 0; l < NL; l++) if (is_slot(l) && r == (uint32_t)l) my_order = lp[l].order;
+                    } else my_order = lp[r].order;
+                    const uint64_t h = slot_hash(my_order, hb, tb8 != 0u, (uint32_t)hist64 & 15u);
                     s_sid[grp * 8u + r] = cmc_select((cm_lds_u32 *)&s_cell[0][grp * 8u + r], (uint32_t)h & 0xFFFu, s_st);
                 }
                 __asm__ volatile("" ::: "memory");
                 __builtin_amdgcn_wave_barrier();
 #pragma unroll
                 for (int l = 0; l < NL; l++)
-                    if (lp[l].kind == 1) sid[l] = s_sid[grp * 8u + (uint32_t)l];
+                    if (is_slot(l)) sid[l] = s_sid[grp * 8u + (uint32_t)l];
             }
             if (HS) {
 #pragma unroll
                 for (int l = 0; l < NL; l++)
-                    if (lp[l].kind == 1) {
+                    if (is_slot(l)) {
                         CmCellRef cr; uint32_t cv;   // this node's 12-bit state from the staged Cell (Slot::get_nib path, hashmap.rs:114-121)
                         val[l] = cmc_state((cm_lds_u32 *)&s_cell[0][grp * 8u + (uint32_t)l], slot_idx(sid[l], k, x), cr, cv);
                     }
@@ -268,9 +278,9 @@ __global__ void __launch_bounds__(64) k_decode_spec(CmArgs a) {
 #pragma unroll
             for (int l = 0; l < NL; l++) {
                 if (!RAW && lp[l].kind > 1) continue;   // (NL is an upper bound: unused entries)
-                const uint32_t pl = RAW ? counter_p_packed(val[l])
-                                  : (HS && lp[l].kind == 1) ? (s_st[val[l]].x & 0xFFFFu)      // StateTable::p, state_table/mod.rs:47-49
-                                                            : lp[l].frozen ? 32768u : counter_p_packed(val[l]);
+                const uint32_t pl = (HS && is_slot(l)) ? (s_st[val[l]].x & 0xFFFFu)      // StateTable::p, state_table/mod.rs:47-49
+                                  : RAW ? counter_p_packed(val[l])
+                                  : lp[l].frozen ? 32768u : counter_p_packed(val[l]);
                 const uint32_t d = opinion_dist(pl);
                 if (first_leaf || d > best) { p = pl; best = d; first_leaf = false; }
             }
@@ -309,7 +319,7 @@ __global__ void __launch_bounds__(64) k_decode_spec(CmArgs a) {
             for (uint32_t kk = 0; kk < (uint32_t)D; kk++) {
                 const uint32_t src = row0 | ((1u << kk) - 1u + xk);
                 const uint32_t psel = (uint32_t)__shfl((int)p, (int)src, 64);
-                const uint32_t bit = RAW ? dec.decode_nz(psel) : dec.decode(psel);   // (RAW: Counter::p and the APM clamp give 1 .. 65535)
+                const uint32_t bit = (RAW && !HS) ? dec.decode_nz(psel) : dec.decode(psel);   // (Counter::p and the APM clamp give 1 .. 65535)
                 if (node && k == kk && x == xk) { on = true; mybit = bit; }
                 xk = (xk << 1) | bit;
             }
@@ -337,13 +347,13 @@ __global__ void __launch_bounds__(64) k_decode_spec(CmArgs a) {
                 __builtin_amdgcn_wave_barrier();
 #pragma unroll
                 for (int l = 0; l < NL; l++)
-                    if (lp[l].kind == 1 && r < 6u) *reinterpret_cast<cm_u32x4 *>(cellp[l] + 16u * r) = s_cell[r][grp * 8u + (uint32_t)l];
+                    if (is_slot(l) && r < 6u) *reinterpret_cast<cm_u32x4 *>(cellp[l] + 16u * r) = s_cell[r][grp * 8u + (uint32_t)l];
             }
             uint32_t claim_rank[NL];
 #pragma unroll
             for (int l = 0; l < NL; l++) {   // (wave-uniform conditions: every lane takes part in the ballots)
                 claim_rank[l] = 0u;
-                if (NM && lp[l].use_hash && (RAW || (lp[l].kind == 0 && !lp[l].frozen && lp[l].hist <= W3_HIST_RAW && lp[l].align == 3u && lp[l].bits >= 6u))) {   // a bucketed map
+                if (NM && is_ctr(l) && lp[l].use_hash && (RAW || (lp[l].hist <= W3_HIST_RAW && lp[l].align == 3u && lp[l].bits >= 6u))) {   // a bucketed map
                     const uint32_t claimers = (uint32_t)(__ballot(on && slot[l] == nullptr && ins[l] != 0xFFFFFFFFu) >> row0) & 0xFFFFu;
                     claim_rank[l] = (uint32_t)__popc(claimers & ((1u << r) - 1u));
                 }
@@ -351,7 +361,7 @@ __global__ void __launch_bounds__(64) k_decode_spec(CmArgs a) {
             if (on) {
 #pragma unroll
                 for (int l = 0; l < NL; l++) {
-                    if (!RAW && (lp[l].kind != 0 || lp[l].frozen)) continue;
+                    if (!is_ctr(l)) continue;
                     const uint32_t nv = counter_update_packed(val[l], mybit);
                     if (slot[l]) { if (lp[l].use_hash) ds_st32(slot[l], nv); else pl_st32(slot[l], nv); }
                     else if (NM) {
@@ -438,6 +448,28 @@ static inline bool decode_spec_all_raw(const CmArgs &ca) {
     }
     return true;
 }
+// ... and the one shape with slot-state leaves that has an instance of its own: models.py's full_cm() — BASELINE configs[2], Order0 / Order1 /
+// OrderN(27, 3) followed by the four slot-state orders (seven leaves, leaf-kind mask 0b1111000)
+#define W3_DS_FULLCM_NL 7
+#define W3_DS_FULLCM_KM 0x78
+static inline bool decode_spec_full_cm_shape(const CmArgs &ca) {
+    if ((ca.dflags & 4u) || ca.g.n_leaves != W3_DS_FULLCM_NL || ca.g.n_huff) return false;
+    for (int l = 0; l < W3_DS_FULLCM_NL; l++) {
+        const LeafParam &lp = ca.g.leaf[l];
+        if ((W3_DS_FULLCM_KM >> l) & 1) { if (lp.kind != 1) return false; }
+        else if (lp.kind != 0 || lp.frozen || lp.hist > W3_HIST_RAW || lp.align != 3u || lp.bits < 6u) return false;
+    }
+    return true;
+}
+template <bool NM>
+static inline void launch_decode_spec_full_cm(const CmArgs &ca, uint32_t cnt, hipStream_t s) {
+    const dim3 grid((cnt + 3u) / 4u), blk(64);
+    switch (ca.n_apm) {
+    case 0: hipLaunchKernelGGL((k_decode_spec<W3_DS_FULLCM_NL, 0, 4, true, NM, true, W3_DS_FULLCM_KM>), grid, blk, 0, s, ca); break;
+    case 1: hipLaunchKernelGGL((k_decode_spec<W3_DS_FULLCM_NL, 1, 4, true, NM, true, W3_DS_FULLCM_KM>), grid, blk, 0, s, ca); break;
+    default: hipLaunchKernelGGL((k_decode_spec<W3_DS_FULLCM_NL, 2, 4, true, NM, true, W3_DS_FULLCM_KM>), grid, blk, 0, s, ca); break;
+    }
+}
 
 #define W3_DECODE_NM_MIN_BLOCKS_RAW 1024u   // ... for the all-raw-history instances (decode_spec_all_raw): never slower there (1e8 B 286 against 277 MiB/s, 4e8 B 823 against 677; equal below)
 #define W3_DECODE_NM_MIN_BLOCKS 8192u   // batches of at least this many blocks decode with the nibble-major table formats (measured: 4e8 B 462 against 490 MiB/s, 1e9 B 885 against 684)
@@ -474,6 +506,7 @@ static inline bool decode_spec_nibble_major(const CmArgs &ca, uint32_t cnt, int 
 // bits_per_group: 4 = the nibble (the shipped form), 2 = half a nibble (a tested variant)
 static inline void launch_decode_spec(const CmArgs &ca, uint32_t cnt, hipStream_t s, int bits_per_group) {
     const bool nm = decode_spec_nibble_major(ca, cnt, bits_per_group);
+    if (bits_per_group == 4 && decode_spec_full_cm_shape(ca)) { if (nm) launch_decode_spec_full_cm<true>(ca, cnt, s); else launch_decode_spec_full_cm<false>(ca, cnt, s); return; }
     if (decode_spec_has_slot(ca)) { if (nm) launch_decode_spec_8<true, true>(ca, cnt, s); else launch_decode_spec_8<true, false>(ca, cnt, s); return; }
     if (ca.g.n_leaves > 4) { if (nm) launch_decode_spec_8<false, true>(ca, cnt, s); else launch_decode_spec_8<false, false>(ca, cnt, s); return; }
     if (bits_per_group == 2) {
