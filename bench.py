@@ -218,8 +218,8 @@ def self_launch(n_gpus, argv):
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=6)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--model", default="order012apm", help="order0 | order01 | order012 | default | order012apm (BASELINE configs[1]) | fullcm (configs[2]) | ac26 | ac20 | ordern32_1 | ordern22_2 (the reference's best published configurations)")
     ap.add_argument("--size", type=int, default=1_000_000_000, help="input bytes: of the one stream (strong) / per GPU (weak); enwik9-class = 1e9")
     ap.add_argument("--scaling", default="both", choices=["both", "weak", "strong"])
