@@ -311,6 +311,9 @@ __device__ __forceinline__ ACHashState ac_history_hash_steps(uint64_t bits, uint
         if (!__ballot(!done)) break;
 #pragma unroll
         for (int r = 0; r < 8; r++) {
+            // (every second step: a wavefront whose lanes all have their max_bits bits stops here, not at the end of the group of eight —
+            //  with small max_bits most lanes need one or two history bits beyond what the prefix table covered)
+            if ((r == 2 || r == 4 || r == 6) && !__ballot(!done)) goto all_done;
             if (!done) {
                 const uint32_t bit = (uint32_t)(bits >> (i0 + r)) & 1u;
                 const uint32_t xmid = x1 + __umulhi(x2 - x1, rot[r]);
@@ -338,6 +341,7 @@ __device__ __forceinline__ ACHashState ac_history_hash_steps(uint64_t bits, uint
             }
         }
     }
+all_done:
     ACHashState o;
     o.x1 = x1; o.x2 = x2; o.hash = hash;
     o.meta = (idx < 255u ? idx : 255u) | (rev << 8) | (done ? 0x80000000u : 0u);   // idx >= max_bits (<= 32) only ever means "done"
