@@ -122,3 +122,22 @@ def test_cli_errors(cli, tmp_path):
     bad.write_bytes(b"not a container at all....")
     r = run(cli, tmp_path, "d", str(bad))
     assert r.returncode == 1 and "Magic numbers" in r.stderr
+
+
+def test_cli_large_file_goes_through_in_pieces(cli, tmp_path):
+    """One library call handles less than 4 GiB; the CLI cuts a larger file into calls of whole blocks (W3_CALL_MAX: the piece size,
+    2 GiB by default).  Blocks are independent, so the container must be the same bytes whatever the pieces — and decode back,
+    also piece by piece."""
+    data = markov_text(300000, seed=41) + mixed_bytes(123457, seed=42)
+    (tmp_path / "a").mkdir(); (tmp_path / "b").mkdir()
+    for d in ("a", "b"):
+        (tmp_path / d / "big.txt").write_bytes(data)
+    r = run(cli, tmp_path / "a", "c", "big.txt", W3_MODEL="order012apm")
+    assert r.returncode == 0, r.stderr
+    r = run(cli, tmp_path / "b", "t", "big.txt", W3_MODEL="order012apm", W3_CALL_MAX="131072")   # seven calls (two blocks each, a ragged last one)
+    assert r.returncode == 0, r.stderr
+    assert (tmp_path / "a" / "big.bin").read_bytes() == (tmp_path / "b" / "big.bin").read_bytes()
+    assert (tmp_path / "b" / "big.orig").read_bytes() == data
+    r = run(cli, tmp_path / "a", "d", "big.bin", W3_MODEL="order012apm", W3_CALL_MAX="65536")
+    assert r.returncode == 0, r.stderr
+    assert (tmp_path / "a" / "big.orig").read_bytes() == data

@@ -9,6 +9,7 @@
 // Model: init_model() of main.rs:151 — OrderNEntropy(11,3,ACHistory(8,book1)).
 #include <sys/stat.h>
 
+#include <algorithm>
 #include <chrono>
 #include <deque>
 #include <memory>
@@ -90,6 +91,12 @@ static int die(w3_ctx *ctx, int rc, const char *what) {
 }
 
 static bool write_block_container(const std::string &out, size_t orig, const std::vector<uint32_t> &lens, size_t nb, const uint8_t *body, size_t blen);
+// bytes per w3_encode_blocks / w3_decode_blocks call: a multiple of the block size below the library's 4 GiB limit
+static size_t call_max() {
+    size_t m = (size_t)1 << 31;
+    if (const char *e = getenv("W3_CALL_MAX")) { const long long v = atoll(e); if (v > 0) m = (size_t)v; }
+    return std::max<size_t>(kBlock, m / kBlock * kBlock);
+}
 
 static int compress(w3_ctx *ctx, const std::string &in, const std::string &out) {
     std::vector<uint8_t> data;
@@ -125,9 +132,18 @@ static int compress(w3_ctx *ctx, const std::string &in, const std::string &out) 
         for (int r = 1; r < k; r++) w3_ctx_destroy(cs[r]);
         if (rc) return die(ctx, rc, "w3_encode_blocks_sharded");
     } else {
-        rc = w3_encode_blocks(ctx, &spec, data.data(), data.size(), kBlock, body.data(), body.size(), &blen, lens.data());
-        if (rc == W3_E_NOSPACE) { body.resize(blen); rc = w3_encode_blocks(ctx, &spec, data.data(), data.size(), kBlock, body.data(), body.size(), &blen, lens.data()); }
-        if (rc) return die(ctx, rc, "w3_encode_blocks");
+        // one call handles less than 4 GiB (w3hip.h): a larger file goes through in pieces of whole blocks — blocks are independent, so the
+        // container is the same bytes whatever the pieces (W3_CALL_MAX=<bytes>: the piece size, for tests)
+        const size_t piece = call_max();
+        for (size_t o = 0; o < data.size() || o == 0; o += piece) {
+            const size_t n_p = std::min(piece, data.size() - o), b0 = o / kBlock;
+            size_t len_p = 0;
+            rc = w3_encode_blocks(ctx, &spec, data.data() + o, n_p, kBlock, body.data() + blen, body.size() - blen, &len_p, lens.data() + b0);
+            if (rc == W3_E_NOSPACE) { body.resize(blen + len_p + (data.size() - o)); rc = w3_encode_blocks(ctx, &spec, data.data() + o, n_p, kBlock, body.data() + blen, body.size() - blen, &len_p, lens.data() + b0); }
+            if (rc) return die(ctx, rc, "w3_encode_blocks");
+            blen += len_p;
+            if (data.empty()) break;
+        }
     }
     return write_block_container(out, data.size(), lens, nb, body.data(), blen) ? 0 : 1;
 }
@@ -212,8 +228,19 @@ static int decompress(w3_ctx *ctx, const std::string &in, const std::string &out
     for (uint32_t b = 0; b < nb; b++) { lens[b] = (uint32_t)get_be(data.data() + 21 + 4ull * b, 4); total += lens[b]; }
     if (data.size() < 21 + 4ull * nb + total) return die(ctx, W3_E_FORMAT, "streams");
     std::vector<uint8_t> o((size_t)orig + 1);
-    int rc = w3_decode_blocks(ctx, &spec, data.data() + 21 + 4ull * nb, data.size() - (21 + 4ull * nb), lens.data(), nb, bs, orig, o.data());
-    if (rc) return die(ctx, rc, "w3_decode_blocks");
+    const uint8_t *body = data.data() + 21 + 4ull * nb;
+    const size_t per_call = bs ? std::max<size_t>(1, call_max() / bs) : nb;   // blocks per call (compress() above)
+    uint64_t coff = 0;
+    for (size_t b0 = 0; b0 < nb || b0 == 0; b0 += per_call) {
+        const size_t b1 = std::min<size_t>(nb, b0 + per_call);
+        uint64_t clen = 0;
+        for (size_t b = b0; b < b1; b++) clen += lens[b];
+        const uint64_t o0 = (uint64_t)b0 * bs, o1 = std::min<uint64_t>(orig, (uint64_t)b1 * bs);
+        int rc = w3_decode_blocks(ctx, &spec, body + coff, (size_t)clen, lens.data() + b0, b1 - b0, bs, (size_t)(o1 > o0 ? o1 - o0 : 0), o.data() + o0);
+        if (rc) return die(ctx, rc, "w3_decode_blocks");
+        coff += clen;
+        if (nb == 0) break;
+    }
     return write_file(out, o.data(), (size_t)orig) ? 0 : 1;
 }
 
