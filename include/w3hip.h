@@ -177,9 +177,11 @@ size_t      w3_max_compressed_size(size_t n, size_t block_size);
  * blocks, each a w3_encode_host_submit call (below) — piece k+1's input crosses PCIe while piece k is encoded and piece k-1's
  * streams travel back; the output is byte-identical to the one-piece call's.  `in` / `out` may be pageable or pinned
  * (hipHostMalloc / hipHostRegister) memory; pinned buffers make the copies asynchronous.
- * Size limit of ONE call on one device (every encode / decode / predict entry point): n < 2^32 - 4096 bytes, W3_E_UNSUPPORTED above
- * (a dispatch counts its work-items in 32 bits and the per-byte kernels use one per input byte).  Blocks are independent: a
- * larger input is split by the caller at block boundaries; w3_encode_sharded's limit applies to each device's shard.            */
+ * Size limit of ONE DEVICE call (the *_device, submit / wait, stats, predict and sweep entry points): n < 2^32 - 4096 bytes,
+ * W3_E_UNSUPPORTED above (a dispatch counts its work-items in 32 bits and the per-byte kernels use one per input byte).  Blocks are
+ * independent: a larger device-resident input is split by the caller at block boundaries.  The HOST-buffer calls w3_encode_blocks
+ * and w3_decode_blocks take any length, as the reference streams any length (main.rs:97-109): they go through in pieces of at most
+ * 2 GiB of input each; w3_encode_blocks_sharded's limit applies to each device's shard.                                          */
 int w3_encode_blocks(w3_ctx *ctx, const w3_model_spec *spec,
                      const uint8_t *in, size_t n, size_t block_size,
                      uint8_t *out, size_t out_cap, size_t *out_len, uint32_t *block_lens);

@@ -42,6 +42,8 @@ def test_encode_blocks_in_ragged_pieces(ctx, oracle, name):
         try:
             out, lens = ctx.encode_blocks(dev(), data, bs)
             assert ctx.timing()["n_parts"] == (42 + pieces_of - 1) // pieces_of
+            # w3_decode_blocks in runs of that many blocks (what an input above the per-call limit of 4 GiB goes through)
+            assert ctx.decode_blocks(dev(), out, lens, bs, len(data)).tobytes() == data, (name, pieces_of)
         finally:
             ctx.set_host_chunk_blocks(0)
         assert lens.tolist() == wlens.tolist(), (name, pieces_of)

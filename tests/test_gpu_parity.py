@@ -670,8 +670,8 @@ def test_nospace_and_errors(ctx):
         ctx.encode_blocks(w3.Order0(), data, 0)
     assert e.value.code == L.W3_E_INVALID
     # one call handles less than 4 GiB (a dispatch counts work-items in 32 bits): refused before any buffer is touched
-    rc = ctx.lib.w3_encode_blocks(ctx.h, C.byref(spec), data.ctypes.data_as(C.c_void_p), 1 << 32, 65536,
-                                  out.ctypes.data_as(C.c_void_p), 100, C.byref(olen), lens.ctypes.data_as(C.c_void_p))
+    rc = ctx.lib.w3_encode_blocks_device(ctx.h, C.byref(spec), C.c_void_p(256), C.c_size_t(1 << 32), C.c_size_t(65536), C.c_void_p(256), C.c_size_t(100),
+                                         C.c_void_p(256), C.c_void_p(256), None)
     assert rc == L.W3_E_UNSUPPORTED and b"4 GiB" in ctx.lib.w3_last_error(ctx.h)
 
 

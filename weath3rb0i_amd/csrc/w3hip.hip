@@ -1475,17 +1475,21 @@ extern "C" int w3_decode_blocks_device(w3_ctx *ctx, const w3_model_spec *spec, c
 //   - beyond: pieces of at most W3_FREE_RUN4_BLOCKS blocks, equal in size — the four-in-flight regime of DESIGN.md 2.8
 //     (measured at 1e9 B from pinned memory, tools/host_api_rate.py: DESIGN.md section 5).
 // W3_OPT_HOST_CHUNK_BLOCKS overrides the piece size (tests: ragged pieces; measurements).
+// blocks per device call of a host-buffer entry point whose input exceeds what one device call handles (check_args): 2 GiB worth
+static size_t host_call_cap_blocks(size_t block_size) { return std::max<size_t>(1, ((size_t)1 << 31) / block_size); }
+
 static size_t host_chunk_blocks(const w3_ctx *ctx, const ParsedSpec &ps, size_t nb, size_t block_size, size_t n) {
-    if (!submit_pipelines(ctx, ps, (uint32_t)nb, block_size, n)) return nb;
+    const size_t cap = host_call_cap_blocks(block_size);   // (a host buffer of any length goes through in pieces, as the reference streams any length: main.rs:97-109)
+    if (!submit_pipelines(ctx, ps, (uint32_t)std::min<size_t>(nb, cap), block_size, std::min(n, cap * block_size))) return std::min(nb, cap);
     if (ctx->host_chunk_blocks) return std::min<size_t>(nb, ctx->host_chunk_blocks);
     if (nb <= W3_FREE_RUN4_BLOCKS) return nb;
     const size_t pieces = (nb + W3_FREE_RUN4_BLOCKS - 1) / W3_FREE_RUN4_BLOCKS;
-    return (nb + pieces - 1) / pieces;
+    return std::min((nb + pieces - 1) / pieces, cap);
 }
 
 extern "C" int w3_encode_blocks(w3_ctx *ctx, const w3_model_spec *spec, const uint8_t *in, size_t n, size_t block_size, uint8_t *out,
                                 size_t out_cap, size_t *out_len, uint32_t *block_lens) {
-    int rc = check_args(ctx, n, block_size);
+    int rc = check_args(ctx, n, block_size, false);   // (any length: the pieces below are the device calls, each under the per-call limit)
     if (rc) return rc;
     if (out_len) *out_len = 0;
     const size_t nb = (n + block_size - 1) / block_size;
@@ -1544,11 +1548,32 @@ extern "C" int w3_encode_blocks(w3_ctx *ctx, const w3_model_spec *spec, const ui
 
 extern "C" int w3_decode_blocks(w3_ctx *ctx, const w3_model_spec *spec, const uint8_t *in, size_t in_len, const uint32_t *block_lens, size_t nblocks,
                                 size_t block_size, uint64_t orig_len, uint8_t *out) {
-    int rc = check_args(ctx, (size_t)orig_len, block_size);
+    int rc = check_args(ctx, (size_t)orig_len, block_size, false);
     if (rc) return rc;
     if ((rc = jobs_idle(ctx))) return rc;
     if (nblocks == 0 && orig_len == 0) return w3_spec_validate(spec);
     if (!in || !block_lens || !out) return W3_E_INVALID;
+    {   // any length: runs of blocks under the per-call limit, one after the other (W3_OPT_HOST_CHUNK_BLOCKS: the run length, for tests)
+        const size_t run = ctx->host_chunk_blocks ? (size_t)ctx->host_chunk_blocks : host_call_cap_blocks(block_size);
+        if (nblocks > run) {
+            if ((uint64_t)(nblocks - 1) * block_size >= orig_len) { ctx->err = "more blocks than orig_len / block_size"; return W3_E_INVALID; }
+            uint64_t coff = 0;
+            for (size_t b0 = 0; b0 < nblocks; b0 += run) {
+                const size_t b1 = std::min(nblocks, b0 + run);
+                uint64_t clen = 0;
+                for (size_t b = b0; b < b1; b++) clen += block_lens[b];
+                if (coff + clen > in_len) { ctx->err = "block length table claims more compressed bytes than the buffer holds"; return W3_E_FORMAT; }
+                const uint64_t o0 = (uint64_t)b0 * block_size, o1 = std::min<uint64_t>(orig_len, (uint64_t)b1 * block_size);
+                const uint32_t keep = ctx->host_chunk_blocks;
+                ctx->host_chunk_blocks = 0;   // (the pieces themselves are single calls)
+                rc = w3_decode_blocks(ctx, spec, in + coff, (size_t)clen, block_lens + b0, b1 - b0, block_size, o1 - o0, out + o0);
+                ctx->host_chunk_blocks = keep;
+                if (rc) return rc;
+                coff += clen;
+            }
+            return W3_OK;
+        }
+    }
     HIPCHK(ctx, hipSetDevice(ctx->device));
     uint64_t total = 0;
     for (size_t b = 0; b < nblocks; b++) total += block_lens[b];
