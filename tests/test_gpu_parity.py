@@ -116,6 +116,8 @@ def decode_both(ctx, model, out, lens, bs, n, forms=4):
     (W3_OPT_VARIANT decode_lane); both must agree — and so must k_decode_spec's other forms (two-bit groups, the nibble-major table
     formats of large batches with the all-raw-history instance and with the general kernel)."""
     a = ctx.decode_blocks(model, out, lens, bs, n).tobytes()
+    if forms <= 1:   # (blocks of several MiB: the lane-per-block decoder alone takes half a minute per block)
+        return np.frombuffer(a, dtype=np.uint8)
     ctx.set_variant("decode_lane")
     try:
         b = ctx.decode_blocks(model, out, lens, bs, n).tobytes()
@@ -778,4 +780,5 @@ def test_large_blocks_twophase(ctx, oracle, bs):
     out, lens = ctx.encode_blocks(dev(), data, bs)
     want, wlens = oracle.encode_blocks(orc(), data, bs, nthreads=8)
     assert lens.tolist() == wlens.tolist() and out.tobytes() == want.tobytes()
-    assert decode_both(ctx, dev(), out, lens, bs, len(data), forms=4 if bs <= (1 << 20) else 2).tobytes() == data
+    # (the decoders' own cross-checks run at the smaller sizes; here the round trip of the encoder's long-block streams is the point)
+    assert decode_both(ctx, dev(), out, lens, bs, len(data), forms=2 if bs <= (1 << 20) else 1).tobytes() == data
