@@ -148,8 +148,8 @@ enum {
                            RESIDUAL RISK, per call: a SYSTEMATIC change of the hardware's behaviour shows in any block and is caught by the
                            first call; a fault confined to ONE block is missed with probability 1 - v/256 (and met after at most 256 / v
                            calls); a fault that hits each block independently with probability q is missed with probability (1 - q)^S,
-                           S = the sample size.  A full in-round check needs a second returning LDS atomic per add (+6 ms per
-                           step) and was not built.  Full coverage = decode the output (w3_decode_blocks_device shares no kernel with the
+                           S = the sample size.  A full in-round check needs a second returning LDS atomic per add (measured
+                           +4.1 % of the step for the atomics alone, and no LDS left for its shadow tables) and was not built.  Full coverage = decode the output (w3_decode_blocks_device shares no kernel with the
                            predict phase; bench.py does that for every block of its last step).  0 = off */
     W3_OPT_TUNE = 11,   /* scheduling / layout experiments (bit mask; output is identical whatever is set).  Bits 0 – 14: the submit / wait
                            pipeline's arrangements and the slot replay's shapes (HISTORY.md 2.8); 15: rank kernels with eight wavefronts per half
