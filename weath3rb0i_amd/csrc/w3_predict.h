@@ -287,17 +287,23 @@ __device__ __forceinline__ uint4 mix_p(uint4 cur, uint4 nw) {
 
 // bytes c0..c3 at position i of a block (zeros before the block start: a fresh model's history is 0).
 // ONE unconditional unaligned dword load, so that batches of these loads stay in flight together
-// (hipcc waits vmcnt(0) right after any load it has to branch around).  `first` = the block starts the
-// input buffer: positions 0..2 then read bytes 0..3 and shift; otherwise they read into the previous
-// block (valid memory) and mask.  Needs n >= 4 (the host sends smaller inputs to the generic kernel).
-__device__ __forceinline__ uint32_t load_window(const uint8_t *blk, uint32_t i, bool first) {
-    const uint32_t j = first ? max(i, 3u) : i;
+// (hipcc waits vmcnt(0) right after any load it has to branch around).  Positions 0..2 of a block read into the previous block
+// (valid memory) and mask — unless the block starts within three bytes of the input buffer's start (the first block; with blocks of one
+// or two bytes also the next ones): `head` = that distance then (W3_NO_HEAD otherwise, the common case: a wave-uniform test), and the
+// load starts at the buffer's first byte instead (until round 4 only the first block did that: blocks 1 and 2 of a 1- or 2-byte block
+// size read up to two bytes BEFORE the buffer — a fault whenever the page before an allocation was not mapped).
+// Needs n >= 4 (the host sends smaller inputs to the generic kernel).
+#define W3_NO_HEAD 0xFFFFFFFFu
+__device__ __forceinline__ uint32_t window_head(uint64_t off, uint32_t reach) { return off < reach ? (uint32_t)off : W3_NO_HEAD; }
+__device__ __forceinline__ uint32_t load_window(const uint8_t *blk, uint32_t i, uint32_t head) {
+    // (no branch around the load — see above: the address moves forward by `adj` bytes when the window would start before the buffer, and the
+    //  word is shifted back by as many)
+    const uint32_t adj = head != W3_NO_HEAD ? 3u - min(head + i, 3u) : 0u;
     uint32_t raw;
-    __builtin_memcpy(&raw, blk + (int64_t)j - 3, 4);
-    uint32_t w = __builtin_bswap32(raw);   // memory order c3 c2 c1 c0 -> c0 | c1<<8 | c2<<16 | c3<<24
-    const uint32_t sh = 8u * (3u - min(i, 3u));
-    w = first ? (w >> sh) : (w & (0xFFFFFFFFu >> sh));
-    return w;
+    __builtin_memcpy(&raw, blk + (int64_t)i - 3 + adj, 4);
+    const uint32_t w = __builtin_bswap32(raw) >> (8u * adj);   // memory order c3 c2 c1 c0 -> c0 | c1<<8 | c2<<16 | c3<<24
+    const uint32_t sh = 8u * (3u - min(i, 3u));              // bytes of the window before the block start: zeros
+    return w & (0xFFFFFFFFu >> sh);
 }
 
 // ---------------------------------------------------------------------------
@@ -326,7 +332,7 @@ __global__ void __launch_bounds__(64 * NW) k_predict_small(PredictArgs a) {
         // index clamped) and parked in LDS at its end, and the rounds read them from LDS.  That keeps loads and stores from being
         // in flight together inside a batch: with both pending hipcc waits vmcnt(0)/(1) EVERY round, i.e. for the round's own
         // 16-byte store to complete (gfx9 counts loads and stores in one counter and LLVM assumes they retire out of order).
-        const bool first = off == 0;
+        const uint32_t first = window_head(off, 3u);   // (the name is history: 0 = the input's first block)
         const uint32_t last = len - 1u;
         uint32_t nw[W3_PF]; uint2 nk[W3_PF];
 #pragma unroll
@@ -414,7 +420,7 @@ __device__ __forceinline__ uint32_t wave_excl_scan_u32(uint32_t v, uint32_t *tot
 // its own HBM transaction).  hist[pass][16] is filled in ONE time-ordered sweep up front.
 
 template <int NPASS, bool C2ONLY = false>
-__device__ __forceinline__ void partition_hist(const uint8_t *blk, uint32_t len, bool first, uint32_t *hist) {
+__device__ __forceinline__ void partition_hist(const uint8_t *blk, uint32_t len, uint32_t first, uint32_t *hist) {
     const int lane = threadIdx.x & 63;
     const uint64_t gt = lane_gt_mask();
     if (lane < 16 * NPASS) hist[lane] = 0u;
@@ -473,7 +479,7 @@ __device__ __forceinline__ void partition_hist(const uint8_t *blk, uint32_t len,
 // no pass ever gathers from the input block again: with 4096 waves in flight the blocks do
 // not stay in L2 and every gathered byte cost a 64-byte fetch (212 GB of FETCH per GB input).
 template <bool FROM_INPUT>
-__device__ __forceinline__ void partition_pass4(const uint8_t *blk, uint32_t len, bool first, uint32_t back, uint32_t shift, const uint2 *src, uint2 *dst, uint32_t *bins) {
+__device__ __forceinline__ void partition_pass4(const uint8_t *blk, uint32_t len, uint32_t first, uint32_t back, uint32_t shift, const uint2 *src, uint2 *dst, uint32_t *bins) {
     const int lane = threadIdx.x & 63;
     const uint64_t gt = lane_gt_mask();
     const uint32_t last = len - 1u;
@@ -536,7 +542,7 @@ __global__ void __launch_bounds__(64) k_partition(PredictArgs a) {
         const uint8_t *blk = a.in + off;
         uint2 *out = a.rec + off;
         unsigned long long t_prev = a.dbg ? __builtin_amdgcn_s_memtime() : 0ull;
-        const bool first = off == 0;
+        const uint32_t first = window_head(off, 3u);   // (the name is history: 0 = the input's first block)
         if constexpr (NBYTES == 3) partition_hist<2, true>(blk, len, first, hist); else partition_hist<2 * NBYTES>(blk, len, first, hist);
         W3_STAMP(0);
         if constexpr (NBYTES == 3) {
@@ -622,7 +628,7 @@ __global__ void __launch_bounds__(64 * NW) k_partition8(PredictArgs a) {
         const uint8_t *blk = a.in + off;
         const uint2 *src = MODE == 3 ? a.rec_src + off : nullptr;
         uint2 *out = a.rec + off;
-        const bool first = off == 0;
+        const uint32_t first = window_head(off, 3u);   // (the name is history: 0 = the input's first block)
         const uint32_t last = len - 1u;
         unsigned long long t_prev = a.dbg ? __builtin_amdgcn_s_memtime() : 0ull;   // W3_OPT_DEBUG_STAMPS: slots 0 histogram, 1 tile load + count + scan, 2 scatter into the tile, 5 copy out, 4 splits
         // digit counts of the whole block.  digit(pos) = byte[pos - K] (K = 1: c1, 2: c2; zeros before the block start), so

@@ -66,7 +66,7 @@ __global__ void __launch_bounds__(64) k_slot_events(Slot2Args a) {
         const uint64_t off = (uint64_t)b * a.block_size;
         const uint32_t len = (uint32_t)((a.n - off) < a.block_size ? (a.n - off) : a.block_size);
         const uint8_t *blk = a.in + off;
-        const bool first = off == 0;
+        const uint32_t first = window_head(off, 7u);
 #pragma unroll
         for (int k = 0; k < 8; k++) s_hist[k * 64 + lane] = 0u;
 #pragma unroll
