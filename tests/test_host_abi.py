@@ -205,3 +205,22 @@ print("ok")
 ''' % ROOT
     p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
     assert p.returncode == 0 and p.stdout.strip().endswith("ok"), (p.returncode, p.stdout[-500:], p.stderr[-1500:])
+
+
+def test_no_launch_counts_more_than_2_pow_32_work_items():
+    """A dispatch counts its work-items in 32 bits.  One call handles less than 2^32 bytes (check_args), so a launch with one work-item
+    per BYTE fits, one per bit-step (8 n) does not: round 4 found k_achash32 covering only 8 n mod 2^32 steps above 2^29 bytes.  Lint: no
+    launch grid may be derived from 8 n (or the event / step counts 2 n, 16 n) without a cap (std::min) that makes it a grid-stride loop."""
+    import glob
+    import re
+    bad = []
+    for path in glob.glob(os.path.join(ROOT, "weath3rb0i_amd", "csrc", "*")):
+        for ln, line in enumerate(open(path, encoding="utf-8"), 1):
+            if "hipLaunchKernelGGL" not in line:
+                continue
+            grid = line.split("hipLaunchKernelGGL", 1)[1]
+            if re.search(r"\bn\s*\*\s*(8|16|2)\b|\b(8|16|2)u?\s*\*\s*n\b", grid) and "std::min" not in grid:
+                bad.append("%s:%d" % (os.path.basename(path), ln))
+    assert not bad, bad
+    src = open(os.path.join(ROOT, "weath3rb0i_amd", "csrc", "w3hip.hip"), encoding="utf-8").read()
+    assert "(1ull << 32) - 4096u" in src   # the per-call size limit the per-byte launches rely on
