@@ -285,26 +285,7 @@ __device__ __forceinline__ uint4 mix_p(uint4 cur, uint4 nw) {
     return make_uint4(mix_pair(cur.x, nw.x), mix_pair(cur.y, nw.y), mix_pair(cur.z, nw.z), mix_pair(cur.w, nw.w));
 }
 
-// bytes c0..c3 at position i of a block (zeros before the block start: a fresh model's history is 0).
-// ONE unconditional unaligned dword load, so that batches of these loads stay in flight together
-// (hipcc waits vmcnt(0) right after any load it has to branch around).  Positions 0..2 of a block read into the previous block
-// (valid memory) and mask — unless the block starts within three bytes of the input buffer's start (the first block; with blocks of one
-// or two bytes also the next ones): `head` = that distance then (W3_NO_HEAD otherwise, the common case: a wave-uniform test), and the
-// load starts at the buffer's first byte instead (until round 4 only the first block did that: blocks 1 and 2 of a 1- or 2-byte block
-// size read up to two bytes BEFORE the buffer — a fault whenever the page before an allocation was not mapped).
-// Needs n >= 4 (the host sends smaller inputs to the generic kernel).
-#define W3_NO_HEAD 0xFFFFFFFFu
-__device__ __forceinline__ uint32_t window_head(uint64_t off, uint32_t reach) { return off < reach ? (uint32_t)off : W3_NO_HEAD; }
-__device__ __forceinline__ uint32_t load_window(const uint8_t *blk, uint32_t i, uint32_t head) {
-    // (no branch around the load — see above: the address moves forward by `adj` bytes when the window would start before the buffer, and the
-    //  word is shifted back by as many)
-    const uint32_t adj = head != W3_NO_HEAD ? 3u - min(head + i, 3u) : 0u;
-    uint32_t raw;
-    __builtin_memcpy(&raw, blk + (int64_t)i - 3 + adj, 4);
-    const uint32_t w = __builtin_bswap32(raw) >> (8u * adj);   // memory order c3 c2 c1 c0 -> c0 | c1<<8 | c2<<16 | c3<<24
-    const uint32_t sh = 8u * (3u - min(i, 3u));              // bytes of the window before the block start: zeros
-    return w & (0xFFFFFFFFu >> sh);
-}
+#include "w3_window.h"   // window_head / load_window / wave_window: the input-window loads (plain C++, also compiled for the host by tests/test_window_loads.py)
 
 // ---------------------------------------------------------------------------
 // H <= 8, time order.  KEYS: key bytes come from args.keys (ACHistory leaves).

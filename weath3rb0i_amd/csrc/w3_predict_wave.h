@@ -56,17 +56,6 @@ __device__ __forceinline__ uint64_t match_value(uint32_t v) {
 
 __device__ __forceinline__ uint64_t wv_load64(const uint64_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
-// bytes [ic - 7, ic] of a block as one big-endian word (zeros before the block start: a fresh model's history is 0).  `head`: the block
-// starts that many bytes (< 7) after the input buffer's start — the window is then taken from the buffer's first eight bytes instead of
-// from memory before it (load_window, w3_predict.h) — or W3_NO_HEAD.  Needs n >= 8.
-__device__ __forceinline__ uint64_t wave_window(const uint8_t *blk, uint32_t ic, uint32_t head) {
-    uint64_t raw, W;
-    if (head != W3_NO_HEAD && head + ic < 7u) { __builtin_memcpy(&raw, blk - head, 8); W = __builtin_bswap64(raw) >> (8u * (7u - (head + ic))); }
-    else { __builtin_memcpy(&raw, blk + (int64_t)ic - 7, 8); W = __builtin_bswap64(raw); }
-    if (ic < 7u) W &= (1ull << (8u * (ic + 1u))) - 1ull;
-    return W;
-}
-
 template <bool KEYS>
 __global__ void __launch_bounds__(64) k_predict_wave(WaveArgs a) {
     const uint32_t lane = threadIdx.x & 63u;
